@@ -1,0 +1,100 @@
+"""ctypes binding of libr3d_hip.so (C ABI: include/r3d.h).
+
+The HIP library IS the product: there is no CPU fallback.  If the shared object is
+missing, or it cannot open a gfx950 device, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libr3d_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+DEPTH_U8, DEPTH_U16, DEPTH_F32 = 0, 1, 2
+F32, F64 = 0, 1
+
+_ERR_NAMES = {ERR_INVALID: "R3D_ERR_INVALID", ERR_HIP: "R3D_ERR_HIP", ERR_NOMEM: "R3D_ERR_NOMEM",
+              ERR_NODEVICE: "R3D_ERR_NODEVICE", ERR_UNSUPPORTED: "R3D_ERR_UNSUPPORTED"}
+
+
+class R3DError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (_ERR_NAMES.get(code, "R3D_ERR"), code, message))
+        self.code = code
+
+
+class R3DLibraryMissing(ImportError):
+    pass
+
+
+_vp, _i, _i64, _d, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float, C.c_size_t
+_pvp, _pi, _pd, _pf, _psz = C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_double), \
+    C.POINTER(C.c_float), C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/r3d.h declaration by declaration
+SIGNATURES = {
+    "r3d_version": (_i, []),
+    "r3d_last_error": (C.c_char_p, []),
+    "r3d_device_count": (_i, [_pi]),
+    "r3d_ctx_create": (_i, [_i, _vp, _pvp]),
+    "r3d_ctx_destroy": (_i, [_vp]),
+    "r3d_ctx_sync": (_i, [_vp]),
+    "r3d_ctx_stream": (_i, [_vp, _pvp]),
+    "r3d_ctx_set_tuning": (_i, [_vp, C.c_char_p, _i]),
+    "r3d_ctx_get_tuning": (_i, [_vp, C.c_char_p, _pi]),
+    "r3d_dev_alloc": (_i, [_vp, _sz, _pvp]),
+    "r3d_dev_free": (_i, [_vp, _vp]),
+    "r3d_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "r3d_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "r3d_memset": (_i, [_vp, _vp, _i, _sz]),
+    "r3d_timer_start": (_i, [_vp]),
+    "r3d_timer_stop": (_i, [_vp, _pf]),
+    "r3d_camera_create": (_i, [_vp, _i, _i, _d, _d, _d, _d, _pvp]),
+    "r3d_camera_destroy": (_i, [_vp]),
+    "r3d_unproject": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
+    "r3d_unproject_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
+    "r3d_fuse_frames": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),
+    "r3d_fuse_frames_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),
+    "r3d_se3_apply": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
+    "r3d_se3_apply_host": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
+    "r3d_apply_T": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
+    "r3d_apply_T_host": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
+    "r3d_icp_nn": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "r3d_icp_nn_host": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),
+    "r3d_format_ply": (_i, [_vp, _i, _i64, _vp, _sz, _psz]),
+    "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),
+    "r3d_write_xyz_txt": (_i, [C.c_char_p, _vp, _i, _i64, _vp, _i, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libr3d_hip.so once; raises R3DLibraryMissing with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise R3DLibraryMissing(
+            "%s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C 3d_reconstruction_system_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().r3d_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    if rc != OK:
+        raise R3DError(rc, last_error())
+    return rc

@@ -1,0 +1,120 @@
+"""Files on either side of the hot path, in the reference's formats.
+
+  depth PNG  -> uint8 raster      cv.imread(..., IMREAD_GRAYSCALE)        c2w:160
+  camera txt `X,Y,Z\\n`           gentxtcord                               c2w:73-83, p2c:33-43
+  world txt                       get_pointdata / local_world             c2w:103-104, icp:87-97
+  ASCII PLY                       genply                                  c2w:112-134, icp:46-68
+
+Writers go through the library's native multi-threaded formatter (byte-identical to Python's
+"%.4f" and repr()); readers are NumPy.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+from .device import xyz_code
+
+
+def read_depth_gray(path):
+    """8-bit grey raster with OpenCV's IMREAD_GRAYSCALE meaning: OpenCV if importable, else
+    PIL's 'L' conversion (identical for 8-bit single-channel PNGs, the reference's input)."""
+    try:
+        import cv2
+        img = cv2.imread(path, cv2.IMREAD_GRAYSCALE)
+    except ImportError:
+        img = None
+        try:
+            from PIL import Image
+            img = np.array(Image.open(path).convert("L"))
+        except FileNotFoundError:
+            img = None
+    if img is None:
+        raise FileNotFoundError("cannot read depth image %r" % path)
+    return np.ascontiguousarray(img)
+
+
+def read_depth_unchanged(path):
+    """IMREAD_UNCHANGED: channels in BGR order like OpenCV (p2c:133 then takes channel 1)."""
+    try:
+        import cv2
+        img = cv2.imread(path, cv2.IMREAD_UNCHANGED)
+    except ImportError:
+        from PIL import Image
+        try:
+            img = np.array(Image.open(path))
+        except FileNotFoundError:
+            img = None
+        if img is not None and img.ndim == 3 and img.shape[2] >= 3:
+            img = img[:, :, [2, 1, 0] + list(range(3, img.shape[2]))]
+    if img is None:
+        raise FileNotFoundError("cannot read image %r" % path)
+    return np.ascontiguousarray(img)
+
+
+def _cloud(xyz):
+    xyz = np.ascontiguousarray(xyz)
+    if xyz.ndim != 2 or xyz.shape[1] != 3:
+        raise ValueError("cloud must be [N,3]")
+    xyz_code(xyz.dtype)
+    return xyz
+
+
+def write_xyz_txt(path, xyz, z_raw=None, append=False):
+    """`X,Y,Z\\n` per point with repr() floats.  z_raw: optional integer raster (uint8/uint16,
+    N values) printed as the third column instead, like the reference's camera txt, where Z is
+    `str(np.uint8)`."""
+    xyz = _cloud(xyz)
+    zp, zc = None, 0
+    if z_raw is not None:
+        z_raw = np.ascontiguousarray(z_raw).reshape(-1)
+        if z_raw.shape[0] != xyz.shape[0] or z_raw.dtype not in (np.uint8, np.uint16):
+            raise ValueError("z_raw must be uint8/uint16 with one value per point")
+        zp, zc = z_raw.ctypes.data, (L.DEPTH_U8 if z_raw.dtype == np.uint8 else L.DEPTH_U16)
+    L.check(L.load().r3d_write_xyz_txt(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0],
+                                       zp, zc, 1 if append else 0))
+
+
+def format_ply(xyz):
+    """The reference PLY bytes for an [N,3] cloud."""
+    xyz = _cloud(xyz)
+    lib = L.load()
+    n = C.c_size_t()
+    L.check(lib.r3d_format_ply(xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0], None, 0, C.byref(n)))
+    buf = C.create_string_buffer(n.value)
+    L.check(lib.r3d_format_ply(xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0], buf, n.value, C.byref(n)))
+    return buf.raw[:n.value]
+
+
+def write_ply(path, xyz):
+    xyz = _cloud(xyz)
+    L.check(L.load().r3d_write_ply(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0]))
+
+
+def read_xyz_txt(path):
+    """[N,3] float64 from `X,Y,Z\\n` lines (first three comma-separated fields, as c2w:97-98)."""
+    with open(path, 'r') as f:
+        text = f.read()
+    if not text:
+        return np.empty((0, 3))
+    flat = np.array(text.replace('\n', ',').split(',')[:-1], dtype=np.float64)
+    return flat.reshape(-1, 3)
+
+
+def read_ply(path):
+    """Vertices of an ASCII PLY in the reference layout -> [N,3] float64."""
+    with open(path, 'r') as f:
+        lines = f.read().split('\n')
+    n, start = None, None
+    for i, s in enumerate(lines):
+        s = s.strip()
+        if s.startswith('element vertex'):
+            n = int(s.split()[-1])
+        if s == 'end_header':
+            start = i + 1
+            break
+    if n is None or start is None:
+        raise ValueError("%s: not a PLY with an 'element vertex' header" % path)
+    rows = [s.split()[:3] for s in lines[start:start + n]]
+    return np.array(rows, dtype=np.float64).reshape(-1, 3)

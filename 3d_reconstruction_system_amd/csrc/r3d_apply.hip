@@ -1,0 +1,195 @@
+// Apply a general 4x4 transform to an AoS xyz cloud on gfx950 (MI355X).
+//
+// Replaces local_world(flag=True) / point_camera of transfer_T_icp.py:71-97, 10-12:
+//     p' = (T . [x, y, z, 1]^T)[0:3]        (scale lives in T's 3x3 block)
+// and serves the standalone SE(3) apply of camera_to_world.py:57-59 on an existing cloud
+// (T = [Rinv | -Rinv t]).
+//
+// Roofline: HBM, 24 B/point (12 read + 12 written) for f32 clouds.
+// A 256-thread workgroup owns a tile of 1024 points = 12 KiB of xyz: it is read as tile-linear
+// 16-B pieces (1 KiB contiguous per wave instruction), staged in LDS, each lane transforms its
+// 4 points from LDS in fp64, writes them back to LDS, and the tile leaves again as linear
+// 16-B pieces.  In-place operation is safe: a tile is fully read before it is written.
+#include <type_traits>
+
+#include "r3d_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPts = 4;
+constexpr int kTile = kThreads * kPts;
+
+struct ApplyArgs {
+  const void* in;
+  void* out;
+  double T[12];  // affine: rows 0..2 of the 4x4, row-major.  SE3: Rinv row-major (9) then t (3)
+  uint64_t n;    // points
+};
+
+template <typename IT, typename OT, bool VEC, bool SE3>
+__global__ __launch_bounds__(kThreads) void apply_kernel(const ApplyArgs a) {
+  // one buffer, sized for the wider of the two element types
+  constexpr size_t kElt = sizeof(IT) > sizeof(OT) ? sizeof(IT) : sizeof(OT);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kTile * 3 * kElt];
+  IT* lin = reinterpret_cast<IT*>(lds_raw);
+  OT* lout = reinterpret_cast<OT*>(lds_raw);
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
+
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t p_base = tile * kTile;
+    const uint32_t n_pts = (uint32_t)min((uint64_t)kTile, a.n - p_base);
+    const uint32_t n_elts = n_pts * 3;
+    const IT* src = static_cast<const IT*>(a.in) + p_base * 3;
+    OT* dst = static_cast<OT*>(a.out) + p_base * 3;
+
+    // ---- tile -> LDS ----
+    if (VEC) {
+      constexpr uint32_t kPerPiece = 16 / sizeof(IT);
+      const uint32_t n_pieces = n_elts / kPerPiece;
+      using V = typename std::conditional<sizeof(IT) == 4, float4, double2>::type;
+      for (uint32_t q = tid; q < n_pieces; q += kThreads)
+        reinterpret_cast<V*>(lin)[q] = reinterpret_cast<const V*>(src)[q];
+      for (uint32_t e = n_pieces * kPerPiece + tid; e < n_elts; e += kThreads) lin[e] = src[e];
+    } else {
+      for (uint32_t e = tid; e < n_elts; e += kThreads) lin[e] = src[e];
+    }
+    __syncthreads();
+
+    // ---- transform this lane's 4 points (fp64, reference order: row . [x y z 1]) ----
+    double w[kPts * 3];
+    const uint32_t first = tid * kPts;
+#pragma unroll
+    for (int k = 0; k < kPts; ++k) {
+      if (first + k < n_pts) {
+        const double x = (double)lin[(first + k) * 3 + 0];
+        const double y = (double)lin[(first + k) * 3 + 1];
+        const double z = (double)lin[(first + k) * 3 + 2];
+        if (SE3) {  // Rinv . (p - t), the order of point_camera (camera_to_world.py:57-59) and of the fused kernel
+          const double dx = x - a.T[9], dy = y - a.T[10], dz = z - a.T[11];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            w[3 * k + r] = fma(a.T[3 * r + 2], dz, fma(a.T[3 * r + 1], dy, a.T[3 * r + 0] * dx));
+        } else {  // row . [x y z 1]  (transfer_T_icp.py:10-12)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            w[3 * k + r] = fma(a.T[4 * r + 2], z, fma(a.T[4 * r + 1], y, a.T[4 * r + 0] * x)) + a.T[4 * r + 3];
+        }
+      }
+    }
+    __syncthreads();  // everyone has read its inputs before the buffer is reused for outputs
+#pragma unroll
+    for (int k = 0; k < kPts; ++k) {
+      if (first + k < n_pts) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) lout[(first + k) * 3 + r] = (OT)w[3 * k + r];
+      }
+    }
+    __syncthreads();
+
+    // ---- LDS -> tile ----
+    if (VEC) {
+      constexpr uint32_t kPerPiece = 16 / sizeof(OT);
+      const uint32_t n_pieces = n_elts / kPerPiece;
+      using V = typename std::conditional<sizeof(OT) == 4, float4, double2>::type;
+      for (uint32_t q = tid; q < n_pieces; q += kThreads)
+        reinterpret_cast<V*>(dst)[q] = reinterpret_cast<const V*>(lout)[q];
+      for (uint32_t e = n_pieces * kPerPiece + tid; e < n_elts; e += kThreads) dst[e] = lout[e];
+    } else {
+      for (uint32_t e = tid; e < n_elts; e += kThreads) dst[e] = lout[e];
+    }
+    __syncthreads();
+  }
+}
+
+template <typename IT, typename OT, bool SE3>
+void launch(const ApplyArgs& a, bool vec, int blocks, hipStream_t s) {
+  if (vec)
+    hipLaunchKernelGGL((apply_kernel<IT, OT, true, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL((apply_kernel<IT, OT, false, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
+}
+
+template <bool SE3>
+int apply_common(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_M,
+                 void* d_xyz_out, int out_dtype) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(in_dtype == R3D_F32 || in_dtype == R3D_F64, "unknown input dtype %d", in_dtype);
+  R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
+  R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
+  R3D_REQUIRE(h_M != nullptr, "transform is NULL");
+  if (n_points == 0) return R3D_OK;
+  R3D_REQUIRE(d_xyz_in && d_xyz_out, "NULL device pointer");
+  R3D_REQUIRE(d_xyz_in == d_xyz_out ? in_dtype == out_dtype : true, "in-place apply needs equal dtypes");
+  ApplyArgs a;
+  a.in = d_xyz_in;
+  a.out = d_xyz_out;
+  for (int k = 0; k < 12; ++k) a.T[k] = h_M[k];
+  a.n = (uint64_t)n_points;
+  // tile bases are multiples of 1024 points = 12 KiB (f32) / 24 KiB (f64): 16-B alignment of
+  // every tile follows from the alignment of the two base pointers
+  const bool vec = ((uintptr_t)d_xyz_in % 16 == 0) && ((uintptr_t)d_xyz_out % 16 == 0);
+  const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
+  int blocks = ctx->apply_blocks > 0 ? ctx->apply_blocks : ctx->num_cus * 8;
+  if ((uint64_t)blocks > n_tiles) blocks = (int)n_tiles;
+  if (in_dtype == R3D_F32 && out_dtype == R3D_F32)
+    launch<float, float, SE3>(a, vec, blocks, ctx->stream);
+  else if (in_dtype == R3D_F32)
+    launch<float, double, SE3>(a, vec, blocks, ctx->stream);
+  else if (out_dtype == R3D_F32)
+    launch<double, float, SE3>(a, vec, blocks, ctx->stream);
+  else
+    launch<double, double, SE3>(a, vec, blocks, ctx->stream);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+template <bool SE3>
+int apply_host_common(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_M,
+                      void* h_xyz_out, int out_dtype) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(in_dtype == R3D_F32 || in_dtype == R3D_F64, "unknown input dtype %d", in_dtype);
+  R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
+  R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
+  if (n_points == 0) return R3D_OK;
+  R3D_REQUIRE(h_xyz_in && h_xyz_out && h_M, "NULL host pointer");
+  const size_t in_bytes = (size_t)n_points * 3 * r3d_xyz_size(in_dtype);
+  const size_t out_bytes = (size_t)n_points * 3 * r3d_xyz_size(out_dtype);
+  void *d_in = nullptr, *d_out = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, in_bytes, &d_in))) return rc;
+  if ((rc = r3d_scratch(ctx, 1, out_bytes, &d_out))) return rc;
+  R3D_HIP(hipMemcpyAsync(d_in, h_xyz_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = apply_common<SE3>(ctx, d_in, in_dtype, n_points, h_M, d_out, out_dtype))) return rc;
+  R3D_HIP(hipMemcpyAsync(h_xyz_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  return R3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_apply_T(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_T,
+                void* d_xyz_out, int out_dtype) {
+  return apply_common<false>(ctx, d_xyz_in, in_dtype, n_points, h_T, d_xyz_out, out_dtype);
+}
+
+int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_T,
+                     void* h_xyz_out, int out_dtype) {
+  return apply_host_common<false>(ctx, h_xyz_in, in_dtype, n_points, h_T, h_xyz_out, out_dtype);
+}
+
+int r3d_se3_apply(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_pose,
+                  void* d_xyz_out, int out_dtype) {
+  return apply_common<true>(ctx, d_xyz_in, in_dtype, n_points, h_pose, d_xyz_out, out_dtype);
+}
+
+int r3d_se3_apply_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_pose,
+                       void* h_xyz_out, int out_dtype) {
+  return apply_host_common<true>(ctx, h_xyz_in, in_dtype, n_points, h_pose, h_xyz_out, out_dtype);
+}
+
+}  // extern "C"

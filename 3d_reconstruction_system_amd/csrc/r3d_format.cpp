@@ -1,0 +1,365 @@
+// Host-side ASCII serialisation in the reference's exact PLY byte layout (multi-threaded).
+//
+// Layout restated from genply() (camera_to_world.py:112-134 == transfer_T_icp.py:46-68 ==
+// pixel_to_camera.py:98-124): the header lines carry the 4-space indentation of the reference's
+// triple-quoted template, every vertex row is "%.4f %.4f %.4f \n" (trailing space), the first row
+// is indented 4 spaces and the file ends with "\n    ".
+//
+// "%.4f" must be the correctly rounded (half-to-even on the exact binary value) 4-decimal
+// expansion, as CPython and glibc both produce.  Fast path: |x| < 2^40 is scaled exactly with
+// 128-bit integer arithmetic (x = m*2^e, m*10^4 < 2^67); everything else goes through snprintf.
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "r3d.h"
+
+void r3d_set_error(const char* fmt, ...);
+
+namespace {
+
+inline char* put_uint(char* p, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do {
+    tmp[n++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+
+// writes "%.4f" of x at p, returns the new end
+inline char* fmt4(char* p, double x) {
+  if (std::isnan(x)) {
+    memcpy(p, "nan", 3);
+    return p + 3;
+  }
+  const bool neg = std::signbit(x);
+  const double ax = std::fabs(x);
+  if (!(ax < 1099511627776.0)) {  // >= 2^40 or inf: rare, take the libc path
+    if (std::isinf(ax)) {
+      if (neg) *p++ = '-';
+      memcpy(p, "inf", 3);
+      return p + 3;
+    }
+    return p + snprintf(p, 400, "%.4f", x);
+  }
+  uint64_t scaled;  // round_half_even(ax * 10^4), exact
+  if (ax == 0.0) {
+    scaled = 0;
+  } else {
+    int e;
+    const double fr = std::frexp(ax, &e);              // ax = fr * 2^e, fr in [0.5,1)
+    const uint64_t m = (uint64_t)std::ldexp(fr, 53);   // 53-bit integer mantissa, exact
+    e -= 53;                                           // ax = m * 2^e
+    const unsigned __int128 prod = (unsigned __int128)m * 10000u;
+    if (e >= 0) {
+      scaled = (uint64_t)(prod << e);  // ax < 2^40 keeps this below 2^54
+    } else {
+      const int sh = -e;
+      if (sh >= 120) {
+        scaled = 0;  // far below half a unit
+      } else {
+        const unsigned __int128 q = prod >> sh;
+        const unsigned __int128 rem = prod - (q << sh);
+        const unsigned __int128 half = (unsigned __int128)1 << (sh - 1);
+        scaled = (uint64_t)q;
+        if (rem > half || (rem == half && (scaled & 1))) ++scaled;
+      }
+    }
+  }
+  if (neg) *p++ = '-';
+  p = put_uint(p, scaled / 10000u);
+  *p++ = '.';
+  const unsigned frac = (unsigned)(scaled % 10000u);
+  p[0] = (char)('0' + frac / 1000);
+  p[1] = (char)('0' + (frac / 100) % 10);
+  p[2] = (char)('0' + (frac / 10) % 10);
+  p[3] = (char)('0' + frac % 10);
+  return p + 4;
+}
+
+template <typename T>
+void format_rows(const T* xyz, int64_t lo, int64_t hi, std::string* out) {
+  // worst case per value below 2^40: sign + 13 digits + '.' + 4 = 19; plus separators
+  out->resize((size_t)(hi - lo) * 64 + 1300);
+  char* base = &(*out)[0];
+  char* p = base;
+  for (int64_t i = lo; i < hi; ++i) {
+    if ((size_t)(p - base) + 1300 > out->size()) {  // only after snprintf-path giants
+      const size_t used = p - base;
+      out->resize(out->size() * 2 + 1300);
+      base = &(*out)[0];
+      p = base + used;
+    }
+    p = fmt4(p, (double)xyz[i * 3 + 0]);
+    *p++ = ' ';
+    p = fmt4(p, (double)xyz[i * 3 + 1]);
+    *p++ = ' ';
+    p = fmt4(p, (double)xyz[i * 3 + 2]);
+    *p++ = ' ';
+    *p++ = '\n';
+  }
+  out->resize(p - base);
+}
+
+// Python's repr(float) ("short" float_repr_style): shortest round-trip digits; fixed notation when
+// -4 < decpt <= 16, else d[.ddd]e+XX with at least two exponent digits; ".0" appended to integers.
+inline char* fmt_repr(char* p, double x) {
+  if (std::isnan(x)) {
+    memcpy(p, "nan", 3);
+    return p + 3;
+  }
+  if (std::isinf(x)) {
+    if (x < 0) *p++ = '-';
+    memcpy(p, "inf", 3);
+    return p + 3;
+  }
+  if (std::signbit(x)) {
+    *p++ = '-';
+    x = -x;
+  }
+  if (x == 0.0) {
+    memcpy(p, "0.0", 3);
+    return p + 3;
+  }
+  char sci[40];
+  const auto res = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);
+  // sci = d[.ddd]e[+-]XX
+  char digits[24];
+  int nd = 0;
+  const char* c = sci;
+  for (; c < res.ptr && *c != 'e'; ++c)
+    if (*c != '.') digits[nd++] = *c;
+  int e10 = 0;
+  {
+    ++c;  // 'e'
+    const bool eneg = (*c == '-');
+    ++c;
+    for (; c < res.ptr; ++c) e10 = e10 * 10 + (*c - '0');
+    if (eneg) e10 = -e10;
+  }
+  const int decpt = e10 + 1;
+  if (decpt <= -4 || decpt > 16) {
+    *p++ = digits[0];
+    if (nd > 1) {
+      *p++ = '.';
+      memcpy(p, digits + 1, nd - 1);
+      p += nd - 1;
+    }
+    *p++ = 'e';
+    int e = decpt - 1;
+    *p++ = e < 0 ? '-' : '+';
+    if (e < 0) e = -e;
+    if (e < 10) *p++ = '0';
+    return put_uint(p, (uint64_t)e);
+  }
+  if (decpt <= 0) {
+    *p++ = '0';
+    *p++ = '.';
+    for (int k = 0; k < -decpt; ++k) *p++ = '0';
+    memcpy(p, digits, nd);
+    return p + nd;
+  }
+  if (decpt >= nd) {
+    memcpy(p, digits, nd);
+    p += nd;
+    for (int k = 0; k < decpt - nd; ++k) *p++ = '0';
+    *p++ = '.';
+    *p++ = '0';
+    return p;
+  }
+  memcpy(p, digits, decpt);
+  p += decpt;
+  *p++ = '.';
+  memcpy(p, digits + decpt, nd - decpt);
+  return p + (nd - decpt);
+}
+
+template <typename T>
+void txt_rows(const T* xyz, const void* z_raw, int z_dtype, int64_t lo, int64_t hi, std::string* out) {
+  out->resize((size_t)(hi - lo) * 80 + 16);  // 3 x (sign + 17 digits + point + e-308) + 2 commas + newline < 80
+  char* base = &(*out)[0];
+  char* p = base;
+  for (int64_t i = lo; i < hi; ++i) {
+    p = fmt_repr(p, (double)xyz[i * 3 + 0]);
+    *p++ = ',';
+    p = fmt_repr(p, (double)xyz[i * 3 + 1]);
+    *p++ = ',';
+    if (z_raw)
+      p = put_uint(p, z_dtype == R3D_DEPTH_U8 ? static_cast<const uint8_t*>(z_raw)[i]
+                                              : static_cast<const uint16_t*>(z_raw)[i]);
+    else
+      p = fmt_repr(p, (double)xyz[i * 3 + 2]);
+    *p++ = '\n';
+  }
+  out->resize(p - base);
+}
+
+int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, std::vector<std::string>* chunks) {
+  char head[256];
+  snprintf(head, sizeof(head),
+           "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
+           "    property float z\n    end_header\n    ",
+           (long long)n);
+  *header = head;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
+  chunks->assign((size_t)n_chunks, std::string());
+  std::vector<std::thread> pool;
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int64_t lo = n * c / n_chunks, hi = n * (c + 1) / n_chunks;
+    auto work = [=]() {
+      if (dtype == R3D_F32)
+        format_rows(static_cast<const float*>(h_xyz), lo, hi, &(*chunks)[(size_t)c]);
+      else
+        format_rows(static_cast<const double*>(h_xyz), lo, hi, &(*chunks)[(size_t)c]);
+    };
+    if (n_chunks == 1)
+      work();
+    else
+      pool.emplace_back(work);
+  }
+  for (auto& t : pool) t.join();
+  return R3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, size_t buf_cap,
+                   size_t* n_bytes_out) {
+  if (n_points < 0 || (n_points > 0 && !h_xyz) || (dtype != R3D_F32 && dtype != R3D_F64) || !n_bytes_out) {
+    r3d_set_error("r3d_format_ply: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  std::string header;
+  std::vector<std::string> chunks;
+  try {
+    format_chunks(h_xyz, dtype, n_points, &header, &chunks);
+  } catch (const std::bad_alloc&) {
+    r3d_set_error("r3d_format_ply: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
+  size_t total = header.size() + 5;  // trailer "\n    "
+  for (const auto& c : chunks) total += c.size();
+  *n_bytes_out = total;
+  if (!h_buf) return R3D_OK;
+  if (buf_cap < total) {
+    r3d_set_error("r3d_format_ply: buffer of %zu bytes is too small for %zu", buf_cap, total);
+    return R3D_ERR_NOMEM;
+  }
+  char* p = h_buf;
+  memcpy(p, header.data(), header.size());
+  p += header.size();
+  for (const auto& c : chunks) {
+    memcpy(p, c.data(), c.size());
+    p += c.size();
+  }
+  memcpy(p, "\n    ", 5);
+  return R3D_OK;
+}
+
+int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_points) {
+  if (!path || n_points < 0 || (n_points > 0 && !h_xyz) || (dtype != R3D_F32 && dtype != R3D_F64)) {
+    r3d_set_error("r3d_write_ply: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    r3d_set_error("r3d_write_ply: cannot open '%s' for writing", path);
+    return R3D_ERR_INVALID;
+  }
+  // format and write in slabs of 8 M points so the text never needs more than ~0.5 GB of host memory
+  const int64_t slab = (int64_t)8 << 20;
+  std::string header;
+  std::vector<std::string> chunks;
+  bool ok = true;
+  try {
+    char head[256];
+    snprintf(head, sizeof(head),
+             "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
+             "    property float z\n    end_header\n    ",
+             (long long)n_points);
+    ok = fwrite(head, 1, strlen(head), f) == strlen(head);
+    const size_t esz = dtype == R3D_F32 ? 4 : 8;
+    for (int64_t lo = 0; ok && lo < n_points; lo += slab) {
+      const int64_t cnt = std::min(slab, n_points - lo);
+      format_chunks(static_cast<const char*>(h_xyz) + (size_t)lo * 3 * esz, dtype, cnt, &header, &chunks);
+      for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+    }
+    ok = ok && fwrite("\n    ", 1, 5, f) == 5;
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    r3d_set_error("r3d_write_ply: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
+  if (fclose(f) != 0) ok = false;
+  if (!ok) {
+    r3d_set_error("r3d_write_ply: short write to '%s'", path);
+    return R3D_ERR_INVALID;
+  }
+  return R3D_OK;
+}
+
+int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw,
+                      int z_raw_dtype, int append) {
+  if (!path || n_points < 0 || (n_points > 0 && !h_xyz) || (dtype != R3D_F32 && dtype != R3D_F64) ||
+      (h_z_raw && z_raw_dtype != R3D_DEPTH_U8 && z_raw_dtype != R3D_DEPTH_U16)) {
+    r3d_set_error("r3d_write_xyz_txt: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  FILE* f = fopen(path, append ? "ab" : "wb");
+  if (!f) {
+    r3d_set_error("r3d_write_xyz_txt: cannot open '%s' for writing", path);
+    return R3D_ERR_INVALID;
+  }
+  bool ok = true;
+  try {
+    const int64_t slab = (int64_t)4 << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
+      const int64_t cnt = std::min(slab, n_points - s0);
+      const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 32768));
+      std::vector<std::string> chunks((size_t)n_chunks);
+      std::vector<std::thread> pool;
+      for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
+        auto work = [=, &chunks]() {
+          if (dtype == R3D_F32)
+            txt_rows(static_cast<const float*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &chunks[(size_t)c]);
+          else
+            txt_rows(static_cast<const double*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &chunks[(size_t)c]);
+        };
+        if (n_chunks == 1)
+          work();
+        else
+          pool.emplace_back(work);
+      }
+      for (auto& t : pool) t.join();
+      for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+    }
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    r3d_set_error("r3d_write_xyz_txt: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
+  if (fclose(f) != 0) ok = false;
+  if (!ok) {
+    r3d_set_error("r3d_write_xyz_txt: short write to '%s'", path);
+    return R3D_ERR_INVALID;
+  }
+  return R3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// ICP estimation kernels for gfx950 (MI355X): brute-force nearest neighbour + the 18 fp64
+// cross-covariance sums of the Umeyama similarity fit.
+//
+// NOT IN THE REFERENCE: other_tools/transfer_T_icp.py only *applies* a T_data.txt produced by an
+// external ICP tool (transfer_T_icp.py:33-43, 99-108).  These kernels produce that matrix
+// on-device; the definition is the build's own, parity unpinned.
+//
+// r3d_icp_nn -- roofline: fp32 VALU (N*M pair evaluations), not HBM.
+//   d2(s,t) = fma(dz,dz, fma(dy,dy, dx*dx)) in fp32, argmin over t, lowest index wins ties.
+//   * a 256-thread workgroup owns 256*S source points (S per lane, in registers) and sweeps the
+//     whole target cloud in LDS tiles of 1024 points stored SoA (x[1024] y[1024] z[1024]).
+//   * every lane reads the SAME 4 targets per step (3 broadcast ds_read_b128), so LDS traffic per
+//     pair falls with S; the inner loop is 6 VALU per pair + min3 over groups of 32 targets.
+//   * no per-pair index bookkeeping: the loop only tracks, per source, the minimum distance and
+//     the 32-target GROUP in which it was first reached (strict <, so the earliest group wins);
+//     a short epilogue re-evaluates that one group with the identical expression and picks the
+//     lowest index that reproduces the minimum bit for bit.
+//
+// r3d_icp_accumulate -- roofline: HBM/L2 gather, 28 B/pair (12 src + 4 idx + 12 gathered tgt).
+//   fp64 accumulators in registers, wavefront shuffle tree (width 64) -> LDS across the 4 waves
+//   -> per-workgroup partials -> one fixed-order final pass.  No float atomics: bitwise
+//   reproducible run to run.
+#include <cmath>
+
+#include "r3d_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTgtTile = 1024;  // targets per LDS tile
+constexpr int kGroup = 32;      // targets per min-tracking group
+
+template <int S>
+__global__ __launch_bounds__(kThreads) void nn_kernel(const float* __restrict__ src, int64_t n_src,
+                                                      const float* __restrict__ tgt, int64_t n_tgt,
+                                                      uint32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+  __shared__ __attribute__((aligned(16))) float tx[kTgtTile];
+  __shared__ __attribute__((aligned(16))) float ty[kTgtTile];
+  __shared__ __attribute__((aligned(16))) float tz[kTgtTile];
+
+  const uint32_t tid = threadIdx.x;
+  const int64_t s_base = (int64_t)blockIdx.x * (kThreads * S);
+  float sx[S], sy[S], sz[S], best[S];
+  uint32_t best_group[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t i = s_base + (int64_t)s * kThreads + tid;
+    const bool ok = i < n_src;
+    sx[s] = ok ? src[i * 3 + 0] : 0.f;
+    sy[s] = ok ? src[i * 3 + 1] : 0.f;
+    sz[s] = ok ? src[i * 3 + 2] : 0.f;
+    best[s] = INFINITY;
+    best_group[s] = 0;
+  }
+
+  const int64_t n_tiles = (n_tgt + kTgtTile - 1) / kTgtTile;
+  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+    const int64_t t_base = tile * kTgtTile;
+    const int64_t n_here = min((int64_t)kTgtTile, n_tgt - t_base);
+    __syncthreads();  // previous tile fully consumed
+    // AoS global -> SoA LDS; slots past the cloud's end get x = +inf so they can never win
+    for (uint32_t e = tid; e < kTgtTile * 3; e += kThreads) {
+      const uint32_t p = e / 3, c = e - p * 3;
+      float v = (c == 0) ? INFINITY : 0.f;
+      if ((int64_t)p < n_here) v = tgt[(t_base + p) * 3 + c];
+      (c == 0 ? tx : c == 1 ? ty : tz)[p] = v;
+    }
+    __syncthreads();
+
+    const uint32_t group0 = (uint32_t)(t_base / kGroup);
+    for (int g = 0; g < kTgtTile / kGroup; ++g) {
+      float gmin[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) gmin[s] = INFINITY;
+#pragma unroll
+      for (int q = 0; q < kGroup / 4; ++q) {
+        const float4 X = reinterpret_cast<const float4*>(tx)[g * (kGroup / 4) + q];
+        const float4 Y = reinterpret_cast<const float4*>(ty)[g * (kGroup / 4) + q];
+        const float4 Z = reinterpret_cast<const float4*>(tz)[g * (kGroup / 4) + q];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          float dx, dy, dz;
+          dx = sx[s] - X.x; dy = sy[s] - Y.x; dz = sz[s] - Z.x;
+          const float d0 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          dx = sx[s] - X.y; dy = sy[s] - Y.y; dz = sz[s] - Z.y;
+          const float d1 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          dx = sx[s] - X.z; dy = sy[s] - Y.z; dz = sz[s] - Z.z;
+          const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          dx = sx[s] - X.w; dy = sy[s] - Y.w; dz = sz[s] - Z.w;
+          const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          gmin[s] = fminf(fminf(gmin[s], d0), d1);  // v_min3_f32
+          gmin[s] = fminf(fminf(gmin[s], d2), d3);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (gmin[s] < best[s]) {  // strict: the earliest group that reaches the minimum keeps it
+          best[s] = gmin[s];
+          best_group[s] = group0 + g;
+        }
+      }
+    }
+  }
+
+  // epilogue: lowest index inside the winning group that reproduces the minimum exactly
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t i = s_base + (int64_t)s * kThreads + tid;
+    if (i >= n_src) continue;
+    const int64_t t0 = (int64_t)best_group[s] * kGroup;
+    uint32_t found = (uint32_t)t0;
+    bool have = false;
+    for (int k = 0; k < kGroup; ++k) {
+      const int64_t t = t0 + k;
+      if (t < n_tgt && !have) {
+        const float dx = sx[s] - tgt[t * 3 + 0], dy = sy[s] - tgt[t * 3 + 1], dz = sz[s] - tgt[t * 3 + 2];
+        const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d == best[s]) {
+          found = (uint32_t)t;
+          have = true;
+        }
+      }
+    }
+    idx_out[i] = found;
+    if (d2_out) d2_out[i] = best[s];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr int kSums = 18;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __restrict__ src, int64_t n_src,
+                                                              const float* __restrict__ tgt,
+                                                              const uint32_t* __restrict__ idx,
+                                                              const float* __restrict__ d2, float max_d2,
+                                                              double* __restrict__ partials) {
+  __shared__ double red[kThreads / 64][kSums];
+  double acc[kSums];
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_src; i += (int64_t)gridDim.x * kThreads) {
+    if (d2 != nullptr && !(d2[i] <= max_d2)) continue;
+    const uint32_t j = idx[i];
+    const double p[3] = {(double)src[i * 3 + 0], (double)src[i * 3 + 1], (double)src[i * 3 + 2]};
+    const double q[3] = {(double)tgt[(int64_t)j * 3 + 0], (double)tgt[(int64_t)j * 3 + 1], (double)tgt[(int64_t)j * 3 + 2]};
+    acc[0] += 1.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      acc[1 + a] += p[a];
+      acc[4 + a] += q[a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[7 + 3 * a + b] += p[a] * q[b];
+      acc[16] += p[a] * p[a];
+      acc[17] += q[a] * q[a];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kSums) {
+    double v = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+    partials[(int64_t)blockIdx.x * kSums + threadIdx.x] = v;
+  }
+}
+
+__global__ void accumulate_final_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ sums) {
+  if (threadIdx.x < kSums) {
+    double v = 0.0;
+    for (int b = 0; b < n_blocks; ++b) v += partials[(int64_t)b * kSums + threadIdx.x];
+    sums[threadIdx.x] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+               uint32_t* d_idx_out, float* d_d2_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_src >= 0 && n_tgt >= 0, "negative cloud size");
+  if (n_src == 0) return R3D_OK;
+  R3D_REQUIRE(n_tgt >= 1, "target cloud is empty");
+  R3D_REQUIRE(n_tgt < ((int64_t)1 << 32), "target cloud too large for uint32 indices");
+  R3D_REQUIRE(d_src && d_tgt && d_idx_out, "NULL device pointer");
+  // S sources per lane: fewer LDS reads per pair; keep enough workgroups to fill 256 CUs
+  int S = ctx->nn_variant;
+  if (S != 1 && S != 2 && S != 4) S = (n_src >= (int64_t)256 * 256 * 4) ? 2 : 1;
+  const int64_t per_block = (int64_t)kThreads * S;
+  const int64_t blocks = (n_src + per_block - 1) / per_block;
+  R3D_REQUIRE(blocks < ((int64_t)1 << 31), "source cloud too large");
+  switch (S) {
+    case 1:
+      hipLaunchKernelGGL((nn_kernel<1>), dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt,
+                         n_tgt, d_idx_out, d_d2_out);
+      break;
+    case 2:
+      hipLaunchKernelGGL((nn_kernel<2>), dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt,
+                         n_tgt, d_idx_out, d_d2_out);
+      break;
+    default:
+      hipLaunchKernelGGL((nn_kernel<4>), dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt,
+                         n_tgt, d_idx_out, d_d2_out);
+      break;
+  }
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float* h_tgt, int64_t n_tgt,
+                    uint32_t* h_idx_out, float* h_d2_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_src >= 0 && n_tgt >= 0, "negative cloud size");
+  if (n_src == 0) return R3D_OK;
+  R3D_REQUIRE(n_tgt >= 1, "target cloud is empty");
+  R3D_REQUIRE(h_src && h_tgt && h_idx_out, "NULL host pointer");
+  void *d_src = nullptr, *d_tgt = nullptr, *d_idx = nullptr, *d_d2 = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, (size_t)n_src * 12, &d_src))) return rc;
+  if ((rc = r3d_scratch(ctx, 1, (size_t)n_tgt * 12, &d_tgt))) return rc;
+  if ((rc = r3d_scratch(ctx, 2, (size_t)n_src * 4, &d_idx))) return rc;
+  if ((rc = r3d_scratch(ctx, 3, (size_t)n_src * 4, &d_d2))) return rc;
+  R3D_HIP(hipMemcpyAsync(d_src, h_src, (size_t)n_src * 12, hipMemcpyHostToDevice, ctx->stream));
+  R3D_HIP(hipMemcpyAsync(d_tgt, h_tgt, (size_t)n_tgt * 12, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = r3d_icp_nn(ctx, (const float*)d_src, n_src, (const float*)d_tgt, n_tgt, (uint32_t*)d_idx, (float*)d_d2)))
+    return rc;
+  R3D_HIP(hipMemcpyAsync(h_idx_out, d_idx, (size_t)n_src * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_d2_out) R3D_HIP(hipMemcpyAsync(h_d2_out, d_d2, (size_t)n_src * 4, hipMemcpyDeviceToHost, ctx->stream));
+  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  return R3D_OK;
+}
+
+int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                       const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_src >= 0 && n_tgt >= 0, "negative cloud size");
+  R3D_REQUIRE(h_sums != nullptr, "h_sums is NULL");
+  for (int k = 0; k < kSums; ++k) h_sums[k] = 0.0;
+  if (n_src == 0) return R3D_OK;
+  R3D_REQUIRE(d_src && d_tgt && d_idx, "NULL device pointer");
+  const bool gated = max_d2 >= 0.f;
+  R3D_REQUIRE(!gated || d_d2 != nullptr, "max_d2 >= 0 needs the d2 array");
+  int blocks = (int)((n_src + kThreads - 1) / kThreads);
+  if (blocks > ctx->num_cus * 4) blocks = ctx->num_cus * 4;
+  void* d_part_v = nullptr;
+  if ((rc = r3d_scratch(ctx, 4, ((size_t)blocks + 1) * kSums * sizeof(double), &d_part_v))) return rc;
+  double* d_part = static_cast<double*>(d_part_v);
+  double* d_sums = d_part + (size_t)blocks * kSums;
+  hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx,
+                     gated ? d_d2 : nullptr, max_d2, d_part);
+  hipLaunchKernelGGL(accumulate_final_kernel, dim3(1), dim3(64), 0, ctx->stream, d_part, blocks, d_sums);
+  R3D_HIP(hipGetLastError());
+  R3D_HIP(hipMemcpyAsync(h_sums, d_sums, kSums * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  (void)n_tgt;
+  return R3D_OK;
+}
+
+}  // extern "C"

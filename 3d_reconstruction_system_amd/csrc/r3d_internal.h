@@ -1,0 +1,65 @@
+// Internal declarations shared by the translation units of libr3d_hip.so.
+// Public surface: include/r3d.h.  gfx950 (MI355X) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "r3d.h"
+
+struct r3d_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  int num_cus = 256;
+  // tuning knobs (r3d_ctx_set_tuning)
+  int fuse_variant = 0;  // 0 auto
+  int fuse_blocks = 0;   // 0 auto
+  int nontemporal = 0;
+  int nn_variant = 0;
+  int apply_blocks = 0;
+  // HIP-event stopwatch
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  // grow-only scratch buffers for the *_host entry points and reductions
+  static constexpr int kScratchSlots = 6;
+  void* scratch[kScratchSlots] = {};
+  size_t scratch_bytes[kScratchSlots] = {};
+};
+
+struct r3d_camera {
+  r3d_ctx* ctx = nullptr;
+  int height = 0, width = 0;
+  double fx = 0, fy = 0, cx = 0, cy = 0;
+  double* d_u = nullptr;  // [width]  (i-cx)/fx
+  double* d_v = nullptr;  // [height] (j-cy)/fy
+};
+
+// thread-local error text
+void r3d_set_error(const char* fmt, ...);
+int r3d_fail_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define R3D_HIP(call)                                                       \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) return r3d_fail_hip(e_, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define R3D_REQUIRE(cond, ...)  \
+  do {                          \
+    if (!(cond)) {              \
+      r3d_set_error(__VA_ARGS__); \
+      return R3D_ERR_INVALID;   \
+    }                           \
+  } while (0)
+
+// make the ctx's device current for the calling thread
+int r3d_ctx_enter(r3d_ctx* ctx);
+// grow-only scratch slot (device memory); returns device pointer in *p
+int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p);
+
+static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
+static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

@@ -1,0 +1,159 @@
+"""Context / camera / device-buffer objects over the C ABI (include/r3d.h).
+
+One `Context` = one MI355X + one HIP stream.  Device memory can come from the library
+(`Context.alloc`) or from anyone else (e.g. a torch tensor's data_ptr()): the C ABI only
+sees raw addresses.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_DEPTH_CODES = {np.dtype(np.uint8): L.DEPTH_U8, np.dtype(np.uint16): L.DEPTH_U16,
+                np.dtype(np.float32): L.DEPTH_F32}
+_XYZ_CODES = {np.dtype(np.float32): L.F32, np.dtype(np.float64): L.F64}
+
+
+def depth_code(dtype):
+    try:
+        return _DEPTH_CODES[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError("depth raster must be uint8, uint16 or float32 (got %s)" % np.dtype(dtype))
+
+
+def xyz_code(dtype):
+    try:
+        return _XYZ_CODES[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError("point clouds are float32 or float64 (got %s)" % np.dtype(dtype))
+
+
+class DeviceBuffer:
+    """A library-owned HBM allocation.  `ptr` is the raw device address."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        L.check(ctx.lib.r3d_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        L.check(self.ctx.lib.r3d_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes))
+        self.ctx.sync()  # `host` may be a temporary
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(self.ctx.lib.r3d_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        self.ctx.sync()
+        return out
+
+    def free(self):
+        if self.ptr:
+            L.check(self.ctx.lib.r3d_dev_free(self.ctx.handle, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.ctx.lib.r3d_dev_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+
+
+class Context:
+    """r3d_ctx wrapper.  stream: raw hipStream_t (int) to share, e.g.
+    torch.cuda.current_stream().cuda_stream, or None for a private stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(self.lib.r3d_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h.value
+        self.device = int(device)
+        self._cameras = {}
+
+    def close(self):
+        if self.handle:
+            for cam in list(self._cameras.values()):
+                cam.close()
+            self._cameras.clear()
+            self.lib.r3d_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        L.check(self.lib.r3d_ctx_sync(self.handle))
+
+    def set_tuning(self, key, value):
+        L.check(self.lib.r3d_ctx_set_tuning(self.handle, key.encode(), int(value)))
+
+    def get_tuning(self, key):
+        v = C.c_int()
+        L.check(self.lib.r3d_ctx_get_tuning(self.handle, key.encode(), C.byref(v)))
+        return v.value
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def timer_start(self):
+        L.check(self.lib.r3d_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        L.check(self.lib.r3d_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def camera(self, height, width, fx, fy, cx, cy):
+        key = (int(height), int(width), float(fx), float(fy), float(cx), float(cy))
+        cam = self._cameras.get(key)
+        if cam is None:
+            cam = Camera(self, *key)
+            self._cameras[key] = cam
+        return cam
+
+
+class Camera:
+    """r3d_camera wrapper: intrinsics + the fp64 ray tables u[i]=(i-cx)/fx, v[j]=(j-cy)/fy in HBM."""
+
+    def __init__(self, ctx, height, width, fx, fy, cx, cy):
+        self.ctx = ctx
+        self.height, self.width = int(height), int(width)
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        h = C.c_void_p()
+        L.check(ctx.lib.r3d_camera_create(ctx.handle, self.height, self.width, self.fx, self.fy, self.cx,
+                                          self.cy, C.byref(h)))
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.r3d_camera_destroy(self.handle)
+            self.handle = None
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device, created on first use (raises if no MI355X is visible)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

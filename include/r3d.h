@@ -1,0 +1,159 @@
+/*
+ * r3d.h -- C ABI of libr3d_hip.so: the MI355X (gfx950) depth -> world point-cloud
+ * fusion path.  This is the drop-in boundary: plain pointers and sizes, no C++ or
+ * torch types.  A Python host binds it with ctypes; the
+ * reference (rainfall1998/3D_reconstruction_system) has no FFI of its own, so each
+ * entry point names the reference *function* whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns an int status: R3D_OK (0) or a negative R3D_ERR_*;
+ *     r3d_last_error() returns a thread-local human-readable message for the last
+ *     failure on the calling thread.  Nothing throws, nothing aborts.
+ *   - "d_" pointers are device (HBM) addresses valid on the ctx's GPU; "h_" pointers
+ *     are host addresses owned by the caller.  The library never frees caller memory.
+ *   - device-pointer entry points are ASYNCHRONOUS on the ctx's HIP stream; *_host
+ *     entry points are synchronous (H2D, kernel, D2H, stream sync).
+ *   - one ctx = one GPU + one stream.  Calls on one ctx are not thread-safe; different
+ *     ctxs are independent.
+ *   - point clouds are AoS xyz, row-major [n][3], float32 (R3D_F32) or float64
+ *     (R3D_F64).  All arithmetic is done in fp64 registers exactly in the reference's
+ *     evaluation order and rounded ONCE on store, so R3D_F32 output is the correctly
+ *     rounded fp64 result (<= 6e-8 relative per component) and R3D_F64 output equals the
+ *     reference's fp64 up to dot-product summation order (~1e-16).
+ */
+#ifndef R3D_H
+#define R3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3D_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define R3D_OK 0
+#define R3D_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, unknown enum) */
+#define R3D_ERR_HIP (-2)         /* a HIP runtime call failed; see r3d_last_error() */
+#define R3D_ERR_NOMEM (-3)       /* device or host allocation failed */
+#define R3D_ERR_NODEVICE (-4)    /* no usable gfx950 device / device index out of range */
+#define R3D_ERR_UNSUPPORTED (-5) /* valid request the library does not implement */
+
+/* depth raster element types (reference: uint8 from cv.imread(...,IMREAD_GRAYSCALE),
+ * camera_to_world.py:160; u16 / f32 cover 16-bit PNG and metric depth rasters) */
+#define R3D_DEPTH_U8 0
+#define R3D_DEPTH_U16 1
+#define R3D_DEPTH_F32 2
+
+/* point-cloud element types */
+#define R3D_F32 0
+#define R3D_F64 1
+
+typedef struct r3d_ctx r3d_ctx;       /* one GPU + one HIP stream + scratch buffers */
+typedef struct r3d_camera r3d_camera; /* pinhole intrinsics + per-column/per-row ray tables in HBM */
+
+/* ---- library / context ------------------------------------------------------------ */
+int r3d_version(void);
+const char* r3d_last_error(void);
+int r3d_device_count(int* n_out);
+/* stream: an existing hipStream_t to launch on (e.g. torch's current stream), or NULL to
+ * let the ctx create and own a non-blocking stream. */
+int r3d_ctx_create(int device, void* stream, r3d_ctx** ctx_out);
+int r3d_ctx_destroy(r3d_ctx* ctx);
+int r3d_ctx_sync(r3d_ctx* ctx);
+int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
+/* tuning knobs (integers): "fuse_variant" {0 auto,1 scalar,2 vec4 direct,3 vec4 LDS-transposed},
+ * "fuse_blocks" (grid cap, 0 = auto), "nontemporal" {0,1}, "nn_variant". Unknown key -> R3D_ERR_INVALID. */
+int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);
+int r3d_ctx_get_tuning(r3d_ctx* ctx, const char* key, int* value_out);
+
+/* ---- device memory + timing helpers (so a ctypes host needs nothing but this library) */
+int r3d_dev_alloc(r3d_ctx* ctx, size_t bytes, void** d_ptr_out);
+int r3d_dev_free(r3d_ctx* ctx, void* d_ptr);
+int r3d_memcpy_h2d(r3d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* async on ctx stream */
+int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on ctx stream */
+int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
+/* HIP-event stopwatch on the ctx's stream: start records an event, stop records a second
+ * one, synchronises on it and returns the elapsed milliseconds between them. */
+int r3d_timer_start(r3d_ctx* ctx);
+int r3d_timer_stop(r3d_ctx* ctx, float* ms_out);
+
+/* ---- camera (replaces the hard-coded fx,fy,cx,cy of pixel_to_camera.py:25-28 and
+ * camera_to_world.py:68-71).  Builds u[i]=(i-cx)/fx, v[j]=(j-cy)/fy in fp64 on the host
+ * with the reference's evaluation order and keeps them in HBM. */
+int r3d_camera_create(r3d_ctx* ctx, int height, int width, double fx, double fy, double cx, double cy,
+                      r3d_camera** cam_out);
+int r3d_camera_destroy(r3d_camera* cam);
+
+/* ---- a1/a2: per-pixel back-projection.  Replaces gentxtcord() (pixel_to_camera.py:24-44,
+ * camera_to_world.py:67-83): Z=depth[j,i]*depth_scale, X=(i-cx)/fx*Z, Y=(j-cy)/fy*Z, row-major,
+ * every pixel emitted, no masking.  n_frames rasters of cam's HxW -> [n_frames*H*W][3]. */
+int r3d_unproject(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
+                  double depth_scale, void* d_xyz_out, int out_dtype);
+int r3d_unproject_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,
+                       double depth_scale, void* h_xyz_out, int out_dtype);
+
+/* ---- a2+a3+a4 fused, batched: unproject + per-frame SE(3), frames concatenated in order.
+ * Replaces the frame loop of get_file_name() (camera_to_world.py:149-172) =
+ * gentxtcord (c2w:67-83) + get_pointdata/point_camera (c2w:86-105, 57-59):
+ *     p_world = Rinv_f . (p_cam - t_f)
+ * pose: n_frames x 12 doubles, [Rinv row-major (9), t (3)] per frame; Rinv is what
+ * scipy_transfer() (c2w:53-55) returns -- computed on the host in fp64. */
+int r3d_fuse_frames(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
+                    double depth_scale, const double* d_pose, void* d_xyz_out, int out_dtype);
+int r3d_fuse_frames_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,
+                         double depth_scale, const double* h_pose, void* h_xyz_out, int out_dtype);
+
+/* ---- a4 on an existing cloud: p_world = Rinv . (p_cam - t), the evaluation order of point_camera()
+ * (camera_to_world.py:57-59) and of the fused kernel, so fuse_frames(depth) == se3_apply(unproject(depth))
+ * bit for bit.  h_pose is ALWAYS a host pointer: 12 doubles [Rinv row-major (9), t (3)].  In-place allowed. */
+int r3d_se3_apply(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_pose,
+                  void* d_xyz_out, int out_dtype);
+int r3d_se3_apply_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_pose,
+                       void* h_xyz_out, int out_dtype);
+
+/* ---- a7: p' = (T . [x,y,z,1]^T)[0:3] for a general row-major 4x4.
+ * Replaces local_world(flag=True)/point_camera (transfer_T_icp.py:71-97, 10-12).
+ * h_T is ALWAYS a host pointer (16 doubles); in-place (d_xyz_out == d_xyz_in) is allowed. */
+int r3d_apply_T(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_T,
+                void* d_xyz_out, int out_dtype);
+int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_T,
+                     void* h_xyz_out, int out_dtype);
+
+/* ---- a8: ICP estimation kernels (NOT in the reference -- transfer_T_icp.py only consumes a
+ * T_data.txt made by an external tool; build-defined per SURVEY.md 8(a8)).
+ * r3d_icp_nn: for each source point the index of the nearest target point under squared L2
+ * computed in fp32 as ((sx-tx)^2+(sy-ty)^2)+(sz-tz)^2 with fma contraction off, lowest index wins ties.
+ * src/tgt are float32 xyz AoS.  d_idx_out [n_src] uint32, d_d2_out [n_src] float32 (may be NULL). */
+int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+               uint32_t* d_idx_out, float* d_d2_out);
+int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float* h_tgt, int64_t n_tgt,
+                    uint32_t* h_idx_out, float* h_d2_out);
+/* r3d_icp_accumulate: the 18 fp64 sums Umeyama needs over the matched pairs (p=src[k], q=tgt[idx[k]]),
+ * pairs with d2 > max_d2 skipped when max_d2 >= 0 (d_d2 may be NULL when max_d2 < 0):
+ *   sums[0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p_a*q_b (a major), [16]=sum |p|^2, [17]=sum |q|^2.
+ * Deterministic (fixed two-stage tree, no float atomics).  h_sums is a host pointer; synchronous. */
+int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                       const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums);
+
+/* ---- f1: reference-layout ASCII serialisation on the host (multi-threaded C++).
+ * r3d_format_ply: the byte layout of genply() (camera_to_world.py:112-134): header with 4-space
+ * indents, "%.4f %.4f %.4f \n" rows, "\n    " trailer.  Two-call protocol: with h_buf == NULL
+ * returns the exact byte count in *n_bytes_out; otherwise writes at most buf_cap bytes. */
+int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, size_t buf_cap,
+                   size_t* n_bytes_out);
+/* Same bytes straight to a file (formatted and written in slabs; replaces the open/write of c2w:122-132). */
+int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_points);
+/* "X,Y,Z\n" lines with Python repr() float formatting -- the camera / world txt of
+ * camera_to_world.py:80-81, 103-104 and transfer_T_icp.py:87,93.  If h_z_raw != NULL the third column
+ * is printed as that raw integer raster value (the reference's camera txt prints str(np.uint8));
+ * z_raw_dtype is R3D_DEPTH_U8 or R3D_DEPTH_U16.  append: 0 truncates ('w'), 1 appends ('a'). */
+int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw,
+                      int z_raw_dtype, int append);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3D_H */

@@ -1,0 +1,215 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same
+seeded inputs, against the golden fixtures, and through size-independent properties at
+BASELINE.json's full size.  Tolerance (north_star <= 1e-4 relative):
+  f32 output: point-wise ||d||/||ref|| <= 1e-6 and per-component |d| <= 1e-4*max(|ref|,1e-3||ref||)
+              (the kernel rounds the fp64 result once, so the observed error is ~6e-8);
+  f64 output: |d| <= 1e-12*(1+||ref||)  (summation order only).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import r3d as _r3d
+from oracle import fusion_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    return _r3d()
+
+
+@pytest.fixture(scope="module")
+def ctx(R):
+    c = R.Context(0)
+    yield c
+    c.close()
+
+
+def check(got, want, out_dtype):
+    assert got.shape == want.shape and got.dtype == out_dtype
+    if out_dtype == np.float32:
+        e_norm, e_comp = O.parity_errors(got, want)
+        assert e_norm <= 1e-6, e_norm
+        assert e_comp <= 1e-4, e_comp
+    else:
+        scale = 1.0 + np.linalg.norm(want, axis=1, keepdims=True)
+        assert (np.abs(got - want) / scale).max() <= 1e-12
+
+
+def make_depth(rng, shape, dtype):
+    if dtype == np.uint8:
+        return rng.integers(0, 256, size=shape, dtype=np.uint8)
+    if dtype == np.uint16:
+        return rng.integers(0, 65536, size=shape, dtype=np.uint16)
+    return (rng.random(size=shape) * 99.5 + 0.5).astype(np.float32)
+
+
+SHAPES = [(1, 4, 6), (3, 24, 32), (2, 37, 52), (1, 192, 640), (5, 33, 128), (2, 3, 2), (1, 1, 2), (1, 480, 640)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("ddtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("odtype", [np.float32, np.float64])
+def test_fuse_matches_oracle(R, ctx, shape, ddtype, odtype):
+    rng = np.random.default_rng(hash((shape, str(ddtype))) % 2**32)
+    d = make_depth(rng, shape, ddtype)
+    q = rng.normal(size=(shape[0], 4))
+    t = rng.normal(size=(shape[0], 3)) * 10
+    ctx.set_tuning("fuse_variant", 0)
+    got = R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx)
+    check(got, O.fuse_frames(d, q, t), odtype)
+    got_u = R.unproject(d, out_dtype=odtype, ctx=ctx)
+    want_u = np.concatenate([O.unproject(f) for f in d])
+    check(got_u, want_u, odtype)
+    if odtype == np.float64:  # unprojection is a single fp64 product per coordinate: bit exact
+        np.testing.assert_array_equal(got_u, want_u)
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 32), (2, 37, 52), (2, 100, 1280)])
+@pytest.mark.parametrize("odtype", [np.float32, np.float64])
+def test_variants_bitwise_equal(R, ctx, shape, odtype):
+    rng = np.random.default_rng(5)
+    d = make_depth(rng, shape, np.uint8)
+    q = rng.normal(size=(shape[0], 4))
+    t = rng.normal(size=(shape[0], 3)) * 10
+    outs = []
+    for variant in (1, 2, 3):
+        for nt in (0, 1):
+            ctx.set_tuning("fuse_variant", variant)
+            ctx.set_tuning("nontemporal", nt)
+            outs.append(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
+    for blocks in (1, 7, 300):
+        ctx.set_tuning("fuse_variant", 3)
+        ctx.set_tuning("fuse_blocks", blocks)
+        outs.append(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
+    ctx.set_tuning("fuse_variant", 0)
+    ctx.set_tuning("nontemporal", 0)
+    ctx.set_tuning("fuse_blocks", 0)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+
+
+def test_intrinsics_and_scale(R, ctx):
+    rng = np.random.default_rng(9)
+    d = make_depth(rng, (2, 20, 28), np.uint16)
+    q = rng.normal(size=(2, 4))
+    t = rng.normal(size=(2, 3))
+    K = (0.58 * 28, 1.92 * 20, 13.5, 9.5)  # monodepth2-KITTI style, non-integer principal point
+    got = R.fuse_frames(d, q, t, intrinsics=K, out_dtype=np.float64, depth_scale=1.0 / 256.0, ctx=ctx)
+    want = O.fuse_frames(d.astype(np.float64) / 256.0, q, t, *K)  # /256 is exact, so scale commutes
+    check(got, want, np.float64)
+
+
+def test_golden_scene3_and_kat(R, ctx, golden_dir):
+    from PIL import Image
+    scene = os.path.join(golden_dir, "scene3")
+    names, quats, ts = R.read_pose_file(os.path.join(scene, "camera_pose", "image_colmap_simi_2.txt"))
+    depths = np.stack([np.array(Image.open(os.path.join(scene, "depth", n)).convert("L")) for n in names])
+    want = R.cloud_io.read_ply(os.path.join(scene, "ply", "small_035_p8.ply"))  # reference output, 4 decimals
+    got64 = R.fuse_frames(depths, quats, ts, out_dtype=np.float64, ctx=ctx)
+    got32 = R.fuse_frames(depths, quats, ts, out_dtype=np.float32, ctx=ctx)
+    assert np.abs(got64 - want).max() <= 0.5001e-4
+    assert np.abs(got32.astype(np.float64) - want).max() <= 0.5e-4 + 1e-4 * np.abs(want).max()
+    # the reference's own PLY bytes, reproduced from the GPU's fp64 output through the native writer
+    assert R.cloud_io.format_ply(got64) == open(os.path.join(scene, "ply", "small_035_p8.ply"), "rb").read()
+    # world txt of the last frame, numerically
+    world = R.cloud_io.read_xyz_txt(os.path.join(scene, "point_world", "small_worldpoint_5_23_5.txt"))
+    check(got64[-768:], world, np.float64)
+    # KAT-1 camera txt, byte exact through the GPU (fp64 product == reference's)
+    j, i = np.mgrid[0:4, 0:6]
+    kat = ((7 * j + 3 * i + 1) % 256).astype(np.uint8)
+    cam = R.unproject(kat, out_dtype=np.float64, ctx=ctx)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        R.cloud_io.write_xyz_txt(os.path.join(td, "k.txt"), cam, z_raw=kat)
+        assert open(os.path.join(td, "k.txt")).read() == open(os.path.join(golden_dir, "kat_unproject_4x6.txt")).read()
+
+
+def test_golden_c1_world_points(R, ctx, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "c1_192x640.json")))
+    depth = np.random.default_rng(g["seed"]).integers(1, 256, tuple(g["shape"]), dtype=np.uint8)
+    got = R.fuse_frames(depth, [g["q_xyzw"]], [g["t"]], out_dtype=np.float64, ctx=ctx)
+    for k, xyz in g["world_xyz"].items():
+        np.testing.assert_allclose(got[int(k)], xyz, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(got.sum(0), g["world_sum_xyz"], rtol=1e-11)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 1024, 1025, 4099, 250001])
+@pytest.mark.parametrize("idt,odt", [(np.float32, np.float32), (np.float64, np.float64), (np.float32, np.float64),
+                                     (np.float64, np.float32)])
+def test_apply_T_and_se3(R, ctx, n, idt, odt):
+    rng = np.random.default_rng(n + 1)
+    p = (rng.normal(size=(n, 3)) * 50).astype(idt)
+    T = np.eye(4)
+    T[:3, :3] = 1.7 * np.asarray(R.scipy_transfer(rng.normal(size=4)))
+    T[:3, 3] = rng.normal(size=3) * 5
+    got = R.apply_T(p, T, out_dtype=odt, ctx=ctx)
+    check(got, O.apply_T(p, T), odt)
+    rinv = np.asarray(R.scipy_transfer(rng.normal(size=4)))
+    t = rng.normal(size=3) * 10
+    got = R.se3_apply(p, rinv, t, out_dtype=odt, ctx=ctx)
+    check(got, O.se3_apply(p, rinv, t), odt)
+
+
+def test_fuse_equals_unproject_then_se3_bitwise(R, ctx):
+    rng = np.random.default_rng(77)
+    d = make_depth(rng, (3, 40, 64), np.uint8)
+    q = rng.normal(size=(3, 4))
+    t = rng.normal(size=(3, 3)) * 10
+    fused = R.fuse_frames(d, q, t, out_dtype=np.float64, ctx=ctx)
+    cam = R.unproject(d, out_dtype=np.float64, ctx=ctx).reshape(3, -1, 3)
+    for k in range(3):
+        w = R.se3_apply(cam[k], R.scipy_transfer(q[k]), t[k], ctx=ctx)
+        np.testing.assert_array_equal(w, fused.reshape(3, -1, 3)[k])
+
+
+def test_identity_pose_is_unproject_bitwise(R, ctx):
+    rng = np.random.default_rng(78)
+    d = make_depth(rng, (2, 16, 20), np.uint8)
+    fused = R.fuse_frames(d, [[0, 0, 0, 1]] * 2, np.zeros((2, 3)), out_dtype=np.float32, ctx=ctx)
+    np.testing.assert_array_equal(fused, R.unproject(d, out_dtype=np.float32, ctx=ctx))
+
+
+def test_empty_and_errors(R, ctx):
+    assert R.fuse_frames(np.zeros((0, 8, 8), np.uint8), np.zeros((0, 4)), np.zeros((0, 3)), ctx=ctx).shape == (0, 3)
+    assert R.apply_T(np.zeros((0, 3), np.float32), np.eye(4), ctx=ctx).shape == (0, 3)
+    with pytest.raises(TypeError):
+        R.fuse_frames(np.zeros((1, 8, 8), np.int32), [[0, 0, 0, 1]], [[0, 0, 0]], ctx=ctx)
+    with pytest.raises(ValueError):
+        R.fuse_frames(np.zeros((2, 8, 8), np.uint8), [[0, 0, 0, 1]], [[0, 0, 0]], ctx=ctx)
+    with pytest.raises(ValueError):
+        R.fuse_frames(np.zeros((1, 8, 8), np.uint8), [[0, 0, 0, 0]], [[0, 0, 0]], ctx=ctx)
+    with pytest.raises(R.R3DError):
+        ctx.set_tuning("no_such_knob", 1)
+    with pytest.raises(R.R3DError):
+        R.Context(99)
+
+
+def test_full_size_c2_properties(R, ctx):
+    """BASELINE config 2: 100 frames of 1280x384 in one launch (49,152,000 points).
+    Size-independent checks: (1) the batch equals frame-by-frame launches bit for bit, (2) a
+    permutation of the frames permutes the output blocks, (3) linearity in Z along each ray:
+    fuse(2*depth) - fuse(depth) == Rinv.(p_cam), (4) oracle agreement on 3 whole frames."""
+    F, H, W = 100, 384, 1280
+    rng = np.random.default_rng(1234)
+    d = rng.integers(1, 128, size=(F, H, W), dtype=np.uint8)
+    q = rng.normal(size=(F, 4))
+    t = rng.normal(size=(F, 3)) * 10
+    full = R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx).reshape(F, H * W, 3)
+    for k in (0, 41, 99):
+        one = R.fuse_frames(d[k], q[k:k + 1], t[k:k + 1], out_dtype=np.float32, ctx=ctx)
+        np.testing.assert_array_equal(one, full[k])
+        check(one, O.fuse_frames(d[k:k + 1], q[k:k + 1], t[k:k + 1]), np.float32)
+    perm = rng.permutation(F)
+    np.testing.assert_array_equal(R.fuse_frames(d[perm], q[perm], t[perm], ctx=ctx).reshape(F, H * W, 3), full[perm])
+    G = 16  # fp64 clouds are 1.2 GB per 100 frames on the host: linearity on the first 16 frames
+    d, q, t = d[:G], q[:G], t[:G]
+    twice = R.fuse_frames((2 * d).astype(np.uint8), q, t, out_dtype=np.float64, ctx=ctx).reshape(G, H * W, 3)
+    once = R.fuse_frames(d, q, t, out_dtype=np.float64, ctx=ctx).reshape(G, H * W, 3)
+    zero_t = R.fuse_frames(d, q, np.zeros_like(t), out_dtype=np.float64, ctx=ctx).reshape(G, H * W, 3)
+    lin = np.abs((twice - once) - zero_t)
+    assert (lin / (1.0 + np.linalg.norm(zero_t, axis=2, keepdims=True))).max() <= 1e-12

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel variants on one MI355X (device-resident data, HIP events
+on the launch stream).  Usage: python tools/bench_variants.py [fuse|apply|nn|all] [--frames F]"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+r3d = importlib.import_module("3d_reconstruction_system_amd")
+
+
+def time_ms(ctx, fn, iters):
+    fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(iters):
+        fn()
+    return ctx.timer_stop() / iters
+
+
+def bench_fuse(ctx, F, H, W, rounds, iters):
+    rng = np.random.default_rng(1234)
+    n = F * H * W
+    depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
+    table = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
+    d_depth = ctx.alloc(n).upload(depth)
+    d_pose = ctx.alloc(table.nbytes).upload(table)
+    d_out = ctx.alloc(n * 12)
+    cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
+    configs = []
+    for variant in (1, 2, 3):
+        for nt in (0, 1):
+            for blocks in (0, 1024, 4096, 16384):
+                if variant == 1 and nt == 1:
+                    continue
+                configs.append((variant, nt, blocks))
+    results = {c: [] for c in configs}
+
+    def run():
+        r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+
+    for _ in range(rounds):
+        for c in configs:
+            ctx.set_tuning("fuse_variant", c[0])
+            ctx.set_tuning("nontemporal", c[1])
+            ctx.set_tuning("fuse_blocks", c[2])
+            results[c].append(time_ms(ctx, run, iters))
+    print("fuse %dx%dx%d = %.1f Mpts, 13 B/pt = %.1f MB per launch" % (F, H, W, n / 1e6, n * 13 / 1e6))
+    print("variant nt blocks   med_ms   min_ms   GB/s(med)  Gpts/s")
+    for c in configs:
+        med, mn = np.median(results[c]), np.min(results[c])
+        print("%7d %2d %6d %8.4f %8.4f %10.1f %7.1f" % (c[0], c[1], c[2], med, mn, n * 13 / med / 1e6, n / med / 1e6))
+    for k in ("fuse_variant", "nontemporal", "fuse_blocks"):
+        ctx.set_tuning(k, 0)
+
+
+def bench_apply(ctx, n, rounds, iters):
+    rng = np.random.default_rng(1)
+    p = (rng.normal(size=(n, 3)) * 50).astype(np.float32)
+    d_in = ctx.alloc(p.nbytes).upload(p)
+    d_out = ctx.alloc(p.nbytes)
+    T = np.eye(4)
+    T[:3, 3] = (1, 2, 3)
+    res = {}
+    for blocks in (0, 1024, 4096, 16384):
+        res[blocks] = []
+    for _ in range(rounds):
+        for blocks in res:
+            ctx.set_tuning("apply_blocks", blocks)
+            res[blocks].append(time_ms(ctx, lambda: r3d.apply_T_device(ctx, d_in.ptr, np.float32, n, T, d_out.ptr,
+                                                                       np.float32), iters))
+    ctx.set_tuning("apply_blocks", 0)
+    print("apply_T %.1f Mpts, 24 B/pt" % (n / 1e6))
+    for blocks, v in res.items():
+        med = np.median(v)
+        print("blocks %6d  med %.4f ms  %.1f GB/s" % (blocks, med, n * 24 / med / 1e6))
+
+
+def bench_nn(ctx, n, m, rounds):
+    import ctypes as C
+    L = importlib.import_module("3d_reconstruction_system_amd._lib")
+    rng = np.random.default_rng(7)
+    tgt = (rng.random(size=(m, 3)) * 20).astype(np.float32)
+    src = (rng.random(size=(n, 3)) * 20).astype(np.float32)
+    d_src = ctx.alloc(src.nbytes).upload(src)
+    d_tgt = ctx.alloc(tgt.nbytes).upload(tgt)
+    d_idx = ctx.alloc(n * 4)
+    d_d2 = ctx.alloc(n * 4)
+    print("nn %d x %d = %.3e pairs" % (n, m, n * m))
+    for S in (1, 2, 4):
+        ctx.set_tuning("nn_variant", S)
+        ts = []
+        for _ in range(rounds):
+            ts.append(time_ms(ctx, lambda: L.check(ctx.lib.r3d_icp_nn(ctx.handle, d_src.ptr, n, d_tgt.ptr, m,
+                                                                       d_idx.ptr, d_d2.ptr)), 1))
+        med = np.median(ts)
+        print("S=%d  med %.3f ms  %.2f Tpairs/s  (%.1f TFLOP/s at 8 flop/pair)" % (S, med, n * m / med / 1e9,
+                                                                                   n * m * 8 / med / 1e9))
+    ctx.set_tuning("nn_variant", 0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--nn", type=int, default=100000)
+    a = ap.parse_args()
+    ctx = r3d.Context(0)
+    if a.what in ("fuse", "all"):
+        bench_fuse(ctx, a.frames, 384, 1280, a.rounds, a.iters)
+    if a.what in ("apply", "all"):
+        bench_apply(ctx, 50_000_000, a.rounds, a.iters)
+    if a.what in ("nn", "all"):
+        bench_nn(ctx, a.nn, a.nn, 3)
+    ctx.close()
