@@ -6,10 +6,13 @@
 // (T = [Rinv | -Rinv t]).
 //
 // Roofline: HBM, 24 B/point (12 read + 12 written) for f32 clouds.
-// A 256-thread workgroup owns a tile of 1024 points = 12 KiB of xyz: it is read as tile-linear
-// 16-B pieces (1 KiB contiguous per wave instruction), staged in LDS, each lane transforms its
-// 4 points from LDS in fp64, writes them back to LDS, and the tile leaves again as linear
-// 16-B pieces.  In-place operation is safe: a tile is fully read before it is written.
+// Default (apply_variant 0): lane-per-point rounds.  In each round the 64 lanes of a wave hold 64
+// CONSECUTIVE points: one 12-byte load and one 12-byte nontemporal store per lane at a 12-byte lane
+// stride = 768 contiguous bytes per wave instruction, no LDS, no barrier.  The fused kernel's A/B
+// (profiles/variants_r01.md) showed this shape beating LDS-transposed 16-byte stores by 1.4x.
+// apply_variant 1 keeps that LDS design for comparison: a 256-thread workgroup owns a tile of 1024
+// points = 12 KiB, read and written as tile-linear 16-B pieces staged through LDS.
+// In-place operation is safe in both: a point is read before it is written, by the same lane.
 #include <type_traits>
 
 #include "r3d_internal.h"
@@ -103,9 +106,64 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const ApplyArgs a) {
   }
 }
 
+template <typename T>
+struct __attribute__((packed, aligned(4))) Packed3 {
+  T x, y, z;
+};
+
+template <typename OT>
+__device__ __forceinline__ void store3_nt(OT* dst, const double w[3]);
+template <>
+__device__ __forceinline__ void store3_nt<float>(float* dst, const double w[3]) {
+  typedef float v3 __attribute__((ext_vector_type(3)));
+  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(v3{(float)w[0], (float)w[1], (float)w[2]}) : "memory");
+}
+template <>
+__device__ __forceinline__ void store3_nt<double>(double* dst, const double w[3]) {
+  __builtin_nontemporal_store(w[0], dst);
+  __builtin_nontemporal_store(w[1], dst + 1);
+  __builtin_nontemporal_store(w[2], dst + 2);
+}
+
 template <typename IT, typename OT, bool SE3>
-void launch(const ApplyArgs& a, bool vec, int blocks, hipStream_t s) {
-  if (vec)
+__global__ __launch_bounds__(kThreads) void apply_lane_kernel(const ApplyArgs a) {
+  const IT* in = static_cast<const IT*>(a.in);
+  OT* out = static_cast<OT*>(a.out);
+  const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t base = tile * kTile + threadIdx.x;
+    Packed3<IT> p[kPts];
+#pragma unroll
+    for (int r = 0; r < kPts; ++r) {
+      const uint64_t i = base + (uint64_t)r * kThreads;
+      if (i < a.n) p[r] = reinterpret_cast<const Packed3<IT>*>(in)[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kPts; ++r) {
+      const uint64_t i = base + (uint64_t)r * kThreads;
+      if (i < a.n) {
+        const double x = (double)p[r].x, y = (double)p[r].y, z = (double)p[r].z;
+        double w[3];
+        if (SE3) {
+          const double dx = x - a.T[9], dy = y - a.T[10], dz = z - a.T[11];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) w[c] = fma(a.T[3 * c + 2], dz, fma(a.T[3 * c + 1], dy, a.T[3 * c + 0] * dx));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            w[c] = fma(a.T[4 * c + 2], z, fma(a.T[4 * c + 1], y, a.T[4 * c + 0] * x)) + a.T[4 * c + 3];
+        }
+        store3_nt<OT>(out + i * 3, w);
+      }
+    }
+  }
+}
+
+template <typename IT, typename OT, bool SE3>
+void launch(const ApplyArgs& a, int variant, bool vec, int blocks, hipStream_t s) {
+  if (variant == 0)
+    hipLaunchKernelGGL((apply_lane_kernel<IT, OT, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
+  else if (vec)
     hipLaunchKernelGGL((apply_kernel<IT, OT, true, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
   else
     hipLaunchKernelGGL((apply_kernel<IT, OT, false, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
@@ -135,13 +193,13 @@ int apply_common(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_poi
   int blocks = ctx->apply_blocks > 0 ? ctx->apply_blocks : ctx->num_cus * 8;
   if ((uint64_t)blocks > n_tiles) blocks = (int)n_tiles;
   if (in_dtype == R3D_F32 && out_dtype == R3D_F32)
-    launch<float, float, SE3>(a, vec, blocks, ctx->stream);
+    launch<float, float, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
   else if (in_dtype == R3D_F32)
-    launch<float, double, SE3>(a, vec, blocks, ctx->stream);
+    launch<float, double, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
   else if (out_dtype == R3D_F32)
-    launch<double, float, SE3>(a, vec, blocks, ctx->stream);
+    launch<double, float, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
   else
-    launch<double, double, SE3>(a, vec, blocks, ctx->stream);
+    launch<double, double, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

@@ -13,10 +13,11 @@
 //   * a TILE is 1024 consecutive pixels of one frame = one 256-thread workgroup, 4 pixels per
 //     lane: one 4-byte (u8) / 8-byte (u16) / 16-byte (f32) load per lane, 256 B..1 KiB per
 //     wave instruction, fully coalesced.
-//   * the lane's 4 points (48 B) are staged through LDS (12 KiB per workgroup) and leave as
-//     3 x 16-B stores per lane at consecutive 16-B slots: every wave store instruction writes
-//     1 KiB contiguous instead of 64 16-B pieces 48 B apart.  (variant 3; variant 2 stores the
-//     48 B directly, variant 1 is the scalar any-width path.)
+//   * the lane's 4 points (48 B) are staged through LDS and leave as 3 x 16-B stores per lane at
+//     consecutive 16-B slots: every wave store instruction writes 1 KiB contiguous instead of 64
+//     16-B pieces 48 B apart.  Variant 4 (default) does this per WAVE with no workgroup barrier and
+//     with the next tile's depth load already in flight; variant 3 per workgroup with barriers;
+//     variant 2 stores the 48 B directly; variant 1 is the scalar any-width path.
 //   * the grid is capped (persistent-style) and strides over tiles; tile -> (frame, tile in
 //     frame) is advanced incrementally on the scalar unit, the per-frame pose (96 B) comes in
 //     through scalar loads, and the per-lane row/column split is one mulhi (magic division).
@@ -33,28 +34,33 @@ constexpr int kThreads = 256;
 constexpr int kPx = 4;                      // pixels per lane
 constexpr int kTile = kThreads * kPx;       // pixels per workgroup tile
 
-struct FuseArgs {
-  const void* depth;
-  void* out;
-  const double* u;     // [W] padded to x4
-  const double* v;     // [H]
-  const double* pose;  // [F][12] or nullptr (unproject only)
+struct FuseDims {
   double scale;
   uint32_t hw;              // H*W
   uint32_t width;
-  uint32_t tiles_per_frame; // ceil(hw / kTile)
+  uint32_t tiles_per_frame; // ceil(hw / tile), tile = 1024 px (variants 1-3) or 256 px (variant 4)
   uint32_t n_frames;
   uint32_t w_magic;         // floor(x / width) = (x * w_magic) >> w_shift for x < 2^31 (make_magic)
   uint32_t w_shift;
+  uint32_t t_magic;         // floor(tile / tiles_per_frame), same scheme
+  uint32_t t_shift;
+  uint32_t total_tiles;     // tiles_per_frame * n_frames (< 2^31)
 };
+
+__device__ __forceinline__ uint32_t magic_div(uint32_t x, uint32_t magic, uint32_t shift) {
+  return (uint32_t)(((uint64_t)x * magic) >> shift);
+}
 
 // ---- depth loads: 4 consecutive rasters elements -> 4 doubles ----
 template <typename DT>
 struct Depth4;
 template <>
 struct Depth4<uint8_t> {
-  static __device__ __forceinline__ void load(const void* base, uint64_t idx, double z[4]) {
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(base) + idx);
+  using raw_t = uint32_t;
+  static __device__ __forceinline__ raw_t fetch(const uint8_t* base, uint64_t idx) {
+    return *reinterpret_cast<const uint32_t*>(base + idx);
+  }
+  static __device__ __forceinline__ void unpack(const raw_t& w, double z[4]) {
     z[0] = (double)(w & 0xffu);
     z[1] = (double)((w >> 8) & 0xffu);
     z[2] = (double)((w >> 16) & 0xffu);
@@ -63,8 +69,11 @@ struct Depth4<uint8_t> {
 };
 template <>
 struct Depth4<uint16_t> {
-  static __device__ __forceinline__ void load(const void* base, uint64_t idx, double z[4]) {
-    const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + idx);
+  using raw_t = uint2;
+  static __device__ __forceinline__ raw_t fetch(const uint16_t* base, uint64_t idx) {
+    return *reinterpret_cast<const uint2*>(base + idx);
+  }
+  static __device__ __forceinline__ void unpack(const raw_t& w, double z[4]) {
     z[0] = (double)(w.x & 0xffffu);
     z[1] = (double)(w.x >> 16);
     z[2] = (double)(w.y & 0xffffu);
@@ -73,8 +82,11 @@ struct Depth4<uint16_t> {
 };
 template <>
 struct Depth4<float> {
-  static __device__ __forceinline__ void load(const void* base, uint64_t idx, double z[4]) {
-    const float4 w = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+  using raw_t = float4;
+  static __device__ __forceinline__ raw_t fetch(const float* base, uint64_t idx) {
+    return *reinterpret_cast<const float4*>(base + idx);
+  }
+  static __device__ __forceinline__ void unpack(const raw_t& w, double z[4]) {
     z[0] = (double)w.x;
     z[1] = (double)w.y;
     z[2] = (double)w.z;
@@ -121,76 +133,84 @@ __device__ __forceinline__ void store16(void* dst, const T& v, bool nt) {
     *reinterpret_cast<T*>(dst) = v;
 }
 
-// VARIANT 1: scalar any-width; 2: vec4 loads + direct 48-B stores; 3: vec4 loads + LDS-transposed stores
+// Everything the four variants share for one lane's 4 pixels that lie in one row.
+template <typename DT, typename OT, bool POSE>
+__device__ __forceinline__ void quad(const typename Depth4<DT>::raw_t& raw, uint32_t p0, const double* __restrict__ u,
+                                     const double* __restrict__ v, const FuseDims& dm, const Pose& P, OT o[12]) {
+  const uint32_t j = magic_div(p0, dm.w_magic, dm.w_shift);
+  const uint32_t i = p0 - j * dm.width;  // width % 4 == 0: the 4 pixels share row j
+  double z[4];
+  Depth4<DT>::unpack(raw, z);
+  const double2 u01 = *reinterpret_cast<const double2*>(u + i);
+  const double2 u23 = *reinterpret_cast<const double2*>(u + i + 2);
+  const double vj = v[j];
+  const double uu[4] = {u01.x, u01.y, u23.x, u23.y};
+#pragma unroll
+  for (int k = 0; k < kPx; ++k) {
+    double w[3];
+    point<POSE>(z[k] * dm.scale, uu[k], vj, P, w);
+    o[3 * k + 0] = (OT)w[0];
+    o[3 * k + 1] = (OT)w[1];
+    o[3 * k + 2] = (OT)w[2];
+  }
+}
+
+template <bool POSE>
+__device__ __forceinline__ void load_pose(const double* __restrict__ pose, uint32_t frame, Pose& P) {
+  if (POSE) {
+    const double* pp = pose + (uint64_t)frame * 12;  // wave-uniform address: scalar loads
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.r[k] = pp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.t[k] = pp[9 + k];
+  }
+}
+
+// VARIANT 1: scalar any-width; 2: vec4 loads + direct 48-B stores; 3: vec4 loads + LDS-transposed stores,
+// 1024-px workgroup tiles, two barriers per tile.
 template <typename DT, typename OT, bool POSE, int VARIANT, bool NT>
-__global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a) {
+__global__ __launch_bounds__(kThreads) void fuse_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
+                                                        const double* __restrict__ u, const double* __restrict__ v,
+                                                        const double* __restrict__ pose, const FuseDims dm) {
   constexpr int kVecPerLane = (int)(kPx * 3 * sizeof(OT) / 16);  // 16-B pieces per lane: 3 (f32) or 6 (f64)
+  using V16 = typename std::conditional<sizeof(OT) == 4, f32x4, f64x2>::type;
   __shared__ __attribute__((aligned(16))) OT lds[VARIANT == 3 ? kTile * 3 : 4];
 
   const uint32_t tid = threadIdx.x;
-  // tile walk: frame / tile-in-frame advance incrementally, all wave-uniform (scalar unit)
-  uint32_t tf = blockIdx.x;
-  uint32_t frame = 0;
-  while (tf >= a.tiles_per_frame) {
-    tf -= a.tiles_per_frame;
-    ++frame;
-  }
-  while (frame < a.n_frames) {
+  // tile walk: tile -> (frame, tile in frame) by magic division, all wave-uniform (scalar unit)
+  for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
     Pose P;
-    if (POSE) {
-      const double* pp = a.pose + (uint64_t)frame * 12;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) P.r[k] = pp[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) P.t[k] = pp[9 + k];
-    }
+    load_pose<POSE>(pose, frame, P);
     const uint32_t p0 = tf * kTile + tid * kPx;              // first pixel of this lane within the frame
-    const uint64_t g0 = (uint64_t)frame * a.hw + p0;         // ... within the batch
+    const uint64_t g0 = (uint64_t)frame * dm.hw + p0;        // ... within the batch
     OT o[kPx * 3];
 
     if (VARIANT == 1) {
 #pragma unroll
       for (int k = 0; k < kPx; ++k) {
         const uint32_t p = p0 + k;
-        if (p < a.hw) {
-          const uint32_t j = (uint32_t)(((uint64_t)p * a.w_magic) >> a.w_shift);
-          const uint32_t i = p - j * a.width;
-          const double z = (double)static_cast<const DT*>(a.depth)[g0 + k] * a.scale;
+        if (p < dm.hw) {
+          const uint32_t j = magic_div(p, dm.w_magic, dm.w_shift);
+          const uint32_t i = p - j * dm.width;
+          const double z = (double)depth[g0 + k] * dm.scale;
           double w[3];
-          point<POSE>(z, a.u[i], a.v[j], P, w);
-          OT* dst = static_cast<OT*>(a.out) + (g0 + k) * 3;
+          point<POSE>(z, u[i], v[j], P, w);
+          OT* dst = out + (g0 + k) * 3;
           dst[0] = (OT)w[0];
           dst[1] = (OT)w[1];
           dst[2] = (OT)w[2];
         }
       }
     } else {
-      const bool live = p0 < a.hw;  // hw % 4 == 0 on this path: a lane is wholly in or out
-      if (live) {
-        const uint32_t j = (uint32_t)(((uint64_t)p0 * a.w_magic) >> a.w_shift);
-        const uint32_t i = p0 - j * a.width;  // width % 4 == 0: the 4 pixels share row j
-        double z[4];
-        Depth4<DT>::load(a.depth, g0, z);
-        const double2 u01 = *reinterpret_cast<const double2*>(a.u + i);
-        const double2 u23 = *reinterpret_cast<const double2*>(a.u + i + 2);
-        const double vj = a.v[j];
-        const double uu[4] = {u01.x, u01.y, u23.x, u23.y};
-#pragma unroll
-        for (int k = 0; k < kPx; ++k) {
-          double w[3];
-          point<POSE>(z[k] * a.scale, uu[k], vj, P, w);
-          o[3 * k + 0] = (OT)w[0];
-          o[3 * k + 1] = (OT)w[1];
-          o[3 * k + 2] = (OT)w[2];
-        }
-      }
-      using V16 = typename std::conditional<sizeof(OT) == 4, f32x4, f64x2>::type;
+      const bool live = p0 < dm.hw;  // hw % 4 == 0 on this path: a lane is wholly in or out
+      if (live) quad<DT, OT, POSE>(Depth4<DT>::fetch(depth, g0), p0, u, v, dm, P, o);
       if (VARIANT == 2) {
         if (live) {
-          char* dst = static_cast<char*>(a.out) + g0 * (3 * sizeof(OT));
+          char* dst = reinterpret_cast<char*>(out) + g0 * (3 * sizeof(OT));
 #pragma unroll
-          for (int k = 0; k < kVecPerLane; ++k)
-            store16<V16>(dst + 16 * k, piece(o, k), NT);
+          for (int k = 0; k < kVecPerLane; ++k) store16<V16>(dst + 16 * k, piece(o, k), NT);
         }
       } else {  // VARIANT 3
         if (live) {
@@ -200,9 +220,9 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a) {
         }
         __syncthreads();
         // pieces of 16 B, tile-linear: piece q holds bytes [16q, 16q+16) of the tile's output
-        const uint32_t px_in_tile = min((uint32_t)kTile, a.hw - tf * kTile);
+        const uint32_t px_in_tile = min((uint32_t)kTile, dm.hw - tf * kTile);
         const uint32_t n_pieces = px_in_tile * (uint32_t)(3 * sizeof(OT) / 4) / 4;  // px*3*sizeof/16
-        char* tile_out = static_cast<char*>(a.out) + ((uint64_t)frame * a.hw + (uint64_t)tf * kTile) * (3 * sizeof(OT));
+        char* tile_out = reinterpret_cast<char*>(out) + ((uint64_t)frame * dm.hw + (uint64_t)tf * kTile) * (3 * sizeof(OT));
 #pragma unroll
         for (int k = 0; k < kVecPerLane; ++k) {
           const uint32_t q = k * kThreads + tid;
@@ -211,47 +231,214 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a) {
         __syncthreads();
       }
     }
-    // next tile of this workgroup
-    tf += gridDim.x;
-    while (tf >= a.tiles_per_frame) {
-      tf -= a.tiles_per_frame;
-      ++frame;
+  }
+}
+
+// VARIANT 4: every WAVE is autonomous.  Its tile is 256 consecutive pixels (4 per lane); the 3 KiB of
+// xyz it produces go through the wave's private LDS slice and leave as 3 x 1 KiB contiguous stores.
+// No workgroup barrier anywhere (same-wave LDS ops complete in order), and the depth word of the
+// wave's NEXT tile is already in flight while the current tile is computed and stored.
+constexpr int kWaveTile = 64 * kPx;
+
+template <typename DT, typename OT, bool POSE, bool NT>
+__global__ __launch_bounds__(kThreads) void fuse_wave_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
+                                                             const double* __restrict__ u, const double* __restrict__ v,
+                                                             const double* __restrict__ pose, const FuseDims dm) {
+  constexpr int kVecPerLane = (int)(kPx * 3 * sizeof(OT) / 16);
+  using V16 = typename std::conditional<sizeof(OT) == 4, f32x4, f64x2>::type;
+  using Raw = typename Depth4<DT>::raw_t;
+  __shared__ __attribute__((aligned(16))) OT lds_all[kThreads / 64][kWaveTile * 3];
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  OT* lds = lds_all[wave];
+  const uint32_t stride = gridDim.x * (kThreads / 64);
+  uint32_t tile = blockIdx.x * (kThreads / 64) + wave;
+  Raw raw_next = {};
+  uint32_t frame = 0, tf = 0;
+  if (tile < dm.total_tiles) {
+    frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    tf = tile - frame * dm.tiles_per_frame;
+    const uint32_t p0 = tf * kWaveTile + lane * kPx;
+    if (p0 < dm.hw) raw_next = Depth4<DT>::fetch(depth, (uint64_t)frame * dm.hw + p0);
+  }
+  while (tile < dm.total_tiles) {
+    const Raw raw = raw_next;
+    const uint32_t cur_tf = tf, cur_frame = frame;
+    // advance, and put the next tile's depth load in flight before touching the current one
+    tile += stride;
+    if (tile < dm.total_tiles) {
+      frame = magic_div(tile, dm.t_magic, dm.t_shift);
+      tf = tile - frame * dm.tiles_per_frame;
+      const uint32_t pn = tf * kWaveTile + lane * kPx;
+      if (pn < dm.hw) raw_next = Depth4<DT>::fetch(depth, (uint64_t)frame * dm.hw + pn);
+    }
+    Pose P;
+    load_pose<POSE>(pose, cur_frame, P);
+    const uint32_t p0 = cur_tf * kWaveTile + lane * kPx;
+    OT o[kPx * 3];
+    if (p0 < dm.hw) {
+      quad<DT, OT, POSE>(raw, p0, u, v, dm, P, o);
+      V16* mine = reinterpret_cast<V16*>(lds) + lane * kVecPerLane;
+#pragma unroll
+      for (int k = 0; k < kVecPerLane; ++k) mine[k] = piece(o, k);
+    }
+    // same-wave LDS hand-off: writes above are ordered before the reads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t px_in_tile = min((uint32_t)kWaveTile, dm.hw - cur_tf * kWaveTile);
+    const uint32_t n_pieces = px_in_tile * (uint32_t)(3 * sizeof(OT) / 4) / 4;
+    char* tile_out = reinterpret_cast<char*>(out) + ((uint64_t)cur_frame * dm.hw + (uint64_t)cur_tf * kWaveTile) * (3 * sizeof(OT));
+#pragma unroll
+    for (int k = 0; k < kVecPerLane; ++k) {
+      const uint32_t q = k * 64 + lane;
+      if (q < n_pieces) store16<V16>(tile_out + (uint64_t)q * 16, reinterpret_cast<const V16*>(lds)[q], NT);
+    }
+    // the next iteration's LDS writes must not pass this iteration's reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// VARIANT 5: lane-per-pixel rounds, no LDS.  A workgroup tile is still 1024 consecutive pixels, but lane
+// `tid` takes pixels tid, tid+256, tid+512, tid+768 of it, so in every round the 64 lanes of a wave hold
+// 64 CONSECUTIVE pixels: the depth read is one coalesced element per lane and the xyz write is one
+// 12-byte (f32) or 24-byte (f64) store per lane at a 12/24-byte lane stride = 768 / 1536 contiguous
+// bytes per wave instruction.  Nothing is shared between lanes, so any raster width works.
+// store modes of the lane-per-pixel kernel: 0 one x3 store, 1 three nontemporal scalar stores,
+// 2 three plain scalar stores, 3 one nontemporal x3 store
+template <typename T>
+struct Xyz3;
+template <>
+struct Xyz3<float> {
+  typedef float v3 __attribute__((ext_vector_type(3)));
+  template <int MODE>
+  static __device__ __forceinline__ void store(float* dst, const double w[3]) {
+    const float a = (float)w[0], b = (float)w[1], c = (float)w[2];
+    if (MODE == 1) {
+      __builtin_nontemporal_store(a, dst);
+      __builtin_nontemporal_store(b, dst + 1);
+      __builtin_nontemporal_store(c, dst + 2);
+    } else if (MODE == 2) {
+      dst[0] = a;
+      dst[1] = b;
+      dst[2] = c;
+    } else if (MODE == 3) {
+      asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(v3{a, b, c}) : "memory");
+    } else {
+      // one global_store_dwordx3 (4-byte alignment suffices on gfx950)
+      asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(dst), "v"(v3{a, b, c}) : "memory");
+    }
+  }
+};
+template <>
+struct Xyz3<double> {
+  template <int MODE>
+  static __device__ __forceinline__ void store(double* dst, const double w[3]) {
+    if (MODE == 1 || MODE == 3) {
+      __builtin_nontemporal_store(w[0], dst);
+      __builtin_nontemporal_store(w[1], dst + 1);
+      __builtin_nontemporal_store(w[2], dst + 2);
+    } else {
+      dst[0] = w[0];
+      dst[1] = w[1];
+      dst[2] = w[2];
+    }
+  }
+};
+
+template <typename DT, typename OT, bool POSE, int MODE>
+__global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
+                                                             const double* __restrict__ u, const double* __restrict__ v,
+                                                             const double* __restrict__ pose, const FuseDims dm) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
+    Pose P;
+    load_pose<POSE>(pose, frame, P);
+    const uint64_t fbase = (uint64_t)frame * dm.hw;
+    DT raw[kPx];
+#pragma unroll
+    for (int r = 0; r < kPx; ++r) {
+      const uint32_t p = tf * kTile + r * kThreads + tid;
+      raw[r] = p < dm.hw ? depth[fbase + p] : DT(0);
+    }
+#pragma unroll
+    for (int r = 0; r < kPx; ++r) {
+      const uint32_t p = tf * kTile + r * kThreads + tid;
+      if (p < dm.hw) {
+        const uint32_t j = magic_div(p, dm.w_magic, dm.w_shift);
+        const uint32_t i = p - j * dm.width;
+        double w[3];
+        point<POSE>((double)raw[r] * dm.scale, u[i], v[j], P, w);
+        Xyz3<OT>::template store<MODE>(out + (fbase + p) * 3, w);
+      }
     }
   }
 }
 
-template <typename DT, typename OT, bool POSE, int VARIANT>
-void launch_nt(const FuseArgs& a, int blocks, bool nt, hipStream_t s) {
-  if (nt)
-    hipLaunchKernelGGL((fuse_kernel<DT, OT, POSE, VARIANT, true>), dim3(blocks), dim3(kThreads), 0, s, a);
+struct FusePtrs {
+  const void* depth;
+  void* out;
+  const double* u;
+  const double* v;
+  const double* pose;
+};
+
+template <typename DT, typename OT, bool POSE, int VARIANT, bool NT>
+void launch_one(const FusePtrs& p, const FuseDims& dm, int blocks, hipStream_t s) {
+  if (VARIANT == 4)
+    hipLaunchKernelGGL((fuse_wave_kernel<DT, OT, POSE, NT>), dim3(blocks), dim3(kThreads), 0, s,
+                       static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
   else
-    hipLaunchKernelGGL((fuse_kernel<DT, OT, POSE, VARIANT, false>), dim3(blocks), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((fuse_kernel<DT, OT, POSE, (VARIANT >= 4 ? 3 : VARIANT), NT>), dim3(blocks), dim3(kThreads), 0, s,
+                       static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
+}
+
+template <typename DT, typename OT, bool POSE, int MODE>
+void launch_lane(const FusePtrs& p, const FuseDims& dm, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((fuse_lane_kernel<DT, OT, POSE, MODE>), dim3(blocks), dim3(kThreads), 0, s,
+                     static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
 }
 
 template <typename DT, typename OT, bool POSE>
-void launch_variant(const FuseArgs& a, int variant, int blocks, bool nt, hipStream_t s) {
+void launch_variant(const FusePtrs& p, const FuseDims& dm, int variant, int blocks, int ntmode, hipStream_t s) {
+  const bool nt = ntmode != 0;
+  if (variant == 5) {
+    switch (ntmode) {
+      case 0: launch_lane<DT, OT, POSE, 0>(p, dm, blocks, s); break;
+      case 2: launch_lane<DT, OT, POSE, 2>(p, dm, blocks, s); break;
+      case 3: launch_lane<DT, OT, POSE, 3>(p, dm, blocks, s); break;
+      default: launch_lane<DT, OT, POSE, 1>(p, dm, blocks, s); break;
+    }
+    return;
+  }
   switch (variant) {
-    case 1: launch_nt<DT, OT, POSE, 1>(a, blocks, false, s); break;
-    case 2: launch_nt<DT, OT, POSE, 2>(a, blocks, nt, s); break;
-    default: launch_nt<DT, OT, POSE, 3>(a, blocks, nt, s); break;
+    case 1: launch_one<DT, OT, POSE, 1, false>(p, dm, blocks, s); break;
+    case 2: nt ? launch_one<DT, OT, POSE, 2, true>(p, dm, blocks, s) : launch_one<DT, OT, POSE, 2, false>(p, dm, blocks, s); break;
+    case 3: nt ? launch_one<DT, OT, POSE, 3, true>(p, dm, blocks, s) : launch_one<DT, OT, POSE, 3, false>(p, dm, blocks, s); break;
+    default: nt ? launch_one<DT, OT, POSE, 4, true>(p, dm, blocks, s) : launch_one<DT, OT, POSE, 4, false>(p, dm, blocks, s); break;
   }
 }
 
 template <typename DT, bool POSE>
-void launch_out(const FuseArgs& a, int out_dtype, int variant, int blocks, bool nt, hipStream_t s) {
+void launch_out(const FusePtrs& p, const FuseDims& dm, int out_dtype, int variant, int blocks, int nt, hipStream_t s) {
   if (out_dtype == R3D_F32)
-    launch_variant<DT, float, POSE>(a, variant, blocks, nt, s);
+    launch_variant<DT, float, POSE>(p, dm, variant, blocks, nt, s);
   else
-    launch_variant<DT, double, POSE>(a, variant, blocks, nt, s);
+    launch_variant<DT, double, POSE>(p, dm, variant, blocks, nt, s);
 }
 
 template <bool POSE>
-void launch_depth(const FuseArgs& a, int depth_dtype, int out_dtype, int variant, int blocks, bool nt,
-                  hipStream_t s) {
+void launch_depth(const FusePtrs& p, const FuseDims& dm, int depth_dtype, int out_dtype, int variant, int blocks,
+                  int nt, hipStream_t s) {
   switch (depth_dtype) {
-    case R3D_DEPTH_U8: launch_out<uint8_t, POSE>(a, out_dtype, variant, blocks, nt, s); break;
-    case R3D_DEPTH_U16: launch_out<uint16_t, POSE>(a, out_dtype, variant, blocks, nt, s); break;
-    default: launch_out<float, POSE>(a, out_dtype, variant, blocks, nt, s); break;
+    case R3D_DEPTH_U8: launch_out<uint8_t, POSE>(p, dm, out_dtype, variant, blocks, nt, s); break;
+    case R3D_DEPTH_U16: launch_out<uint16_t, POSE>(p, dm, out_dtype, variant, blocks, nt, s); break;
+    default: launch_out<float, POSE>(p, dm, out_dtype, variant, blocks, nt, s); break;
   }
 }
 
@@ -278,33 +465,36 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   R3D_REQUIRE(d_depth && d_out, "NULL device pointer");
   R3D_REQUIRE(!with_pose || d_pose, "pose table is NULL");
   const uint64_t hw = (uint64_t)cam->height * cam->width;
-  FuseArgs a;
-  a.depth = d_depth;
-  a.out = d_out;
-  a.u = cam->d_u;
-  a.v = cam->d_v;
-  a.pose = with_pose ? d_pose : nullptr;
-  a.scale = depth_scale;
-  a.hw = (uint32_t)hw;
-  a.width = (uint32_t)cam->width;
-  a.tiles_per_frame = (uint32_t)((hw + kTile - 1) / kTile);
-  a.n_frames = (uint32_t)n_frames;
-  make_magic(a.width, &a.w_magic, &a.w_shift);
-  const uint64_t total_tiles = (uint64_t)a.tiles_per_frame * n_frames;
-
   // vector paths need the 4 pixels of a lane in one row and 16-B aligned output pieces
   const size_t dsz = r3d_depth_size(depth_dtype);
   const bool vec_ok = (cam->width % 4 == 0) && (((uintptr_t)d_depth % (4 * dsz)) == 0) && (((uintptr_t)d_out % 16) == 0);
   int variant = ctx->fuse_variant;
-  if (variant == 0) variant = 3;
-  if (!vec_ok) variant = 1;
-
-  int blocks = ctx->fuse_blocks > 0 ? ctx->fuse_blocks : ctx->num_cus * 8;
-  if ((uint64_t)blocks > total_tiles) blocks = (int)total_tiles;
+  if (variant < 1 || variant > 5) variant = 5;  // measured best on MI355X (profiles/variants_r01.md)
+  if (!vec_ok && variant != 5) variant = 1;
+  int ntmode = ctx->nontemporal;
+  if (ctx->fuse_variant == 0) ntmode = 3;      // auto: lane-per-pixel kernel with one nontemporal x3 store
+  const uint32_t tile = variant == 4 ? kWaveTile : kTile;
+  FusePtrs p{d_depth, d_out, cam->d_u, cam->d_v, with_pose ? d_pose : nullptr};
+  FuseDims dm;
+  dm.scale = depth_scale;
+  dm.hw = (uint32_t)hw;
+  dm.width = (uint32_t)cam->width;
+  dm.tiles_per_frame = (uint32_t)((hw + tile - 1) / tile);
+  dm.n_frames = (uint32_t)n_frames;
+  make_magic(dm.width, &dm.w_magic, &dm.w_shift);
+  make_magic(dm.tiles_per_frame, &dm.t_magic, &dm.t_shift);
+  const uint64_t total_tiles = (uint64_t)dm.tiles_per_frame * n_frames;
+  R3D_REQUIRE(total_tiles < ((uint64_t)1 << 31), "batch too large for one launch (%llu tiles); split the frames",
+              (unsigned long long)total_tiles);
+  dm.total_tiles = (uint32_t)total_tiles;
+  const uint64_t tiles_per_block = variant == 4 ? kThreads / 64 : 1;
+  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : (uint64_t)ctx->num_cus * 8;
+  const uint64_t max_blocks = (total_tiles + tiles_per_block - 1) / tiles_per_block;
+  if (blocks > max_blocks) blocks = max_blocks;
   if (with_pose)
-    launch_depth<true>(a, depth_dtype, out_dtype, variant, blocks, ctx->nontemporal != 0, ctx->stream);
+    launch_depth<true>(p, dm, depth_dtype, out_dtype, variant, (int)blocks, ntmode, ctx->stream);
   else
-    launch_depth<false>(a, depth_dtype, out_dtype, variant, blocks, ctx->nontemporal != 0, ctx->stream);
+    launch_depth<false>(p, dm, depth_dtype, out_dtype, variant, (int)blocks, ntmode, ctx->stream);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

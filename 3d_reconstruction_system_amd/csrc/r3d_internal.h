@@ -22,6 +22,7 @@ struct r3d_ctx {
   int nontemporal = 0;
   int nn_variant = 0;
   int apply_blocks = 0;
+  int apply_variant = 0;  // 0 lane-per-point (default), 1 LDS-tiled
   // HIP-event stopwatch
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // grow-only scratch buffers for the *_host entry points and reductions

@@ -31,6 +31,8 @@ def ctx(R):
 
 def check(got, want, out_dtype):
     assert got.shape == want.shape and got.dtype == out_dtype
+    if got.size == 0:
+        return
     if out_dtype == np.float32:
         e_norm, e_comp = O.parity_errors(got, want)
         assert e_norm <= 1e-6, e_norm
@@ -77,8 +79,8 @@ def test_variants_bitwise_equal(R, ctx, shape, odtype):
     q = rng.normal(size=(shape[0], 4))
     t = rng.normal(size=(shape[0], 3)) * 10
     outs = []
-    for variant in (1, 2, 3):
-        for nt in (0, 1):
+    for variant in (1, 2, 3, 4, 5):
+        for nt in ((0, 1, 2, 3) if variant == 5 else (0, 1)):
             ctx.set_tuning("fuse_variant", variant)
             ctx.set_tuning("nontemporal", nt)
             outs.append(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
@@ -147,12 +149,19 @@ def test_apply_T_and_se3(R, ctx, n, idt, odt):
     T = np.eye(4)
     T[:3, :3] = 1.7 * np.asarray(R.scipy_transfer(rng.normal(size=4)))
     T[:3, 3] = rng.normal(size=3) * 5
-    got = R.apply_T(p, T, out_dtype=odt, ctx=ctx)
-    check(got, O.apply_T(p, T), odt)
     rinv = np.asarray(R.scipy_transfer(rng.normal(size=4)))
     t = rng.normal(size=3) * 10
-    got = R.se3_apply(p, rinv, t, out_dtype=odt, ctx=ctx)
-    check(got, O.se3_apply(p, rinv, t), odt)
+    outs = []
+    for variant in (0, 1):  # lane-per-point (default) and LDS-tiled: same arithmetic, bit-identical results
+        ctx.set_tuning("apply_variant", variant)
+        got = R.apply_T(p, T, out_dtype=odt, ctx=ctx)
+        check(got, O.apply_T(p, T), odt)
+        got2 = R.se3_apply(p, rinv, t, out_dtype=odt, ctx=ctx)
+        check(got2, O.se3_apply(p, rinv, t), odt)
+        outs.append((got, got2))
+    ctx.set_tuning("apply_variant", 0)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
 def test_fuse_equals_unproject_then_se3_bitwise(R, ctx):

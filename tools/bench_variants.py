@@ -32,10 +32,10 @@ def bench_fuse(ctx, F, H, W, rounds, iters):
     d_out = ctx.alloc(n * 12)
     cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
     configs = []
-    for variant in (1, 2, 3):
-        for nt in (0, 1):
-            for blocks in (0, 1024, 4096, 16384):
-                if variant == 1 and nt == 1:
+    for variant in (3, 5):
+        for nt in (0, 1, 2, 3):
+            for blocks in (1024, 2048, 4096, 1000000):
+                if variant != 5 and nt > 1:
                     continue
                 configs.append((variant, nt, blocks))
     results = {c: [] for c in configs}
@@ -66,18 +66,21 @@ def bench_apply(ctx, n, rounds, iters):
     T = np.eye(4)
     T[:3, 3] = (1, 2, 3)
     res = {}
-    for blocks in (0, 1024, 4096, 16384):
-        res[blocks] = []
+    for variant in (0, 1):
+        for blocks in (1024, 2048, 4096, 16384, 1000000):
+            res[(variant, blocks)] = []
     for _ in range(rounds):
-        for blocks in res:
+        for (variant, blocks) in res:
+            ctx.set_tuning("apply_variant", variant)
             ctx.set_tuning("apply_blocks", blocks)
-            res[blocks].append(time_ms(ctx, lambda: r3d.apply_T_device(ctx, d_in.ptr, np.float32, n, T, d_out.ptr,
+            res[(variant, blocks)].append(time_ms(ctx, lambda: r3d.apply_T_device(ctx, d_in.ptr, np.float32, n, T, d_out.ptr,
                                                                        np.float32), iters))
     ctx.set_tuning("apply_blocks", 0)
+    ctx.set_tuning("apply_variant", 0)
     print("apply_T %.1f Mpts, 24 B/pt" % (n / 1e6))
-    for blocks, v in res.items():
+    for (variant, blocks), v in res.items():
         med = np.median(v)
-        print("blocks %6d  med %.4f ms  %.1f GB/s" % (blocks, med, n * 24 / med / 1e6))
+        print("variant %d blocks %7d  med %.4f ms  %.1f GB/s" % (variant, blocks, med, n * 24 / med / 1e6))
 
 
 def bench_nn(ctx, n, m, rounds):
