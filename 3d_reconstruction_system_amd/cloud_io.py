@@ -66,14 +66,31 @@ def write_xyz_txt(path, xyz, z_raw=None, append=False):
     N values) printed as the third column instead, like the reference's camera txt, where Z is
     `str(np.uint8)`."""
     xyz = _cloud(xyz)
-    zp, zc = None, 0
-    if z_raw is not None:
-        z_raw = np.ascontiguousarray(z_raw).reshape(-1)
-        if z_raw.shape[0] != xyz.shape[0] or z_raw.dtype not in (np.uint8, np.uint16):
-            raise ValueError("z_raw must be uint8/uint16 with one value per point")
-        zp, zc = z_raw.ctypes.data, (L.DEPTH_U8 if z_raw.dtype == np.uint8 else L.DEPTH_U16)
+    keep, zp, zc = _z_raw_args(xyz, z_raw)
     L.check(L.load().r3d_write_xyz_txt(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0],
                                        zp, zc, 1 if append else 0))
+
+
+def _z_raw_args(xyz, z_raw):
+    if z_raw is None:
+        return None, None, 0
+    z_raw = np.ascontiguousarray(z_raw).reshape(-1)
+    if z_raw.shape[0] != xyz.shape[0] or z_raw.dtype not in (np.uint8, np.uint16):
+        raise ValueError("z_raw must be uint8/uint16 with one value per point")
+    return z_raw, z_raw.ctypes.data, (L.DEPTH_U8 if z_raw.dtype == np.uint8 else L.DEPTH_U16)
+
+
+def format_xyz_txt(xyz, z_raw=None):
+    """The `X,Y,Z\\n` text as bytes (same formatting as write_xyz_txt)."""
+    xyz = _cloud(xyz)
+    keep, zp, zc = _z_raw_args(xyz, z_raw)
+    lib = L.load()
+    n = C.c_size_t()
+    L.check(lib.r3d_format_xyz_txt(xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0], zp, zc, None, 0, C.byref(n)))
+    buf = C.create_string_buffer(max(n.value, 1))
+    L.check(lib.r3d_format_xyz_txt(xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0], zp, zc, buf, n.value,
+                                   C.byref(n)))
+    return buf.raw[:n.value]
 
 
 def format_ply(xyz):

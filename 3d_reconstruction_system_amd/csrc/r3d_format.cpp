@@ -311,6 +311,59 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
   return R3D_OK;
 }
 
+static void txt_chunks(const void* h_xyz, int dtype, int64_t s0, int64_t cnt, const void* h_z_raw, int z_raw_dtype,
+                       std::vector<std::string>* chunks) {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 32768));
+  chunks->assign((size_t)n_chunks, std::string());
+  std::vector<std::thread> pool;
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
+    auto work = [=]() {
+      if (dtype == R3D_F32)
+        txt_rows(static_cast<const float*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &(*chunks)[(size_t)c]);
+      else
+        txt_rows(static_cast<const double*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &(*chunks)[(size_t)c]);
+    };
+    if (n_chunks == 1)
+      work();
+    else
+      pool.emplace_back(work);
+  }
+  for (auto& t : pool) t.join();
+}
+
+int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
+                       char* h_buf, size_t buf_cap, size_t* n_bytes_out) {
+  if (n_points < 0 || (n_points > 0 && !h_xyz) || (dtype != R3D_F32 && dtype != R3D_F64) || !n_bytes_out ||
+      (h_z_raw && z_raw_dtype != R3D_DEPTH_U8 && z_raw_dtype != R3D_DEPTH_U16)) {
+    r3d_set_error("r3d_format_xyz_txt: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  std::vector<std::string> chunks;
+  try {
+    txt_chunks(h_xyz, dtype, 0, n_points, h_z_raw, z_raw_dtype, &chunks);
+  } catch (const std::bad_alloc&) {
+    r3d_set_error("r3d_format_xyz_txt: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
+  size_t total = 0;
+  for (const auto& c : chunks) total += c.size();
+  *n_bytes_out = total;
+  if (!h_buf) return R3D_OK;
+  if (buf_cap < total) {
+    r3d_set_error("r3d_format_xyz_txt: buffer of %zu bytes is too small for %zu", buf_cap, total);
+    return R3D_ERR_NOMEM;
+  }
+  char* p = h_buf;
+  for (const auto& c : chunks) {
+    memcpy(p, c.data(), c.size());
+    p += c.size();
+  }
+  return R3D_OK;
+}
+
 int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw,
                       int z_raw_dtype, int append) {
   if (!path || n_points < 0 || (n_points > 0 && !h_xyz) || (dtype != R3D_F32 && dtype != R3D_F64) ||
@@ -326,27 +379,9 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
   bool ok = true;
   try {
     const int64_t slab = (int64_t)4 << 20;
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 1;
+    std::vector<std::string> chunks;
     for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
-      const int64_t cnt = std::min(slab, n_points - s0);
-      const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 32768));
-      std::vector<std::string> chunks((size_t)n_chunks);
-      std::vector<std::thread> pool;
-      for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
-        auto work = [=, &chunks]() {
-          if (dtype == R3D_F32)
-            txt_rows(static_cast<const float*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &chunks[(size_t)c]);
-          else
-            txt_rows(static_cast<const double*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &chunks[(size_t)c]);
-        };
-        if (n_chunks == 1)
-          work();
-        else
-          pool.emplace_back(work);
-      }
-      for (auto& t : pool) t.join();
+      txt_chunks(h_xyz, dtype, s0, std::min(slab, n_points - s0), h_z_raw, z_raw_dtype, &chunks);
       for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
     }
   } catch (const std::bad_alloc&) {

@@ -33,12 +33,13 @@ def _as_batch(depths):
 def unproject(depth, intrinsics=REF_INTRINSICS, out_dtype=np.float32, depth_scale=1.0, ctx=None):
     """Camera-frame points of one raster [H,W] or a batch [F,H,W]: float [F*H*W,3], row-major,
     every pixel emitted (Z=0 pixels included, like the reference)."""
-    ctx = ctx or default_context()
     d = _as_batch(depth)
     f, h, w = d.shape
     out = np.empty((f * h * w, 3), dtype=out_dtype)
+    xyz_code(out.dtype)
     if f * h * w == 0:
         return out
+    ctx = ctx or default_context()
     cam = ctx.camera(h, w, *intrinsics)
     L.check(ctx.lib.r3d_unproject_host(ctx.handle, cam.handle, d.ctypes.data, depth_code(d.dtype), f,
                                        float(depth_scale), out.ctypes.data, xyz_code(out.dtype)))
@@ -48,15 +49,16 @@ def unproject(depth, intrinsics=REF_INTRINSICS, out_dtype=np.float32, depth_scal
 def fuse_frames(depths, quats_xyzw, ts, intrinsics=REF_INTRINSICS, out_dtype=np.float32, depth_scale=1.0,
                 ctx=None):
     """World-frame cloud of F frames, concatenated in frame order: p_w = Rinv_f (p_cam - t_f)."""
-    ctx = ctx or default_context()
     d = _as_batch(depths)
     f, h, w = d.shape
     table = pose_table(quats_xyzw, ts)
     if table.shape[0] != f:
         raise ValueError("%d frames but %d poses" % (f, table.shape[0]))
     out = np.empty((f * h * w, 3), dtype=out_dtype)
+    xyz_code(out.dtype)
     if f * h * w == 0:
         return out
+    ctx = ctx or default_context()
     cam = ctx.camera(h, w, *intrinsics)
     L.check(ctx.lib.r3d_fuse_frames_host(ctx.handle, cam.handle, d.ctypes.data, depth_code(d.dtype), f,
                                          float(depth_scale), table.ctypes.data, out.ctypes.data,
@@ -66,13 +68,14 @@ def fuse_frames(depths, quats_xyzw, ts, intrinsics=REF_INTRINSICS, out_dtype=np.
 
 def se3_apply(xyz, rinv, t, out_dtype=None, ctx=None):
     """Rinv . (p - t) for every point of an [N,3] cloud -- point_camera() (c2w:57-59) in bulk."""
-    ctx = ctx or default_context()
     xyz = np.ascontiguousarray(xyz)
     if xyz.ndim != 2 or xyz.shape[1] != 3:
         raise ValueError("cloud must be [N,3]")
     out = np.empty(xyz.shape, dtype=out_dtype or xyz.dtype)
+    xyz_code(xyz.dtype), xyz_code(out.dtype)
     if xyz.shape[0] == 0:
         return out
+    ctx = ctx or default_context()
     pose = np.concatenate([np.asarray(rinv, dtype=np.float64).reshape(9), np.asarray(t, dtype=np.float64).reshape(3)])
     L.check(ctx.lib.r3d_se3_apply_host(ctx.handle, xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0],
                                        pose.ctypes.data, out.ctypes.data, xyz_code(out.dtype)))
@@ -81,13 +84,14 @@ def se3_apply(xyz, rinv, t, out_dtype=None, ctx=None):
 
 def apply_T(xyz, T, out_dtype=None, ctx=None):
     """(T . [x,y,z,1])[0:3] for every point of an [N,3] float32/float64 cloud."""
-    ctx = ctx or default_context()
     xyz = np.ascontiguousarray(xyz)
     if xyz.ndim != 2 or xyz.shape[1] != 3:
         raise ValueError("cloud must be [N,3]")
     out = np.empty(xyz.shape, dtype=out_dtype or xyz.dtype)
+    xyz_code(xyz.dtype), xyz_code(out.dtype)
     if xyz.shape[0] == 0:
         return out
+    ctx = ctx or default_context()
     T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4))
     L.check(ctx.lib.r3d_apply_T_host(ctx.handle, xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0],
                                      T.ctypes.data, out.ctypes.data, xyz_code(out.dtype)))

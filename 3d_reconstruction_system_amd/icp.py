@@ -1,0 +1,129 @@
+"""ICP similarity estimation on the MI355X: produces the T_data.txt that the reference's
+other_tools/transfer_T_icp.py consumes (get_T, icp:33-43) but never computes itself -- the
+reference obtained it from an external tool (readme: CloudCompare).  Build-defined:
+
+  repeat: nearest neighbour of every source point in the target cloud  (HIP, r3d_icp_nn)
+          18 fp64 sums over the matched pairs                          (HIP, r3d_icp_accumulate)
+          closed-form similarity (s, R, t) from the sums               (host, 3x3 SVD; Umeyama 1991)
+          move the source cloud by it                                  (HIP, r3d_apply_T, in place)
+
+Both clouds stay resident in HBM for the whole loop; per iteration only 144 bytes come back.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .device import default_context
+
+
+def umeyama_from_sums(sums, with_scale=True):
+    """4x4 T = [sR t; 0 1] minimising sum |q - (s R p + t)|^2 from the 18 sums of
+    r3d_icp_accumulate: n, sum p (3), sum q (3), sum p_a q_b (9, a major), sum |p|^2, sum |q|^2."""
+    sums = np.asarray(sums, dtype=np.float64)
+    n = sums[0]
+    if not n >= 3:
+        raise ValueError("need at least 3 matched pairs (got %g)" % n)
+    mu_p, mu_q = sums[1:4] / n, sums[4:7] / n
+    cov_pq = sums[7:16].reshape(3, 3) / n - np.outer(mu_p, mu_q)   # E[(p-mu_p)(q-mu_q)^T]
+    var_p = sums[16] / n - mu_p @ mu_p
+    U, D, Vt = np.linalg.svd(cov_pq.T)                             # Sigma_qp = U D V^T
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1.0
+    R = U @ S @ Vt
+    s = float(np.trace(np.diag(D) @ S) / var_p) if with_scale else 1.0
+    T = np.eye(4)
+    T[:3, :3] = s * R
+    T[:3, 3] = mu_q - s * (R @ mu_p)
+    return T
+
+
+class IcpDevice:
+    """Source / target clouds resident on one GPU."""
+
+    def __init__(self, src, tgt, ctx=None):
+        self.ctx = ctx or default_context()
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        tgt = np.ascontiguousarray(tgt, dtype=np.float32)
+        if src.ndim != 2 or src.shape[1] != 3 or tgt.ndim != 2 or tgt.shape[1] != 3:
+            raise ValueError("clouds must be [N,3]")
+        if tgt.shape[0] < 1:
+            raise ValueError("target cloud is empty")
+        self.n, self.m = src.shape[0], tgt.shape[0]
+        c = self.ctx
+        self.d_src = c.alloc(max(src.nbytes, 16)).upload(src)
+        self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
+        self.d_idx = c.alloc(max(self.n * 4, 16))
+        self.d_d2 = c.alloc(max(self.n * 4, 16))
+
+    def nn(self):
+        c = self.ctx
+        L.check(c.lib.r3d_icp_nn(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
+                                 self.d_d2.ptr))
+
+    def sums(self, max_d2=-1.0):
+        c = self.ctx
+        out = np.zeros(18, dtype=np.float64)
+        L.check(c.lib.r3d_icp_accumulate(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
+                                         self.d_d2.ptr if max_d2 >= 0 else None, float(max_d2), out.ctypes.data))
+        return out
+
+    def move_source(self, T):
+        c = self.ctx
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        L.check(c.lib.r3d_apply_T(c.handle, self.d_src.ptr, L.F32, self.n, T.ctypes.data, self.d_src.ptr, L.F32))
+
+    def download(self):
+        idx = self.d_idx.download(np.uint32, self.n)
+        d2 = self.d_d2.download(np.float32, self.n)
+        return idx, d2
+
+    def source(self):
+        return self.d_src.download(np.float32, self.n * 3).reshape(-1, 3)
+
+    def free(self):
+        for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2):
+            b.free()
+
+
+def nearest_neighbours(src, tgt, ctx=None):
+    """(idx uint32 [N], d2 float32 [N]): brute-force squared-L2 nearest target of every source point."""
+    ctx = ctx or default_context()
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    tgt = np.ascontiguousarray(tgt, dtype=np.float32)
+    idx = np.empty(src.shape[0], dtype=np.uint32)
+    d2 = np.empty(src.shape[0], dtype=np.float32)
+    if src.shape[0] == 0:
+        return idx, d2
+    L.check(ctx.lib.r3d_icp_nn_host(ctx.handle, src.ctypes.data, src.shape[0], tgt.ctypes.data, tgt.shape[0],
+                                    idx.ctypes.data, d2.ctypes.data))
+    return idx, d2
+
+
+def icp_similarity(src, tgt, max_iter=30, tol=1e-7, with_scale=True, trim_d2=None, ctx=None):
+    """Iterate NN + Umeyama until the RMS match distance stops improving by more than `tol`
+    (relative).  Returns (T 4x4 mapping src -> tgt, info dict).  trim_d2: ignore pairs whose
+    squared distance exceeds it (None = use all)."""
+    dev = IcpDevice(src, tgt, ctx)
+    T_total = np.eye(4)
+    history = []
+    prev = None
+    try:
+        for it in range(max_iter):
+            dev.nn()
+            sums = dev.sums(-1.0 if trim_d2 is None else float(trim_d2))
+            n = sums[0]
+            # sum |p-q|^2 = sum|p|^2 + sum|q|^2 - 2 tr(sum p q^T)
+            rms = float(np.sqrt(max(sums[16] + sums[17] - 2.0 * (sums[7] + sums[11] + sums[15]), 0.0) / max(n, 1.0)))
+            history.append(rms)
+            T = umeyama_from_sums(sums, with_scale)
+            dev.move_source(T)
+            T_total = T @ T_total
+            if prev is not None and abs(prev - rms) <= tol * max(prev, 1e-30):
+                break
+            prev = rms
+        dev.ctx.sync()
+    finally:
+        dev.free()
+    return T_total, {"iterations": len(history), "rms_history": history}

@@ -1,0 +1,46 @@
+"""Shared plumbing of the drop-in scripts: locate the package whether the script is imported as
+part of it or run as `python camera_to_world.py` from a data directory, and read the optional
+environment overrides.
+
+Environment (all optional; the defaults are the reference's hard-coded values):
+  R3D_FX R3D_FY R3D_CX R3D_CY   pinhole intrinsics        (p2c:25-28, c2w:68-71)
+  R3D_DEVICE                    GPU index                 (default 0)
+  R3D_SKIP_INTERMEDIATE=1       do not write ./point/<stem>.txt and ./point_world/*.txt
+"""
+import importlib
+import os
+import sys
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ROOT = os.path.dirname(_PKG_DIR)
+
+
+def package():
+    name = os.path.basename(_PKG_DIR)
+    if name in sys.modules:
+        return sys.modules[name]
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    return importlib.import_module(name)
+
+
+def intrinsics():
+    r3d = package()
+    fx, fy, cx, cy = r3d.REF_INTRINSICS
+
+    def num(key, default):
+        v = os.environ.get(key)
+        if v is None:
+            return default
+        f = float(v)
+        return int(f) if f.is_integer() and isinstance(default, int) else f
+
+    return (num("R3D_FX", fx), num("R3D_FY", fy), num("R3D_CX", cx), num("R3D_CY", cy))
+
+
+def context():
+    return package().default_context(int(os.environ.get("R3D_DEVICE", "0")))
+
+
+def skip_intermediate():
+    return os.environ.get("R3D_SKIP_INTERMEDIATE", "0") not in ("", "0")

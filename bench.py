@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused depth -> world point-cloud throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "C2"): KITTI-sized 1280x384 uint8 depth, 100 frames per GPU,
+synthetic (seed 1234), device-resident; one STEP = one pass of the hot path over the batch =
+ONE fused unproject + SE(3) launch over all 100 frames (49,152,000 points -> f32 xyz), and for
+N > 1 additionally the RCCL all-gather that assembles the fused world cloud on every rank
+(north_star).  Weak scaling: every rank owns 100 frames.  `value` is whole-job Mpoints/s
+(all ranks' points / max-over-ranks time).
+
+Extra objects on the JSON line:
+  roofline     -- the fused kernel against the HBM roof: algorithmic bytes (13 B/point) per launch
+                  / average launch duration measured with HIP events on the launch stream.
+  cpu_baseline -- the loop-faithful CPU restatement of the reference path (oracle/, test
+                  infrastructure; rank 0, N=1 only) timed on a bounded sample, 1 core.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, FRAMES_PER_GPU = 384, 1280, 100
+BYTES_PER_POINT = 13          # 1 B u8 depth read + 12 B f32 xyz written
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(sample_frames=1):
+    """Loop-faithful restatement of camera_to_world.py:67-105 (per-point Python loops + text round
+    trip), 1 core, on `sample_frames` frames of the same workload.  Reported, not optimised against."""
+    from oracle import fusion_ref as O
+    rng = np.random.default_rng(1234)
+    depth = rng.integers(1, 256, size=(sample_frames, H, W), dtype=np.uint8)
+    q = rng.normal(size=(sample_frames, 4))
+    t = rng.normal(size=(sample_frames, 3)) * 10
+    with tempfile.TemporaryDirectory() as td:
+        t0 = time.perf_counter()
+        O.fuse_frames_loop(depth, q, t, td)
+        dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.fuse_frames(depth, q, t)
+    dt_vec = time.perf_counter() - t0
+    pts = sample_frames * H * W
+    return {"value": round(pts / dt / 1e6, 5), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": "%d frame(s) of 1280x384 u8 (%d points), per-point Python loops + txt round trip as "
+                      "camera_to_world.py:67-105, no PLY; %.1f s" % (sample_frames, pts, dt),
+            "vectorised_numpy_fp64_Mpoints_s": round(pts / dt_vec / 1e6, 3),
+            "host_cpus": os.cpu_count()}
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command, if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_fuse_latest.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (100 = config C2)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the all-gather out of the step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (a.gpus, a.gpus))
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    r3d = importlib.import_module("3d_reconstruction_system_amd")
+    D = importlib.import_module("3d_reconstruction_system_amd.dist")
+    stream = torch.cuda.current_stream(dev)
+    ctx = r3d.Context(local_rank, stream=stream.cuda_stream)
+    cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
+
+    # synthetic job: rank r owns frames [r*F, (r+1)*F) of a world*F-frame sequence
+    F = a.frames
+    rng = np.random.default_rng(1234 + rank)
+    depth = torch.from_numpy(rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)).to(dev)
+    table = torch.from_numpy(r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)).to(dev)
+    out_np = np.float32 if a.out_dtype == "float32" else np.float64
+    out_t = torch.float32 if a.out_dtype == "float32" else torch.float64
+    n_local = F * H * W
+    gather = world > 1 and not a.no_gather
+    if gather:
+        full = torch.empty((world * n_local, 3), dtype=out_t, device=dev)
+        shard = full[rank * n_local:(rank + 1) * n_local]       # fuse straight into this rank's slot
+    else:
+        full = None
+        shard = torch.empty((n_local, 3), dtype=out_t, device=dev)
+
+    def fuse():
+        r3d.fuse_frames_device(ctx, cam, depth.data_ptr(), np.uint8, F, table.data_ptr(), shard.data_ptr(), out_np)
+
+    def step():
+        fuse()
+        if gather:
+            dist.all_gather_into_tensor(full, shard)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(a.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # kernel-only duration of the dominant kernel: HIP events on the launch stream, K back-to-back launches
+    for _ in range(5):
+        fuse()
+    torch.cuda.synchronize(dev)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record(stream)
+    for _ in range(a.steps):
+        fuse()
+    k1.record(stream)
+    torch.cuda.synchronize(dev)
+    kernel_ms = k0.elapsed_time(k1) / a.steps
+    bytes_per_launch = n_local * (1 + 3 * (4 if a.out_dtype == "float32" else 8))
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_pts = world * n_local * a.steps
+        line = {
+            "metric": "Mpoints/s fused (1280x384 depth, N frames)",
+            "value": round(total_pts / elapsed / 1e6, 2),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2: 1280x384 u8 depth x %d frames per GPU -> %s xyz, fused unproject+SE(3), "
+                                   "inputs resident in HBM" % (F, a.out_dtype),
+                       "frames_per_gpu": F, "points_per_step": world * n_local,
+                       "step": "1 fused launch" + (" + RCCL all-gather of the world cloud" if gather else ""),
+                       "parallelism": "frames sharded, %d rank(s)" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                         "kernel": "fuse_lane_kernel<u8,%s,pose>" % ("f32" if a.out_dtype == "float32" else "f64"),
+                         "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "timing": "HIP events on the launch stream over %d back-to-back launches" % a.steps},
+            "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,9 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
  * z_raw_dtype is R3D_DEPTH_U8 or R3D_DEPTH_U16.  append: 0 truncates ('w'), 1 appends ('a'). */
 int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw,
                       int z_raw_dtype, int append);
+/* The same text into a caller buffer; two-call protocol like r3d_format_ply. */
+int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
+                       char* h_buf, size_t buf_cap, size_t* n_bytes_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,119 @@
+"""Oracle (test infrastructure): ICP estimation restated on the CPU.  PARITY UNPINNED.
+
+The reference repo has no ICP code to pin against (other_tools/transfer_T_icp.py:99-108 only
+reads a T_data.txt made by an external tool; requirements.txt:52-53 pins open3d but nothing
+imports it).  This file states the build's own definition:
+  * nearest neighbour under squared L2 evaluated in fp32 as fma(dz,dz, fma(dy,dy, dx*dx)),
+    lowest target index wins exact ties;
+  * the 18 pair sums in fp64;
+  * Umeyama (IEEE PAMI 13(4), 1991) closed-form similarity from point pairs.
+Anchors: synthetic clouds with a known (s, R, t) and exact correspondences; scipy's cKDTree as
+an independent NN cross-check (fp64 distances).
+"""
+import numpy as np
+
+
+def _fma32(a, b, c):
+    """round32(a*b + c) for float32 arrays: the product of two fp32 numbers is exact in fp64; the
+    fp64 sum is then rounded to fp32 (double rounding can differ from a true fma only when the
+    fp64 sum lands exactly on an fp32 tie, ~2^-29 of cases)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def pair_d2(src, tgt):
+    """[N,M] float32 squared distances with the kernel's exact expression."""
+    s = np.asarray(src, dtype=np.float32)[:, None, :]
+    t = np.asarray(tgt, dtype=np.float32)[None, :, :]
+    dx, dy, dz = s[..., 0] - t[..., 0], s[..., 1] - t[..., 1], s[..., 2] - t[..., 2]
+    return _fma32(dz, dz, _fma32(dy, dy, dx * dx))
+
+
+def nearest_neighbours(src, tgt, chunk=512):
+    """(idx uint32 [N], d2 float32 [N]); np.argmin returns the lowest index among ties."""
+    src = np.asarray(src, dtype=np.float32)
+    tgt = np.asarray(tgt, dtype=np.float32)
+    idx = np.empty(src.shape[0], dtype=np.uint32)
+    d2 = np.empty(src.shape[0], dtype=np.float32)
+    for lo in range(0, src.shape[0], chunk):
+        d = pair_d2(src[lo:lo + chunk], tgt)
+        k = np.argmin(d, axis=1)
+        idx[lo:lo + chunk] = k
+        d2[lo:lo + chunk] = d[np.arange(d.shape[0]), k]
+    return idx, d2
+
+
+def pair_sums(src, tgt, idx, d2=None, max_d2=-1.0):
+    """The 18 fp64 sums: n, sum p, sum q, sum p_a q_b (a major), sum |p|^2, sum |q|^2."""
+    p = np.asarray(src, dtype=np.float32).astype(np.float64)
+    q = np.asarray(tgt, dtype=np.float32).astype(np.float64)[np.asarray(idx, dtype=np.int64)]
+    if max_d2 >= 0:
+        keep = np.asarray(d2) <= np.float32(max_d2)
+        p, q = p[keep], q[keep]
+    out = np.zeros(18)
+    out[0] = p.shape[0]
+    out[1:4] = p.sum(0)
+    out[4:7] = q.sum(0)
+    out[7:16] = (p[:, :, None] * q[:, None, :]).sum(0).reshape(9)
+    out[16] = (p * p).sum()
+    out[17] = (q * q).sum()
+    return out
+
+
+def umeyama(p, q, with_scale=True):
+    """T = [sR t; 0 1] minimising sum |q_i - (s R p_i + t)|^2, straight from the point pairs."""
+    p = np.asarray(p, dtype=np.float64)
+    q = np.asarray(q, dtype=np.float64)
+    mp, mq = p.mean(0), q.mean(0)
+    pc, qc = p - mp, q - mq
+    sigma = qc.T @ pc / p.shape[0]
+    U, D, Vt = np.linalg.svd(sigma)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    s = np.trace(np.diag(D) @ S) / (pc ** 2).sum(1).mean() if with_scale else 1.0
+    T = np.eye(4)
+    T[:3, :3] = s * R
+    T[:3, 3] = mq - s * R @ mp
+    return T
+
+
+def icp_similarity(src, tgt, max_iter=30, tol=1e-7, with_scale=True):
+    src = np.asarray(src, dtype=np.float32).copy()
+    tgt = np.asarray(tgt, dtype=np.float32)
+    T_total = np.eye(4)
+    prev = None
+    for _ in range(max_iter):
+        idx, _d2 = nearest_neighbours(src, tgt)
+        q = tgt[idx.astype(np.int64)].astype(np.float64)
+        p = src.astype(np.float64)
+        rms = float(np.sqrt(((p - q) ** 2).sum(1).mean()))
+        T = umeyama(p, q, with_scale)
+        src = (p @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        T_total = T @ T_total
+        if prev is not None and abs(prev - rms) <= tol * max(prev, 1e-30):
+            break
+        prev = rms
+    return T_total
+
+
+def synthetic_pair(n_tgt=4000, n_src=3000, seed=7, s=1.7, angle_deg=10.0, t_norm=0.5, noise=0.0, extent=20.0):
+    """SURVEY 8(d) C3 recipe at a chosen size: tgt uniform in a cube (+ optional noise);
+    src = the inverse similarity applied to a subset of tgt, so the transform that maps src back
+    onto tgt is exactly (s, R, t)."""
+    rng = np.random.default_rng(seed)
+    tgt = rng.random((n_tgt, 3)) * extent
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    a = np.deg2rad(angle_deg)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    t = rng.normal(size=3)
+    t *= t_norm / np.linalg.norm(t)
+    T = np.eye(4)
+    T[:3, :3] = s * R
+    T[:3, 3] = t
+    pick = rng.permutation(n_tgt)[:n_src]
+    q = tgt[pick] + rng.normal(size=(n_src, 3)) * noise
+    src = (q - t) @ np.linalg.inv(s * R).T
+    return src.astype(np.float32), tgt.astype(np.float32), T, pick

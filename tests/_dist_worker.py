@@ -1,0 +1,68 @@
+"""Worker for tests/test_dist_gloo.py: rank-local fusion + all-gather over gloo on CPU tensors.
+The compute hook injected here is the ORACLE (test infrastructure) -- the product's own hook needs
+an MI355X; what this exercises is the sharding, padding and gather logic of dist.py."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import fusion_ref as O  # noqa: E402
+
+D = importlib.import_module("3d_reconstruction_system_amd.dist")
+P = importlib.import_module("3d_reconstruction_system_amd.poses")
+
+
+def oracle_fuse(depth, pose, out):
+    d = depth.numpy()
+    tab = pose.numpy()
+    res = np.empty((d.shape[0], d.shape[1] * d.shape[2], 3))
+    for k in range(d.shape[0]):
+        res[k] = O.se3_apply(O.unproject(d[k]), tab[k, :9].reshape(3, 3), tab[k, 9:])
+    out.copy_(torch.from_numpy(res.reshape(-1, 3)).to(out.dtype))
+
+
+def main():
+    out_path, n_frames = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    H, W = 12, 16
+    rng = np.random.default_rng(99)          # every rank draws the same full job, then keeps its shard
+    depths = rng.integers(0, 256, size=(n_frames, H, W), dtype=np.uint8)
+    quats = rng.normal(size=(n_frames, 4))
+    ts = rng.normal(size=(n_frames, 3)) * 10
+    lo, hi = D.shard_range(n_frames, rank, world)
+    counts = D.shard_counts(n_frames, world)
+    eng = D.ShardedFusion(H, W, O.REF_FX and (O.REF_FX, O.REF_FY, O.REF_CX, O.REF_CY), out_dtype="float64",
+                          fuse_fn=oracle_fuse)
+    table = P.pose_table(quats[lo:hi], ts[lo:hi]) if hi > lo else np.zeros((0, 12))
+    full = eng.fuse_and_gather(torch.from_numpy(depths[lo:hi].copy()), torch.from_numpy(table), counts)
+    # single-process answer from the SAME pose table (bit-exact check of the shard/gather logic) ...
+    tab_all = P.pose_table(quats, ts)
+    want = np.concatenate([O.se3_apply(O.unproject(depths[k]), tab_all[k, :9].reshape(3, 3), tab_all[k, 9:])
+                           for k in range(n_frames)]) if n_frames else np.zeros((0, 3))
+    ok = full.shape == (n_frames * H * W, 3) and np.array_equal(full.numpy(), want)
+    # ... and the oracle's own quaternion path to fp64 round-off
+    ok = ok and np.allclose(full.numpy(), O.fuse_frames(depths, quats, ts), rtol=0, atol=1e-11)
+    # the product's own compute hook must refuse CPU tensors rather than fall back
+    eng2 = D.ShardedFusion(H, W, (O.REF_FX, O.REF_FY, O.REF_CX, O.REF_CY))
+    refused = False
+    if hi > lo:
+        try:
+            eng2.fuse_local(torch.from_numpy(depths[lo:hi].copy()), torch.from_numpy(table))
+        except RuntimeError as e:
+            refused = "no CPU" in str(e) or "MI355X" in str(e)
+    else:
+        refused = True
+    with open("%s.rank%d" % (out_path, rank), "w") as f:
+        f.write("ok=%d refused=%d lo=%d hi=%d\n" % (ok, refused, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""GPU: the drop-in scripts, run exactly as the reference's are (python <script>.py from a working
+directory with ./depth ./camera_pose ./point ./point_world ./ply), against the files the unmodified
+reference wrote for the same inputs (tests/golden/)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import PKG, ROOT, r3d as _r3d
+from oracle import fusion_ref as O
+
+pytestmark = pytest.mark.gpu
+
+SCRIPTS = os.path.join(ROOT, PKG)
+
+
+def run_script(rel, cwd, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(SCRIPTS, rel)] + list(args), cwd=cwd, env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_camera_to_world_script_reproduces_reference_files(tmp_path, golden_dir):
+    scene = os.path.join(golden_dir, "scene3")
+    for d in ("depth", "camera_pose"):
+        shutil.copytree(os.path.join(scene, d), tmp_path / d)
+    for d in ("point", "point_world", "ply"):
+        os.makedirs(tmp_path / d)
+    out = run_script("transfer/camera_to_world.py", str(tmp_path))
+    assert "Write into .ply file Done." in out
+    # camera txt per frame: byte identical (fp64 product u*Z is the reference's own operation)
+    for name in ("000", "007", "frame_b"):
+        assert (tmp_path / "point" / (name + ".txt")).read_bytes() == \
+            open(os.path.join(scene, "point", name + ".txt"), "rb").read()
+    # fused PLY: byte identical at 4 decimals
+    assert (tmp_path / "ply" / "small_035_p8.ply").read_bytes() == \
+        open(os.path.join(scene, "ply", "small_035_p8.ply"), "rb").read()
+    # world txt (last frame only, like the reference): fp64 values equal up to summation order
+    got = O.read_xyz_txt(str(tmp_path / "point_world" / "small_worldpoint_5_23_5.txt"))
+    want = O.read_xyz_txt(os.path.join(scene, "point_world", "small_worldpoint_5_23_5.txt"))
+    assert got.shape == want.shape == (768, 3)
+    assert (np.abs(got - want) / (1 + np.linalg.norm(want, axis=1, keepdims=True))).max() <= 1e-12
+
+
+def test_camera_to_world_functions_keep_reference_semantics(tmp_path, golden_dir, monkeypatch):
+    import importlib
+    c2w = importlib.import_module(PKG + ".transfer.camera_to_world")
+    scene = os.path.join(golden_dir, "scene3")
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("point_world")
+    names, quats, ts = O.parse_pose_file(os.path.join(scene, "camera_pose", "image_colmap_simi_2.txt"))
+    xs, ys, zs = [], [], []
+    for k, n in enumerate(names):      # get_pointdata mutates the caller's lists and rewrites the world txt
+        c2w.get_pointdata(os.path.join(scene, "point", n[:-4] + ".txt"), quats[k], ts[k], xs, ys, zs)
+    assert len(xs) == len(ys) == len(zs) == 2304 and isinstance(xs[0], float)
+    want = O.read_ply_vertices(os.path.join(scene, "ply", "small_035_p8.ply"))
+    assert np.abs(np.stack([xs, ys, zs], 1) - want).max() <= 0.5001e-4
+    c2w.genply([xs, ys, zs], "out.ply", len(xs))
+    assert open("out.ply", "rb").read() == open(os.path.join(scene, "ply", "small_035_p8.ply"), "rb").read()
+    assert c2w.gentxtcord("cam.txt", np.zeros((2, 4), np.uint8)) is None
+    p = c2w.point_camera(np.array([1.0, 0.0, 2.0]), c2w.scipy_transfer([0.1, 0.2, 0.3, 0.9]), np.array([1.0, 2, 3]))
+    np.testing.assert_allclose(p.ravel(), [-0.9052631578947368, -1.8947368421052633, -0.768421052631579], atol=1e-15)
+
+
+def test_pixel_to_camera_script_config_c1(tmp_path, golden_dir):
+    """BASELINE config 1: a single 640x192 depth PNG -> camera-frame txt + PLY (the reference script
+    itself raises IndexError on this size and TypeError before writing any PLY)."""
+    from PIL import Image
+    for d in ("depth", "point", "ply"):
+        os.makedirs(tmp_path / d)
+    depth = np.random.default_rng(0).integers(1, 256, (192, 640), dtype=np.uint8)
+    Image.fromarray(np.stack([depth // 2, depth, depth // 3], 2).astype(np.uint8), "RGB").save(tmp_path / "depth" / "24.png")
+    run_script("transfer/pixel_to_camera.py", str(tmp_path))
+    import hashlib, json
+    g = json.load(open(os.path.join(golden_dir, "c1_192x640.json")))
+    assert hashlib.sha256((tmp_path / "point" / "24.txt").read_bytes()).hexdigest() == g["sha256_cam_txt"]
+    cam = O.unproject(depth)
+    assert (tmp_path / "ply" / "24.ply").read_bytes() == O.format_ply(cam).encode()
+
+
+def test_pixel_to_camera_functions(tmp_path, golden_dir):
+    import importlib, json
+    p2c = importlib.import_module(PKG + ".transfer.pixel_to_camera")
+    g = json.load(open(os.path.join(golden_dir, "p2c_480x640.json")))
+    depth = np.random.default_rng(g["seed"]).integers(1, 256, tuple(g["shape"]), dtype=np.uint8)
+    xs, ys, zs = p2c.gentxtcord(str(tmp_path / "p.txt"), depth)
+    import hashlib
+    assert hashlib.sha256((tmp_path / "p.txt").read_bytes()).hexdigest() == g["sha256_txt"]
+    for k, (x, y, z) in g["ret_samples"].items():
+        assert (xs[int(k)], ys[int(k)], zs[int(k)]) == (x, y, z)
+    assert isinstance(zs[0], int)
+    p2c.genply_RGB([xs[:7], ys[:7], zs[:7]], str(tmp_path / "f.ply"))
+    assert (tmp_path / "f.ply").read_bytes() == open(os.path.join(golden_dir, "p2c_first7.ply"), "rb").read()
+    from PIL import Image
+    rgb = np.random.default_rng(1).integers(0, 256, (2, 3, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    p2c.genply_noRGB([xs[:6], ys[:6], zs[:6]], str(tmp_path / "c.png"), str(tmp_path / "c.ply"))
+    lines = (tmp_path / "c.ply").read_text().split("\n")
+    assert lines[2].strip() == "element vertex 6" and lines[9].strip() == "property uchar alpha"
+    assert lines[11].split() == ["%.4f" % xs[0], "%.4f" % ys[0], "%.4f" % zs[0]] + [str(v) for v in rgb[0, 0]] + ["0"]
+
+
+def test_transfer_T_icp_script_reproduces_reference_files(tmp_path, golden_dir):
+    d = os.path.join(golden_dir, "icp_apply")
+    shutil.copytree(os.path.join(d, "point"), tmp_path / "point")
+    shutil.copy(os.path.join(d, "T_data.txt"), tmp_path / "T_data.txt")
+    os.makedirs(tmp_path / "point_world")
+    os.makedirs(tmp_path / "ply" / "icp")
+    run_script("other_tools/transfer_T_icp.py", str(tmp_path))
+    assert (tmp_path / "ply" / "icp" / "024.ply").read_bytes() == open(os.path.join(d, "ply", "icp", "024.ply"), "rb").read()
+    got = O.read_xyz_txt(str(tmp_path / "point_world" / "03_testT.txt"))
+    want = O.read_xyz_txt(os.path.join(d, "point_world", "03_testT.txt"))
+    assert got.shape == want.shape == (100, 3)
+    np.testing.assert_array_equal(got[:50], want[:50])            # pass-through cloud: exact
+    assert np.abs(got[50:] - want[50:]).max() <= 1e-12 * 500
+
+
+def test_transfer_T_icp_estimate_recovers_transform(tmp_path):
+    from oracle import icp_ref as OI
+    R = _r3d()
+    src, tgt, T_true, _ = OI.synthetic_pair(n_tgt=3000, n_src=2500, s=1.3, angle_deg=6.0, t_norm=0.3, seed=4)
+    for dd in ("point", "point_world", os.path.join("ply", "icp")):
+        os.makedirs(tmp_path / dd)
+    R.cloud_io.write_xyz_txt(str(tmp_path / "point" / "0.txt"), tgt.astype(np.float64))
+    R.cloud_io.write_xyz_txt(str(tmp_path / "point" / "24.txt"), src.astype(np.float64))
+    out = run_script("other_tools/transfer_T_icp.py", str(tmp_path), "--estimate")
+    assert "ICP:" in out
+    T = R.get_T(str(tmp_path / "T_data.txt"))
+    np.testing.assert_allclose(T, T_true, rtol=0, atol=5e-4)
+    merged = R.cloud_io.read_ply(str(tmp_path / "ply" / "icp" / "024.ply"))
+    assert merged.shape == (5500, 3)

@@ -1,0 +1,147 @@
+"""CPU: host-side logic of the package (pose maths, file parsers, native text writers) against
+the oracle and the golden fixtures.  Nothing here needs a GPU."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import PKG
+from oracle import fusion_ref as O
+
+
+@pytest.fixture(scope="module")
+def R():
+    return importlib.import_module(PKG)
+
+
+def test_scipy_transfer_and_get_r_match_golden(R, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "poses.json")))
+    for q, want in zip(g["quats_xyzw"], g["scipy_transfer"]):
+        got = R.scipy_transfer(q)
+        assert isinstance(got, np.matrix)
+        np.testing.assert_array_equal(np.asarray(got), np.array(want))      # same scipy + same inverse: bit equal
+        np.testing.assert_allclose(np.asarray(got), O.quat_to_rinv(q), atol=2e-15)
+    for q, want in zip(g["get_r_wxyz_input"], g["get_r"]):
+        np.testing.assert_allclose(np.asarray(R.get_r(q)), np.array(want), atol=2e-15)
+    with pytest.raises(ValueError):
+        R.scipy_transfer([0, 0, 0, 0])
+
+
+def test_pose_table_layout(R):
+    q = [[0.1, 0.2, 0.3, 0.9], [0, 0, 0, 1]]
+    t = [[1, 2, 3], [4, 5, 6]]
+    tab = R.pose_table(q, t)
+    assert tab.shape == (2, 12) and tab.dtype == np.float64
+    np.testing.assert_array_equal(tab[0, :9].reshape(3, 3), np.asarray(R.scipy_transfer(q[0])))
+    np.testing.assert_array_equal(tab[:, 9:], np.array(t, dtype=np.float64))
+    np.testing.assert_array_equal(tab[1, :9].reshape(3, 3), np.eye(3))
+    with pytest.raises(ValueError):
+        R.pose_table(q, t[:1])
+    T = R.pose_to_T(tab[0, :9].reshape(3, 3), tab[0, 9:])
+    p = np.array([1.0, 0.0, 2.0])
+    np.testing.assert_allclose(T[:3, :3] @ p + T[:3, 3], O.se3_apply(p[None], tab[0, :9].reshape(3, 3), t[0])[0],
+                               atol=1e-14)
+
+
+def test_read_pose_file_matches_oracle_and_rejects_trailing_name(R, golden_dir, tmp_path):
+    path = os.path.join(golden_dir, "scene3", "camera_pose", "image_colmap_simi_2.txt")
+    names, quats, ts = R.read_pose_file(path)
+    on, oq, ot = O.parse_pose_file(path)
+    assert names == on
+    np.testing.assert_array_equal(quats, oq)
+    np.testing.assert_array_equal(ts, ot)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("h\n1,0,0,0,0,0,0,1,a.png\n")
+    with pytest.raises(ValueError):
+        R.read_pose_file(str(bad))
+    short = tmp_path / "short.txt"
+    short.write_text("h\n1,0,0\n")
+    with pytest.raises(ValueError):
+        R.read_pose_file(str(short))
+    empty = tmp_path / "empty.txt"
+    empty.write_text("header only\n")
+    n, q, t = R.read_pose_file(str(empty))
+    assert n == [] and q.shape == (0, 4) and t.shape == (0, 3)
+
+
+def test_get_T_and_write_T_round_trip(R, golden_dir, tmp_path):
+    d = os.path.join(golden_dir, "icp_apply")
+    T = R.get_T(os.path.join(d, "T_data.txt"))
+    np.testing.assert_array_equal(T, np.array(json.load(open(os.path.join(d, "T_parsed.json")))))
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(4, 4)) * 10.0 ** rng.integers(-6, 6, size=(4, 4))
+    R.write_T(str(tmp_path / "T.txt"), M)
+    np.testing.assert_array_equal(R.get_T(str(tmp_path / "T.txt")), M)
+
+
+def test_native_writers_match_reference_bytes(R, golden_dir, tmp_path):
+    scene = os.path.join(golden_dir, "scene3")
+    names, quats, ts = O.parse_pose_file(os.path.join(scene, "camera_pose", "image_colmap_simi_2.txt"))
+    from PIL import Image
+    depths = np.stack([np.array(Image.open(os.path.join(scene, "depth", n)).convert("L")) for n in names])
+    # camera txt: X,Y from the oracle's fp64 (bit-equal to the reference), Z printed as the raw integer
+    for k, n in enumerate(names):
+        cam = O.unproject(depths[k])
+        want = open(os.path.join(scene, "point", n[:-4] + ".txt"), "rb").read()
+        assert R.cloud_io.format_xyz_txt(cam, z_raw=depths[k]) == want
+        R.cloud_io.write_xyz_txt(str(tmp_path / "c.txt"), cam, z_raw=depths[k])
+        assert (tmp_path / "c.txt").read_bytes() == want
+    # world txt + PLY from the values the reference itself wrote (repr round-trips fp64)
+    world = R.cloud_io.read_xyz_txt(os.path.join(scene, "point_world", "small_worldpoint_5_23_5.txt"))
+    assert R.cloud_io.format_xyz_txt(world) == open(os.path.join(scene, "point_world",
+                                                                 "small_worldpoint_5_23_5.txt"), "rb").read()
+    np.testing.assert_array_equal(world, O.read_xyz_txt(os.path.join(scene, "point_world",
+                                                                     "small_worldpoint_5_23_5.txt")))
+    fused = O.fuse_frames(depths, quats, ts)
+    assert R.cloud_io.format_ply(fused) == O.format_ply(fused).encode()
+    R.cloud_io.write_ply(str(tmp_path / "p.ply"), fused)
+    assert (tmp_path / "p.ply").read_bytes() == O.format_ply(fused).encode()
+    np.testing.assert_array_equal(R.cloud_io.read_ply(os.path.join(scene, "ply", "small_035_p8.ply")),
+                                  O.read_ply_vertices(os.path.join(scene, "ply", "small_035_p8.ply")))
+    # append mode and the empty cloud
+    R.cloud_io.write_xyz_txt(str(tmp_path / "a.txt"), world[:3])
+    R.cloud_io.write_xyz_txt(str(tmp_path / "a.txt"), world[3:5], append=True)
+    assert (tmp_path / "a.txt").read_bytes() == R.cloud_io.format_xyz_txt(world[:5])
+    assert R.cloud_io.format_ply(np.zeros((0, 3))) == O.format_ply(np.zeros((0, 3))).encode()
+    assert R.cloud_io.format_xyz_txt(np.zeros((0, 3), np.float32)) == b""
+
+
+def test_native_formatters_fuzz_against_python(R):
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(20001, 3)) * 10.0 ** rng.integers(-9, 13, size=(20001, 3))
+    x[0] = [0.0, -0.0, 0.00005]
+    x[1] = [0.00015, 0.00025, -0.00005]
+    x[2] = [1e15, 1e16, 123456789012345678.0]
+    x[3] = [1e-4, 1e-5, 9.999999e-5]
+    x[4] = [2.0 ** 40, 2.0 ** 41 + 0.5, 1e300]
+    x[5] = [np.inf, -np.inf, 0.12345]
+    for dt in (np.float64, np.float32):
+        with np.errstate(over="ignore"):
+            a = x.astype(dt)
+        assert R.cloud_io.format_ply(a) == O.format_ply(a.astype(np.float64)).encode()
+        want = "".join("%r,%r,%r\n" % (float(p[0]), float(p[1]), float(p[2])) for p in a).encode()
+        assert R.cloud_io.format_xyz_txt(a) == want
+
+
+def test_depth_readers(R, golden_dir, tmp_path):
+    from PIL import Image
+    p = os.path.join(golden_dir, "scene3", "depth", "000.png")
+    np.testing.assert_array_equal(R.cloud_io.read_depth_gray(p), np.array(Image.open(p)))
+    rgb = np.random.default_rng(0).integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    bgr = R.cloud_io.read_depth_unchanged(str(tmp_path / "c.png"))
+    np.testing.assert_array_equal(bgr[:, :, 1], rgb[:, :, 1])
+    np.testing.assert_array_equal(bgr[:, :, 0], rgb[:, :, 2])
+    with pytest.raises(FileNotFoundError):
+        R.cloud_io.read_depth_gray(str(tmp_path / "missing.png"))
+
+
+def test_type_checks_happen_before_any_device_work(R):
+    with pytest.raises(TypeError):
+        R.unproject(np.zeros((4, 4), np.int64))
+    with pytest.raises(ValueError):
+        R.unproject(np.zeros((4,), np.uint8))
+    with pytest.raises(ValueError):
+        R.cloud_io.write_xyz_txt("/tmp/x.txt", np.zeros((3, 2)))
