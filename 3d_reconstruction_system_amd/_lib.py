@@ -13,6 +13,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 DEPTH_U8, DEPTH_U16, DEPTH_F32 = 0, 1, 2
 F32, F64 = 0, 1
+CTX_EXTERNAL_STREAM = 1
 
 _ERR_NAMES = {ERR_INVALID: "R3D_ERR_INVALID", ERR_HIP: "R3D_ERR_HIP", ERR_NOMEM: "R3D_ERR_NOMEM",
               ERR_NODEVICE: "R3D_ERR_NODEVICE", ERR_UNSUPPORTED: "R3D_ERR_UNSUPPORTED"}
@@ -37,7 +38,7 @@ SIGNATURES = {
     "r3d_version": (_i, []),
     "r3d_last_error": (C.c_char_p, []),
     "r3d_device_count": (_i, [_pi]),
-    "r3d_ctx_create": (_i, [_i, _vp, _pvp]),
+    "r3d_ctx_create": (_i, [_i, _vp, _i, _pvp]),
     "r3d_ctx_destroy": (_i, [_vp]),
     "r3d_ctx_sync": (_i, [_vp]),
     "r3d_ctx_stream": (_i, [_vp, _pvp]),

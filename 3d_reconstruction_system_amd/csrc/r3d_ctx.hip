@@ -61,9 +61,10 @@ int r3d_device_count(int* n_out) {
   return R3D_OK;
 }
 
-int r3d_ctx_create(int device, void* stream, r3d_ctx** ctx_out) {
+int r3d_ctx_create(int device, void* stream, int flags, r3d_ctx** ctx_out) {
   R3D_REQUIRE(ctx_out != nullptr, "ctx_out is NULL");
   *ctx_out = nullptr;
+  R3D_REQUIRE((flags & ~R3D_CTX_EXTERNAL_STREAM) == 0, "unknown ctx flags 0x%x", flags);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -88,8 +89,8 @@ int r3d_ctx_create(int device, void* stream, r3d_ctx** ctx_out) {
   }
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
-  if (stream) {
-    c->stream = (hipStream_t)stream;
+  if (flags & R3D_CTX_EXTERNAL_STREAM) {
+    c->stream = (hipStream_t)stream;  // NULL = the device's default stream
     c->owns_stream = false;
   } else {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -67,13 +67,16 @@ class DeviceBuffer:
 
 
 class Context:
-    """r3d_ctx wrapper.  stream: raw hipStream_t (int) to share, e.g.
-    torch.cuda.current_stream().cuda_stream, or None for a private stream."""
+    """r3d_ctx wrapper.  stream=None: the ctx owns a private non-blocking stream.  stream=<int>: launch on
+    that raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream (0 = the device's default stream)."""
 
     def __init__(self, device=0, stream=None):
         self.lib = L.load()
         h = C.c_void_p()
-        L.check(self.lib.r3d_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        if stream is None:
+            L.check(self.lib.r3d_ctx_create(int(device), None, 0, C.byref(h)))
+        else:
+            L.check(self.lib.r3d_ctx_create(int(device), C.c_void_p(int(stream)), L.CTX_EXTERNAL_STREAM, C.byref(h)))
         self.handle = h.value
         self.device = int(device)
         self._cameras = {}

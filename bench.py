@@ -191,7 +191,7 @@ def main():
             "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(1)
+            line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -58,9 +58,11 @@ typedef struct r3d_camera r3d_camera; /* pinhole intrinsics + per-column/per-row
 int r3d_version(void);
 const char* r3d_last_error(void);
 int r3d_device_count(int* n_out);
-/* stream: an existing hipStream_t to launch on (e.g. torch's current stream), or NULL to
- * let the ctx create and own a non-blocking stream. */
-int r3d_ctx_create(int device, void* stream, r3d_ctx** ctx_out);
+/* flags = 0: the ctx creates and owns a non-blocking stream (`stream` is ignored).
+ * flags & R3D_CTX_EXTERNAL_STREAM: launch on the caller's hipStream_t `stream` (e.g. torch's current
+ * stream); NULL then means the device's default stream.  The ctx never destroys an external stream. */
+#define R3D_CTX_EXTERNAL_STREAM 1
+int r3d_ctx_create(int device, void* stream, int flags, r3d_ctx** ctx_out);
 int r3d_ctx_destroy(r3d_ctx* ctx);
 int r3d_ctx_sync(r3d_ctx* ctx);
 int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);

