@@ -71,8 +71,8 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (100 = config C2)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the all-gather out of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
