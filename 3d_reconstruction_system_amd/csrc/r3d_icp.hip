@@ -30,10 +30,15 @@ constexpr int kThreads = 256;
 constexpr int kTgtTile = 1024;  // targets per LDS tile
 constexpr int kGroup = 32;      // targets per min-tracking group
 
+// grid = (source blocks, target segments).  Segment y sweeps target tiles [y*tiles_per_seg, (y+1)*tiles_per_seg)
+// and writes its winners to idx_out/d2_out + y*n_src; with more than one segment nn_merge_kernel picks
+// the overall winner (earliest segment on ties = lowest index).  Splitting the targets is what fills
+// 256 CUs when the source cloud alone gives too few workgroups.
 template <int S>
 __global__ __launch_bounds__(kThreads) void nn_kernel(const float* __restrict__ src, int64_t n_src,
                                                       const float* __restrict__ tgt, int64_t n_tgt,
-                                                      uint32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+                                                      int64_t tiles_per_seg, uint32_t* __restrict__ idx_out,
+                                                      float* __restrict__ d2_out) {
   __shared__ __attribute__((aligned(16))) float tx[kTgtTile];
   __shared__ __attribute__((aligned(16))) float ty[kTgtTile];
   __shared__ __attribute__((aligned(16))) float tz[kTgtTile];
@@ -54,7 +59,11 @@ __global__ __launch_bounds__(kThreads) void nn_kernel(const float* __restrict__ 
   }
 
   const int64_t n_tiles = (n_tgt + kTgtTile - 1) / kTgtTile;
-  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+  const int64_t tile_lo = (int64_t)blockIdx.y * tiles_per_seg;
+  const int64_t tile_hi = min(n_tiles, tile_lo + tiles_per_seg);
+  idx_out += (int64_t)blockIdx.y * n_src;
+  if (d2_out) d2_out += (int64_t)blockIdx.y * n_src;
+  for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
     const int64_t t_base = tile * kTgtTile;
     const int64_t n_here = min((int64_t)kTgtTile, n_tgt - t_base);
     __syncthreads();  // previous tile fully consumed
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void nn_kernel(const float* __restrict__ 
   for (int s = 0; s < S; ++s) {
     const int64_t i = s_base + (int64_t)s * kThreads + tid;
     if (i >= n_src) continue;
-    const int64_t t0 = (int64_t)best_group[s] * kGroup;
+    const int64_t t0 = best[s] < INFINITY ? (int64_t)best_group[s] * kGroup : tile_lo * kTgtTile;
     uint32_t found = (uint32_t)t0;
     bool have = false;
     for (int k = 0; k < kGroup; ++k) {
@@ -124,6 +133,25 @@ __global__ __launch_bounds__(kThreads) void nn_kernel(const float* __restrict__ 
     idx_out[i] = found;
     if (d2_out) d2_out[i] = best[s];
   }
+}
+
+__global__ __launch_bounds__(kThreads) void nn_merge_kernel(const uint32_t* __restrict__ part_idx,
+                                                            const float* __restrict__ part_d2, int n_seg,
+                                                            int64_t n_src, uint32_t* __restrict__ idx_out,
+                                                            float* __restrict__ d2_out) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_src) return;
+  float best = part_d2[i];
+  uint32_t bi = part_idx[i];
+  for (int s = 1; s < n_seg; ++s) {
+    const float d = part_d2[(int64_t)s * n_src + i];
+    if (d < best) {  // strict: earlier segment (lower indices) keeps ties
+      best = d;
+      bi = part_idx[(int64_t)s * n_src + i];
+    }
+  }
+  idx_out[i] = bi;
+  if (d2_out) d2_out[i] = best;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -195,26 +223,46 @@ int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_t
   R3D_REQUIRE(n_tgt >= 1, "target cloud is empty");
   R3D_REQUIRE(n_tgt < ((int64_t)1 << 32), "target cloud too large for uint32 indices");
   R3D_REQUIRE(d_src && d_tgt && d_idx_out, "NULL device pointer");
-  // S sources per lane: fewer LDS reads per pair; keep enough workgroups to fill 256 CUs
+  // S sources per lane cut the LDS reads per pair; target segments supply the workgroups that S takes away
   int S = ctx->nn_variant;
-  if (S != 1 && S != 2 && S != 4) S = (n_src >= (int64_t)256 * 256 * 4) ? 2 : 1;
+  if (S != 1 && S != 2 && S != 4) S = 4;
   const int64_t per_block = (int64_t)kThreads * S;
-  const int64_t blocks = (n_src + per_block - 1) / per_block;
-  R3D_REQUIRE(blocks < ((int64_t)1 << 31), "source cloud too large");
+  const int64_t src_blocks = (n_src + per_block - 1) / per_block;
+  R3D_REQUIRE(src_blocks < ((int64_t)1 << 31), "source cloud too large");
+  const int64_t n_tiles = (n_tgt + kTgtTile - 1) / kTgtTile;
+  int64_t want_blocks = ctx->nn_blocks > 0 ? ctx->nn_blocks : (int64_t)ctx->num_cus * 16;
+  int64_t n_seg = (want_blocks + src_blocks - 1) / src_blocks;
+  if (n_seg > n_tiles) n_seg = n_tiles;
+  if (n_seg > 65535) n_seg = 65535;
+  if (n_seg < 1) n_seg = 1;
+  const int64_t tiles_per_seg = (n_tiles + n_seg - 1) / n_seg;
+  n_seg = (n_tiles + tiles_per_seg - 1) / tiles_per_seg;
+  uint32_t* k_idx = d_idx_out;
+  float* k_d2 = d_d2_out;
+  if (n_seg > 1) {
+    void* part = nullptr;
+    if ((rc = r3d_scratch(ctx, 5, (size_t)n_seg * n_src * 8, &part))) return rc;
+    k_idx = static_cast<uint32_t*>(part);
+    k_d2 = reinterpret_cast<float*>(k_idx + (size_t)n_seg * n_src);
+  }
+  const dim3 grid((unsigned)src_blocks, (unsigned)n_seg);
   switch (S) {
     case 1:
-      hipLaunchKernelGGL((nn_kernel<1>), dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt,
-                         n_tgt, d_idx_out, d_d2_out);
+      hipLaunchKernelGGL((nn_kernel<1>), grid, dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, n_tgt,
+                         tiles_per_seg, k_idx, k_d2);
       break;
     case 2:
-      hipLaunchKernelGGL((nn_kernel<2>), dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt,
-                         n_tgt, d_idx_out, d_d2_out);
+      hipLaunchKernelGGL((nn_kernel<2>), grid, dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, n_tgt,
+                         tiles_per_seg, k_idx, k_d2);
       break;
     default:
-      hipLaunchKernelGGL((nn_kernel<4>), dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt,
-                         n_tgt, d_idx_out, d_d2_out);
+      hipLaunchKernelGGL((nn_kernel<4>), grid, dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, n_tgt,
+                         tiles_per_seg, k_idx, k_d2);
       break;
   }
+  if (n_seg > 1)
+    hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)((n_src + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       ctx->stream, k_idx, k_d2, (int)n_seg, n_src, d_idx_out, d_d2_out);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

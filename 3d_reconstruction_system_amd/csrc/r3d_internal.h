@@ -20,7 +20,8 @@ struct r3d_ctx {
   int fuse_variant = 0;  // 0 auto
   int fuse_blocks = 0;   // 0 auto
   int nontemporal = 0;
-  int nn_variant = 0;
+  int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
+  int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
   int apply_variant = 0;  // 0 lane-per-point (default), 1 LDS-tiled
   // HIP-event stopwatch
