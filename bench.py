@@ -92,16 +92,22 @@ def main():
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; R3D_DIST_BACKEND=gloo lets several ranks share one GPU for a functional rehearsal
+    backend = os.environ.get("R3D_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     r3d = importlib.import_module("3d_reconstruction_system_amd")
     D = importlib.import_module("3d_reconstruction_system_amd.dist")
     stream = torch.cuda.current_stream(dev)
-    ctx = r3d.Context(local_rank, stream=stream.cuda_stream)
+    ctx = r3d.Context(dev_index, stream=stream.cuda_stream)
     cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
 
     # synthetic job: rank r owns frames [r*F, (r+1)*F) of a world*F-frame sequence
@@ -145,7 +151,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
