@@ -1,10 +1,15 @@
 """Frame-sharded fusion across the GPUs of one node: one process per GPU, frames split into
 contiguous blocks in pose-file order (the frame loop of camera_to_world.py:149-172 carries no
-state between frames), the fused world cloud assembled with ONE all-gather of xyz shards
-(torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+state between frames).  torch.distributed is the transport (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in CPU tests); the per-point arithmetic is the HIP library's.
 
-torch is plumbing here: device memory, the process group and the collective.  The per-point
-arithmetic is the HIP library's.
+Assembling the fused world cloud on every rank, two ways with bit-identical results:
+  * "outputs": every rank fuses its own frames, then ONE all-gather of the xyz shards
+    (12 B/point over xGMI).
+  * "inputs":  ONE all-gather of the depth rasters + pose rows (1 B/point + 96 B/frame over xGMI),
+    then every rank fuses ALL frames locally.  On MI355X the fused kernel streams 6.6 TB/s of
+    HBM while an xGMI link moves ~0.1-0.15 TB/s, so re-computing 13 B/point of HBM traffic is
+    far cheaper than receiving 12 B/point over the fabric: this is the default.
 """
 import numpy as np
 
@@ -91,6 +96,47 @@ class ShardedFusion:
         return out
 
     def fuse_and_gather(self, depth, pose, frames_per_rank, out=None):
+        """'outputs' assembly: fuse this rank's frames, all-gather the xyz shards."""
         shard = self.fuse_local(depth, pose, out)
         pts = [c * self.h * self.w for c in frames_per_rank]
         return all_gather_cloud(shard, pts, self.group)
+
+    def gather_inputs(self, depth, pose, frames_per_rank):
+        """All-gather the depth rasters and pose rows of every rank (padded to the longest shard).
+        Returns (depth_all [world*Fmax,H,W], pose_all [world*Fmax,12], Fmax)."""
+        import torch.distributed as dist
+        torch = self.torch
+        world = dist.get_world_size(self.group)
+        fmax = max(frames_per_rank)
+        if depth.shape[0] != fmax:
+            pad_d = torch.zeros((fmax, self.h, self.w), dtype=depth.dtype, device=depth.device)
+            pad_d[:depth.shape[0]] = depth
+            pad_p = torch.zeros((fmax, 12), dtype=pose.dtype, device=pose.device)
+            pad_p[:pose.shape[0]] = pose
+            depth, pose = pad_d, pad_p
+        depth_all = torch.empty((world * fmax, self.h, self.w), dtype=depth.dtype, device=depth.device)
+        pose_all = torch.empty((world * fmax, 12), dtype=pose.dtype, device=pose.device)
+        dist.all_gather_into_tensor(depth_all, depth.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(pose_all, pose.contiguous(), group=self.group)
+        return depth_all, pose_all, fmax
+
+    def gather_inputs_and_fuse(self, depth, pose, frames_per_rank, out=None):
+        """'inputs' assembly: all-gather rasters + poses, fuse every frame here.  Same bits as
+        fuse_and_gather (same kernel, same per-frame arithmetic), 1/12 of the fabric traffic."""
+        torch = self.torch
+        depth_all, pose_all, fmax = self.gather_inputs(depth, pose, frames_per_rank)
+        total = sum(frames_per_rank)
+        per = self.h * self.w
+        if out is None:
+            out = torch.empty((total * per, 3), dtype=self.out_dtype, device=depth.device)
+        if all(c == fmax for c in frames_per_rank):
+            if total:
+                self.fuse_fn(depth_all, pose_all, out)          # one launch over world*F frames
+            return out
+        done = 0
+        for r, c in enumerate(frames_per_rank):                  # ragged: skip each rank's padding
+            if c:
+                self.fuse_fn(depth_all[r * fmax:r * fmax + c], pose_all[r * fmax:r * fmax + c],
+                             out[done * per:(done + c) * per])
+            done += c
+        return out

@@ -7,9 +7,12 @@
 Workload (BASELINE.json configs[1], "C2"): KITTI-sized 1280x384 uint8 depth, 100 frames per GPU,
 synthetic (seed 1234), device-resident; one STEP = one pass of the hot path over the batch =
 ONE fused unproject + SE(3) launch over all 100 frames (49,152,000 points -> f32 xyz), and for
-N > 1 additionally the RCCL all-gather that assembles the fused world cloud on every rank
-(north_star).  Weak scaling: every rank owns 100 frames.  `value` is whole-job Mpoints/s
-(all ranks' points / max-over-ranks time).
+N > 1 additionally the collective that assembles the fused world cloud on every rank (north_star):
+by default an all-gather of the INPUTS (depth + poses, 1 B/point) followed by a local fuse of every
+rank's frames, which is bit-identical to and several times faster than all-gathering the xyz
+OUTPUTS (12 B/point) on xGMI; `--assemble outputs|none` selects the other strategies, and all of
+them are timed and printed under "assemble_ms_per_step".  Weak scaling: every rank owns 100 frames.
+`value` is whole-job Mpoints/s = UNIQUE fused points of all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
   roofline     -- the fused kernel against the HBM roof: algorithmic bytes (13 B/point) per launch
@@ -74,7 +77,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (100 = config C2)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the all-gather out of the step")
+    ap.add_argument("--assemble", default="inputs", choices=["inputs", "outputs", "none"],
+                    help="N>1: how the step assembles the fused world cloud on every rank: 'inputs' = all-gather "
+                         "depth+poses (1 B/point over xGMI) then fuse all frames locally (default, fastest); "
+                         "'outputs' = fuse own frames then all-gather xyz (12 B/point over xGMI); 'none' = shards stay put")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
     a = ap.parse_args()
@@ -118,21 +124,36 @@ def main():
     out_np = np.float32 if a.out_dtype == "float32" else np.float64
     out_t = torch.float32 if a.out_dtype == "float32" else torch.float64
     n_local = F * H * W
-    gather = world > 1 and not a.no_gather
-    if gather:
-        full = torch.empty((world * n_local, 3), dtype=out_t, device=dev)
-        shard = full[rank * n_local:(rank + 1) * n_local]       # fuse straight into this rank's slot
-    else:
-        full = None
+    mode = a.assemble if world > 1 else "none"
+    full = shard = depth_all = pose_all = None
+    if mode == "none":
         shard = torch.empty((n_local, 3), dtype=out_t, device=dev)
+    else:
+        full = torch.empty((world * n_local, 3), dtype=out_t, device=dev)
+        shard = full[rank * n_local:(rank + 1) * n_local]       # 'outputs': fuse straight into this rank's slot
+        depth_all = torch.empty((world * F, H, W), dtype=torch.uint8, device=dev)
+        pose_all = torch.empty((world * F, 12), dtype=torch.float64, device=dev)
 
-    def fuse():
+    def fuse():                                                  # this rank's frames only
         r3d.fuse_frames_device(ctx, cam, depth.data_ptr(), np.uint8, F, table.data_ptr(), shard.data_ptr(), out_np)
 
-    def step():
-        fuse()
-        if gather:
-            dist.all_gather_into_tensor(full, shard)
+    def make_step(m):
+        if m == "none":
+            return fuse
+        if m == "outputs":
+            def step_outputs():
+                fuse()
+                dist.all_gather_into_tensor(full, shard)
+            return step_outputs
+
+        def step_inputs():
+            dist.all_gather_into_tensor(depth_all, depth)
+            dist.all_gather_into_tensor(pose_all, table)
+            r3d.fuse_frames_device(ctx, cam, depth_all.data_ptr(), np.uint8, world * F, pose_all.data_ptr(),
+                                   full.data_ptr(), out_np)
+        return step_inputs
+
+    step = make_step(mode)
 
     def fence():
         if world > 1:
@@ -169,6 +190,25 @@ def main():
     bytes_per_launch = n_local * (1 + 3 * (4 if a.out_dtype == "float32" else 8))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
+    # N > 1: the other assembly strategies, timed briefly after the main region (reported, not `value`)
+    assemble_ms = {}
+    if world > 1:
+        for m in ("none", "outputs", "inputs"):
+            if m == mode or (m != "none" and full is None):
+                continue
+            st = make_step(m)
+            for _ in range(3):
+                st()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                st()
+            fence()
+            tm = torch.tensor([(time.perf_counter() - t1) / 10], dtype=torch.float64,
+                              device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            assemble_ms[m] = round(float(tm.item()) * 1e3, 4)
+
     if rank == 0:
         total_pts = world * n_local * a.steps
         line = {
@@ -187,7 +227,11 @@ def main():
             "config": {"workload": "C2: 1280x384 u8 depth x %d frames per GPU -> %s xyz, fused unproject+SE(3), "
                                    "inputs resident in HBM" % (F, a.out_dtype),
                        "frames_per_gpu": F, "points_per_step": world * n_local,
-                       "step": "1 fused launch" + (" + RCCL all-gather of the world cloud" if gather else ""),
+                       "step": {"none": "1 fused launch over this rank's frames (shards stay resident)",
+                                "outputs": "1 fused launch + all-gather of xyz shards (12 B/point over xGMI)",
+                                "inputs": "all-gather of depth+poses (1 B/point over xGMI) + 1 fused launch over "
+                                          "all ranks' frames on every rank"}[mode],
+                       "assemble": mode,
                        "parallelism": "frames sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
@@ -196,6 +240,9 @@ def main():
                          "timing": "HIP events on the launch stream over %d back-to-back launches" % a.steps},
             "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),
         }
+        if assemble_ms:
+            assemble_ms[mode] = line["ms_per_step"]
+            line["assemble_ms_per_step"] = assemble_ms
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line), flush=True)

@@ -37,6 +37,10 @@ def main():
     want = O.fuse_frames(depths, quats, ts)
     e_norm, e_comp = O.parity_errors(got, want)
     ok = got.shape == want.shape and e_norm <= 1e-6 and e_comp <= 1e-4
+    full2 = eng.gather_inputs_and_fuse(torch.from_numpy(depths[lo:hi].copy()).to(dev), torch.from_numpy(table).to(dev),
+                                       counts)
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(full2.cpu().numpy(), got)      # 'inputs' assembly: bit-identical
     with open("%s.rank%d" % (out_path, rank), "w") as f:
         f.write("ok=%d e_norm=%.3e lo=%d hi=%d\n" % (ok, e_norm, lo, hi))
     dist.barrier()

@@ -48,6 +48,9 @@ def main():
     ok = full.shape == (n_frames * H * W, 3) and np.array_equal(full.numpy(), want)
     # ... and the oracle's own quaternion path to fp64 round-off
     ok = ok and np.allclose(full.numpy(), O.fuse_frames(depths, quats, ts), rtol=0, atol=1e-11)
+    # the 'inputs' assembly (gather rasters + poses, fuse everything locally) must give the same bits
+    full2 = eng.gather_inputs_and_fuse(torch.from_numpy(depths[lo:hi].copy()), torch.from_numpy(table), counts)
+    ok = ok and full2.shape == full.shape and np.array_equal(full2.numpy(), full.numpy())
     # the product's own compute hook must refuse CPU tensors rather than fall back
     eng2 = D.ShardedFusion(H, W, (O.REF_FX, O.REF_FY, O.REF_CX, O.REF_CY))
     refused = False
