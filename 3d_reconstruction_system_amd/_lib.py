@@ -49,6 +49,8 @@ SIGNATURES = {
     "r3d_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memset": (_i, [_vp, _vp, _i, _sz]),
+    "r3d_host_alloc": (_i, [_vp, _sz, _pvp]),
+    "r3d_host_free": (_i, [_vp, _vp]),
     "r3d_timer_start": (_i, [_vp]),
     "r3d_timer_stop": (_i, [_vp, _pf]),
     "r3d_camera_create": (_i, [_vp, _i, _i, _d, _d, _d, _d, _pvp]),

@@ -219,10 +219,31 @@ int apply_host_common(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t 
   void *d_in = nullptr, *d_out = nullptr;
   if ((rc = r3d_scratch(ctx, 0, in_bytes, &d_in))) return rc;
   if ((rc = r3d_scratch(ctx, 1, out_bytes, &d_out))) return rc;
-  R3D_HIP(hipMemcpyAsync(d_in, h_xyz_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = apply_common<SE3>(ctx, d_in, in_dtype, n_points, h_M, d_out, out_dtype))) return rc;
-  R3D_HIP(hipMemcpyAsync(h_xyz_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  // 64 Ki points per pipeline item keeps every chunk boundary on a tile (and 16-byte) boundary
+  const int64_t item_pts = 65536;
+  const size_t isz = 3 * r3d_xyz_size(in_dtype), osz = 3 * r3d_xyz_size(out_dtype);
+  // whole items stream through the pinned pipeline; a ragged tail (< 64 Ki points) goes directly
+  const int64_t whole = (n_points / item_pts) * item_pts;
+  if (whole > 0) {
+    auto launch = [&](int64_t lo, int64_t n) -> int {
+      return apply_common<SE3>(ctx, static_cast<char*>(d_in) + (size_t)lo * item_pts * isz, in_dtype, n * item_pts, h_M,
+                               static_cast<char*>(d_out) + (size_t)lo * item_pts * osz, out_dtype);
+    };
+    if ((rc = r3d_host_pipeline(ctx, whole / item_pts, item_pts * isz, item_pts * osz, h_xyz_in, h_xyz_out, d_in, d_out,
+                                launch)))
+      return rc;
+  }
+  const int64_t tail = n_points - whole;
+  if (tail > 0) {
+    const char* hi = static_cast<const char*>(h_xyz_in) + (size_t)whole * isz;
+    char* ho = static_cast<char*>(h_xyz_out) + (size_t)whole * osz;
+    char* di = static_cast<char*>(d_in) + (size_t)whole * isz;
+    char* dout = static_cast<char*>(d_out) + (size_t)whole * osz;
+    R3D_HIP(hipMemcpyAsync(di, hi, (size_t)tail * isz, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = apply_common<SE3>(ctx, di, in_dtype, tail, h_M, dout, out_dtype))) return rc;
+    R3D_HIP(hipMemcpyAsync(ho, dout, (size_t)tail * osz, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return R3D_OK;
 }
 

@@ -116,6 +116,10 @@ int r3d_ctx_destroy(r3d_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < r3d_ctx::kScratchSlots; ++i)
     if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->pinned[i]) hipHostFree(ctx->pinned[i]);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->ev_pipe[i]) hipEventDestroy(ctx->ev_pipe[i]);
   if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);

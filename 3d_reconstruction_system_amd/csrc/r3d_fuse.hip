@@ -516,17 +516,19 @@ int fuse_host_common(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, i
   void *d_in = nullptr, *d_out = nullptr, *d_pose = nullptr;
   if ((rc = r3d_scratch(ctx, 0, in_bytes, &d_in))) return rc;
   if ((rc = r3d_scratch(ctx, 1, out_bytes, &d_out))) return rc;
-  R3D_HIP(hipMemcpyAsync(d_in, h_depth, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (with_pose) {
     if ((rc = r3d_scratch(ctx, 2, (size_t)n_frames * 12 * sizeof(double), &d_pose))) return rc;
     R3D_HIP(hipMemcpyAsync(d_pose, h_pose, (size_t)n_frames * 12 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
-  rc = fuse_common(ctx, cam, d_in, depth_dtype, n_frames, depth_scale, (const double*)d_pose, with_pose, d_out,
-                   out_dtype);
-  if (rc) return rc;
-  R3D_HIP(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  R3D_HIP(hipStreamSynchronize(ctx->stream));
-  return R3D_OK;
+  // frames stream through the pinned double-buffered pipeline, a few frames per chunk
+  const size_t frame_in = (size_t)cam->height * cam->width * r3d_depth_size(depth_dtype);
+  const size_t frame_out = (size_t)cam->height * cam->width * 3 * r3d_xyz_size(out_dtype);
+  auto launch = [&](int64_t lo, int64_t n) -> int {
+    return fuse_common(ctx, cam, static_cast<char*>(d_in) + (size_t)lo * frame_in, depth_dtype, (int)n, depth_scale,
+                       with_pose ? static_cast<const double*>(d_pose) + (size_t)lo * 12 : nullptr, with_pose,
+                       static_cast<char*>(d_out) + (size_t)lo * frame_out, out_dtype);
+  };
+  return r3d_host_pipeline(ctx, n_frames, frame_in, frame_out, h_depth, h_out, d_in, d_out, launch);
 }
 
 }  // namespace

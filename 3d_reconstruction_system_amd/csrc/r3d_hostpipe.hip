@@ -1,0 +1,139 @@
+// Host-buffer pipeline shared by the *_host entry points.
+//
+// The boundary hands over pageable host buffers (NumPy arrays).  A plain hipMemcpy from pageable
+// memory runs at ~11 GB/s on the MI355X host, which would cap the fused path at ~1 Gpoint/s.  Here the
+// batch is cut into chunks that flow through two pinned staging buffers per direction:
+//
+//   CPU: user -> pinned_in[b]   |  GPU stream: H2D, kernel, D2H -> pinned_out[b], event[b]
+//   CPU: wait event[b]; threads copy pinned_out[b] -> user      (while the GPU works on chunk c+1)
+//
+// so PCIe runs at its pinned rate and the pageable copies are spread over host threads.  Buffers that are
+// already pinned (r3d_host_alloc, or hipHostRegister'ed by the caller) skip the staging copies.
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "r3d_internal.h"
+
+namespace {
+
+void parallel_memcpy(void* dst, const void* src, size_t bytes, unsigned n_threads) {
+  if (bytes < ((size_t)4 << 20) || n_threads <= 1) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t per = ((bytes / n_threads) + 4095) & ~(size_t)4095;
+  for (unsigned t = 0; t < n_threads; ++t) {
+    const size_t lo = (size_t)t * per;
+    if (lo >= bytes) break;
+    const size_t n = std::min(per, bytes - lo);
+    pool.emplace_back([=]() { memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, n); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable pointers report an error: clear it
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+int pinned_slot(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
+  if (ctx->pinned_bytes[slot] < bytes) {
+    if (ctx->pinned[slot]) {
+      R3D_HIP(hipStreamSynchronize(ctx->stream));
+      R3D_HIP(hipHostFree(ctx->pinned[slot]));
+      ctx->pinned[slot] = nullptr;
+      ctx->pinned_bytes[slot] = 0;
+    }
+    R3D_HIP(hipHostMalloc(&ctx->pinned[slot], bytes, hipHostMallocDefault));
+    ctx->pinned_bytes[slot] = bytes;
+  }
+  *p = ctx->pinned[slot];
+  return R3D_OK;
+}
+
+}  // namespace
+
+int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
+                      void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch) {
+  if (n_items <= 0) return R3D_OK;
+  int rc;
+  unsigned n_threads = std::thread::hardware_concurrency();
+  n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
+  const bool in_pinned = is_pinned(h_in), out_pinned = is_pinned(h_out);
+  // ~32 MiB of the larger direction per chunk, at least 4 chunks when the batch allows it
+  const size_t big = std::max(in_item_bytes, out_item_bytes);
+  int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)32 << 20) / big));
+  chunk = std::min(chunk, std::max<int64_t>(1, (n_items + 3) / 4));
+  const int64_t n_chunks = (n_items + chunk - 1) / chunk;
+  void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  for (int b = 0; b < 2; ++b) {
+    if (!in_pinned && (rc = pinned_slot(ctx, b, (size_t)chunk * in_item_bytes, &pin_in[b]))) return rc;
+    if (!out_pinned && (rc = pinned_slot(ctx, 2 + b, (size_t)chunk * out_item_bytes, &pin_out[b]))) return rc;
+  }
+  if (!ctx->ev_pipe[0]) {
+    R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[0], hipEventDisableTiming));
+    R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[1], hipEventDisableTiming));
+  }
+  auto issue = [&](int64_t c) -> int {
+    const int b = (int)(c & 1);
+    const int64_t lo = c * chunk, n = std::min(chunk, n_items - lo);
+    const char* src = static_cast<const char*>(h_in) + (size_t)lo * in_item_bytes;
+    if (!in_pinned) {
+      parallel_memcpy(pin_in[b], src, (size_t)n * in_item_bytes, n_threads);
+      src = static_cast<const char*>(pin_in[b]);
+    }
+    R3D_HIP(hipMemcpyAsync(static_cast<char*>(d_in) + (size_t)lo * in_item_bytes, src, (size_t)n * in_item_bytes,
+                           hipMemcpyHostToDevice, ctx->stream));
+    int r = launch(lo, n);
+    if (r) return r;
+    void* dst = out_pinned ? static_cast<void*>(static_cast<char*>(h_out) + (size_t)lo * out_item_bytes) : pin_out[b];
+    R3D_HIP(hipMemcpyAsync(dst, static_cast<char*>(d_out) + (size_t)lo * out_item_bytes, (size_t)n * out_item_bytes,
+                           hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(hipEventRecord(ctx->ev_pipe[b], ctx->stream));
+    return R3D_OK;
+  };
+  auto drain = [&](int64_t c) -> int {
+    const int b = (int)(c & 1);
+    const int64_t lo = c * chunk, n = std::min(chunk, n_items - lo);
+    R3D_HIP(hipEventSynchronize(ctx->ev_pipe[b]));
+    if (!out_pinned)
+      parallel_memcpy(static_cast<char*>(h_out) + (size_t)lo * out_item_bytes, pin_out[b], (size_t)n * out_item_bytes,
+                      n_threads);
+    return R3D_OK;
+  };
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    if (c >= 2 && (rc = drain(c - 2))) return rc;  // frees staging pair b before it is reused
+    if ((rc = issue(c))) return rc;
+  }
+  for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c)
+    if ((rc = drain(c))) return rc;
+  return R3D_OK;
+}
+
+extern "C" {
+
+int r3d_host_alloc(r3d_ctx* ctx, size_t bytes, void** h_ptr_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(h_ptr_out != nullptr, "h_ptr_out is NULL");
+  *h_ptr_out = nullptr;
+  R3D_HIP(hipHostMalloc(h_ptr_out, bytes ? bytes : 16, hipHostMallocDefault));
+  return R3D_OK;
+}
+
+int r3d_host_free(r3d_ctx* ctx, void* h_ptr) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  if (!h_ptr) return R3D_OK;
+  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  R3D_HIP(hipHostFree(h_ptr));
+  return R3D_OK;
+}
+
+}  // extern "C"

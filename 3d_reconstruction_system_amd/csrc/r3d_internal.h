@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 
 #include "r3d.h"
 
@@ -30,6 +31,10 @@ struct r3d_ctx {
   static constexpr int kScratchSlots = 6;
   void* scratch[kScratchSlots] = {};
   size_t scratch_bytes[kScratchSlots] = {};
+  // pinned staging buffers of the host pipeline: [0,1] inbound, [2,3] outbound
+  void* pinned[4] = {};
+  size_t pinned_bytes[4] = {};
+  hipEvent_t ev_pipe[2] = {nullptr, nullptr};
 };
 
 struct r3d_camera {
@@ -62,6 +67,11 @@ int r3d_fail_hip(hipError_t e, const char* what, const char* file, int line);
 int r3d_ctx_enter(r3d_ctx* ctx);
 // grow-only scratch slot (device memory); returns device pointer in *p
 int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p);
+
+// Chunked, double-buffered host<->device pipeline (r3d_hostpipe.hip).  Items [lo, lo+n) of the batch are uploaded
+// to d_in + lo*in_item_bytes, `launch(lo, n)` enqueues the kernel for them, and d_out + lo*out_item_bytes comes back.
+int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
+                      void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch);
 
 static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
 static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

@@ -29,6 +29,23 @@ def xyz_code(dtype):
         raise TypeError("point clouds are float32 or float64 (got %s)" % np.dtype(dtype))
 
 
+_pinned_owners = {}
+
+
+class _PinnedOwner:
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+
+def _release_pinned(key):
+    owner = _pinned_owners.pop(key, None)
+    if owner is not None and owner.ctx.handle:
+        try:
+            owner.ctx.lib.r3d_host_free(owner.ctx.handle, owner.ptr)
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """A library-owned HBM allocation.  `ptr` is the raw device address."""
 
@@ -114,6 +131,22 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def pinned_empty(self, shape, dtype):
+        """NumPy array backed by page-locked host memory (r3d_host_alloc): the *_host entry points DMA
+        straight into it instead of staging.  Freed when the array (and its views) are garbage collected."""
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = max(count * dtype.itemsize, 16)
+        p = C.c_void_p()
+        L.check(self.lib.r3d_host_alloc(self.handle, nbytes, C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        owner = _PinnedOwner(self, p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+        _pinned_owners[id(buf)] = owner
+        import weakref
+        weakref.finalize(buf, _release_pinned, id(buf))
+        return arr
 
     def timer_start(self):
         L.check(self.lib.r3d_timer_start(self.handle))

@@ -46,15 +46,24 @@ def unproject(depth, intrinsics=REF_INTRINSICS, out_dtype=np.float32, depth_scal
     return out
 
 
+def _out_array(out, n, out_dtype):
+    if out is None:
+        return np.empty((n, 3), dtype=out_dtype)
+    if not (isinstance(out, np.ndarray) and out.shape == (n, 3) and out.flags.c_contiguous):
+        raise ValueError("out must be a C-contiguous [%d,3] array" % n)
+    return out
+
+
 def fuse_frames(depths, quats_xyzw, ts, intrinsics=REF_INTRINSICS, out_dtype=np.float32, depth_scale=1.0,
-                ctx=None):
-    """World-frame cloud of F frames, concatenated in frame order: p_w = Rinv_f (p_cam - t_f)."""
+                ctx=None, out=None):
+    """World-frame cloud of F frames, concatenated in frame order: p_w = Rinv_f (p_cam - t_f).
+    out: optional preallocated [F*H*W,3] array (e.g. ctx.pinned_empty(...) for full-rate PCIe)."""
     d = _as_batch(depths)
     f, h, w = d.shape
     table = pose_table(quats_xyzw, ts)
     if table.shape[0] != f:
         raise ValueError("%d frames but %d poses" % (f, table.shape[0]))
-    out = np.empty((f * h * w, 3), dtype=out_dtype)
+    out = _out_array(out, f * h * w, out_dtype)
     xyz_code(out.dtype)
     if f * h * w == 0:
         return out

@@ -77,6 +77,10 @@ int r3d_dev_free(r3d_ctx* ctx, void* d_ptr);
 int r3d_memcpy_h2d(r3d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* async on ctx stream */
 int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on ctx stream */
 int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
+/* Pinned (page-locked) host memory.  The *_host entry points detect pinned buffers and DMA straight from/to them;
+ * pageable buffers go through the library's own pinned staging ring with multi-threaded copies. */
+int r3d_host_alloc(r3d_ctx* ctx, size_t bytes, void** h_ptr_out);
+int r3d_host_free(r3d_ctx* ctx, void* h_ptr);
 /* HIP-event stopwatch on the ctx's stream: start records an event, stop records a second
  * one, synchronises on it and returns the elapsed milliseconds between them. */
 int r3d_timer_start(r3d_ctx* ctx);

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point (r3d_fuse_frames_host) on config C2."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+r3d = importlib.import_module("3d_reconstruction_system_amd")
+
+F, H, W = 100, 384, 1280
+rng = np.random.default_rng(1234)
+depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
+q = rng.normal(size=(F, 4))
+t = rng.normal(size=(F, 3)) * 10
+ctx = r3d.Context(0)
+for dt in (np.float32, np.float64):
+    for rep in range(4):
+        t0 = time.perf_counter()
+        out = r3d.fuse_frames(depth, q, t, out_dtype=dt, ctx=ctx)
+        dt_s = time.perf_counter() - t0
+        print("%s rep %d: %.1f ms  %.2f Gpoints/s  (D2H-equivalent %.1f GB/s)" % (np.dtype(dt).name, rep, dt_s * 1e3,
+              F * H * W / dt_s / 1e9, out.nbytes / dt_s / 1e9))
+    if hasattr(ctx, "pinned_empty"):
+        pin = ctx.pinned_empty((F * H * W, 3), dt)
+        for rep in range(3):
+            t0 = time.perf_counter()
+            r3d.fuse_frames(depth, q, t, out_dtype=dt, ctx=ctx, out=pin)
+            dt_s = time.perf_counter() - t0
+            print("%s pinned out rep %d: %.1f ms  %.2f Gpoints/s  (%.1f GB/s)" % (np.dtype(dt).name, rep, dt_s * 1e3,
+                  F * H * W / dt_s / 1e9, pin.nbytes / dt_s / 1e9))
+ctx.close()
