@@ -70,6 +70,15 @@ SIGNATURES = {
     "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),
     "r3d_write_xyz_txt": (_i, [C.c_char_p, _vp, _i, _i64, _vp, _i, _i]),
     "r3d_format_xyz_txt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _sz, _psz]),
+    "r3d_voxelset_create": (_i, [_vp, _d, _i64, _pvp]),
+    "r3d_voxelset_destroy": (_i, [_vp]),
+    "r3d_voxelset_clear": (_i, [_vp]),
+    "r3d_voxelset_insert": (_i, [_vp, _vp, _i64]),
+    "r3d_voxelset_insert_host": (_i, [_vp, _vp, _i64]),
+    "r3d_voxelset_stats": (_i, [_vp, _vp, _vp, _vp]),
+    "r3d_voxelset_codes": (_i, [_vp, _vp, _i64, _vp]),
+    "r3d_octree_format_bt": (_i, [_vp, _i64, _d, _vp, _sz, _psz, _vp]),
+    "r3d_octree_write_bt": (_i, [C.c_char_p, _vp, _i64, _d, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,398 @@
+// Occupied-voxel set of a world cloud on gfx950 (MI355X) + OctoMap binary (.bt) export.
+//
+// Replaces the per-point `tree.updateNode(xyz, True)` loop, `updateInnerOccupancy()` and
+// `writeBinary()` of octomap/txt_transfer_octomap.py:16-36 (== octomap/ply_transfer_octomap.py:16-48).
+// The arithmetic of that path lives in the third-party OctoMap library (not vendored, not pinned by the
+// reference): restated from its published semantics, parity unpinned (oracle/octomap_ref.py).
+//
+// A hits-only tree written with writeBinary() depends only on the SET of voxels that received a point
+// (toMaxLikelihood makes every hit leaf "occupied"), so the GPU's job is a set insert:
+//   * voxel_insert_kernel (HBM-bound, 12 B/point read): lane-per-point 12-byte loads, key per axis
+//     = (int)floor((1/res) * (double)x) + 32768 in fp64 like OcTreeBaseImpl::coordToKey, 16-bit keys
+//     interleaved to a 48-bit Morton code (x lowest, as OctoMap's child index), lanes whose predecessor
+//     lane holds the same code drop out, the rest go into an open-addressing hash set in HBM
+//     (64-bit atomicCAS, multiplicative hash, linear probing).
+//   * voxel_compact_kernel: table -> dense list of codes.
+// The host sorts the (much smaller) unique list and emits the pruned octree depth-first: a child subtree
+// is a pruned leaf exactly when its code range holds 8^(levels below) codes.
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "r3d_internal.h"
+
+struct r3d_voxelset {
+  r3d_ctx* ctx = nullptr;
+  double res = 0.1;
+  double factor = 10.0;
+  uint64_t* d_table = nullptr;
+  uint64_t capacity = 0;  // power of two
+  int log2cap = 0;
+  unsigned long long* d_counters = nullptr;  // [0] voxels, [1] ignored points, [2] overflow, [3] compaction cursor
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint64_t kEmpty = ~0ull;
+constexpr int kTreeMaxVal = 32768;
+
+struct __attribute__((packed, aligned(4))) P3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 16 bits -> every third bit
+  uint64_t x = v & 0xffffu;
+  x = (x | x << 16) & 0x0000ff0000ffull;
+  x = (x | x << 8) & 0x00f00f00f00full;
+  x = (x | x << 4) & 0x0c30c30c30c3ull;
+  x = (x | x << 2) & 0x249249249249ull;
+  return x;
+}
+
+__device__ __forceinline__ bool voxel_code(const P3& p, double factor, uint64_t* code) {
+  const double kx = floor(factor * (double)p.x), ky = floor(factor * (double)p.y), kz = floor(factor * (double)p.z);
+  // rejects NaN/inf and anything outside the 2^16 key range
+  const bool ok = kx >= -(double)kTreeMaxVal && kx < (double)kTreeMaxVal && ky >= -(double)kTreeMaxVal &&
+                  ky < (double)kTreeMaxVal && kz >= -(double)kTreeMaxVal && kz < (double)kTreeMaxVal;
+  if (!ok) return false;
+  const uint32_t ix = (uint32_t)((int)kx + kTreeMaxVal), iy = (uint32_t)((int)ky + kTreeMaxVal),
+                 iz = (uint32_t)((int)kz + kTreeMaxVal);
+  *code = spread3(ix) | (spread3(iy) << 1) | (spread3(iz) << 2);
+  return true;
+}
+
+__global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __restrict__ xyz, int64_t n, double factor,
+                                                                uint64_t* __restrict__ table, int log2cap,
+                                                                unsigned long long* __restrict__ counters) {
+  const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
+  const int lane = threadIdx.x & 63;
+  const int64_t n_tiles = (n + kThreads * 4 - 1) / (kThreads * 4);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t base = tile * (kThreads * 4) + threadIdx.x;
+    P3 p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + (int64_t)r * kThreads;
+      if (i < n) p[r] = reinterpret_cast<const P3*>(xyz)[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + (int64_t)r * kThreads;
+      uint64_t code = kEmpty;
+      bool live = i < n;
+      if (live && !voxel_code(p[r], factor, &code)) {
+        atomicAdd(&counters[1], 1ull);
+        live = false;
+        code = kEmpty;
+      }
+      // neighbouring pixels mostly fall into the same voxel: a lane whose predecessor carries the same
+      // code leaves the insert to it
+      const uint64_t prev = __shfl_up(code, 1, 64);
+      if (live && lane > 0 && prev == code) live = false;
+      if (live) {
+        uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+        bool done = false;
+        for (uint64_t probe = 0; probe <= mask && !done; ++probe) {
+          const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
+                                         (unsigned long long)code);
+          if (old == kEmpty) {
+            atomicAdd(&counters[0], 1ull);
+            done = true;
+          } else if (old == code) {
+            done = true;
+          } else {
+            slot = (slot + 1) & mask;
+          }
+        }
+        if (!done) atomicAdd(&counters[2], 1ull);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void voxel_compact_kernel(const uint64_t* __restrict__ table, uint64_t capacity,
+                                                                 uint64_t* __restrict__ out,
+                                                                 unsigned long long* __restrict__ counters) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t v = table[i];
+    if (v != kEmpty) out[atomicAdd(&counters[3], 1ull)] = v;
+  }
+}
+
+void parallel_sort(uint64_t* a, int64_t n) {
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned parts = 1;
+  while (parts * 2 <= std::min(hw == 0 ? 1u : hw, 16u) && n / (parts * 2) >= 65536) parts *= 2;
+  if (parts == 1) {
+    std::sort(a, a + n);
+    return;
+  }
+  std::vector<int64_t> cut(parts + 1);
+  for (unsigned p = 0; p <= parts; ++p) cut[p] = n * p / parts;
+  {
+    std::vector<std::thread> pool;
+    for (unsigned p = 0; p < parts; ++p) pool.emplace_back([=, &cut]() { std::sort(a + cut[p], a + cut[p + 1]); });
+    for (auto& t : pool) t.join();
+  }
+  for (unsigned width = 1; width < parts; width *= 2) {
+    std::vector<std::thread> pool;
+    for (unsigned p = 0; p + width < parts; p += 2 * width) {
+      const int64_t lo = cut[p], mid = cut[p + width], hi = cut[std::min(p + 2 * width, parts)];
+      pool.emplace_back([=]() { std::inplace_merge(a + lo, a + mid, a + hi); });
+    }
+    for (auto& t : pool) t.join();
+  }
+}
+
+// ---- octree serialisation (host) ----
+constexpr int kDepth = 16;
+
+struct BtWriter {
+  const uint64_t* codes;
+  std::string body;
+  int64_t n_nodes = 0;
+
+  static bool full(int64_t count, int child_depth) {
+    const int levels = kDepth - child_depth;  // 8^levels leaves below a node at child_depth
+    return levels <= 20 && count == ((int64_t)1 << (3 * levels));
+  }
+
+  void node(int64_t lo, int64_t hi, int depth) {
+    ++n_nodes;
+    const int shift = 3 * (kDepth - 1 - depth);
+    int64_t bounds[9];
+    bounds[0] = lo;
+    for (int c = 1; c <= 8; ++c) {
+      // first index whose child id at this level is >= c
+      const uint64_t* first = std::lower_bound(codes + bounds[c - 1], codes + hi, (uint64_t)c,
+                                               [shift](uint64_t v, uint64_t cc) { return ((v >> shift) & 7u) < cc; });
+      bounds[c] = first - codes;
+    }
+    unsigned char b[2] = {0, 0};
+    int64_t inner[8][2];
+    int n_inner = 0;
+    for (int c = 0; c < 8; ++c) {
+      const int64_t clo = bounds[c], chi = bounds[c + 1];
+      if (chi == clo) continue;
+      if (depth + 1 == kDepth || full(chi - clo, depth + 1)) {
+        b[c / 4] |= (unsigned char)(2u << (2 * (c % 4)));  // occupied leaf (possibly a pruned subtree)
+        ++n_nodes;
+      } else {
+        b[c / 4] |= (unsigned char)(3u << (2 * (c % 4)));
+        inner[n_inner][0] = clo;
+        inner[n_inner][1] = chi;
+        ++n_inner;
+      }
+    }
+    body.push_back((char)b[0]);
+    body.push_back((char)b[1]);
+    for (int k = 0; k < n_inner; ++k) node(inner[k][0], inner[k][1], depth + 1);
+  }
+};
+
+int build_bt(const uint64_t* codes, int64_t n, double res, std::string* out, int64_t* n_nodes) {
+  for (int64_t i = 1; i < n; ++i)
+    if (codes[i] <= codes[i - 1]) {
+      r3d_set_error("octree export needs strictly ascending Morton codes (violated at index %lld)", (long long)i);
+      return R3D_ERR_INVALID;
+    }
+  if (n > 0 && (codes[n - 1] >> 48) != 0) {
+    r3d_set_error("Morton code above 48 bits");
+    return R3D_ERR_INVALID;
+  }
+  BtWriter w;
+  w.codes = codes;
+  if (n > 0) {
+    if (BtWriter::full(n, 0)) {
+      w.n_nodes = 1;
+      w.body.assign(2, '\0');
+    } else {
+      w.node(0, n, 0);
+    }
+  }
+  char head[256];
+  snprintf(head, sizeof(head),
+           "# Octomap OcTree binary file\n# (feel free to add / change comments, but leave the first line as it is!)\n#\n"
+           "id OcTree\nsize %lld\nres %g\ndata\n",
+           (long long)w.n_nodes, res);
+  *out = std::string(head) + w.body;
+  *n_nodes = w.n_nodes;
+  return R3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_voxelset** vs_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(vs_out != nullptr, "vs_out is NULL");
+  *vs_out = nullptr;
+  R3D_REQUIRE(resolution > 0.0 && std::isfinite(resolution), "resolution must be positive");
+  R3D_REQUIRE(capacity >= 0, "capacity must be >= 0");
+  r3d_voxelset* vs = new (std::nothrow) r3d_voxelset();
+  if (!vs) {
+    r3d_set_error("host allocation failed");
+    return R3D_ERR_NOMEM;
+  }
+  vs->ctx = ctx;
+  vs->res = resolution;
+  vs->factor = 1.0 / resolution;  // OcTreeBaseImpl::resolution_factor
+  vs->log2cap = 10;
+  while (((int64_t)1 << vs->log2cap) < capacity && vs->log2cap < 40) ++vs->log2cap;
+  vs->capacity = (uint64_t)1 << vs->log2cap;
+  hipError_t e = hipMalloc((void**)&vs->d_table, vs->capacity * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&vs->d_counters, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream);
+  if (e != hipSuccess) {
+    r3d_voxelset_destroy(vs);
+    return r3d_fail_hip(e, "voxel set allocation", __FILE__, __LINE__);
+  }
+  *vs_out = vs;
+  return R3D_OK;
+}
+
+int r3d_voxelset_destroy(r3d_voxelset* vs) {
+  if (!vs) return R3D_OK;
+  if (vs->ctx) {
+    (void)hipSetDevice(vs->ctx->device);
+    (void)hipStreamSynchronize(vs->ctx->stream);
+  }
+  if (vs->d_table) (void)hipFree(vs->d_table);
+  if (vs->d_counters) (void)hipFree(vs->d_counters);
+  delete vs;
+  return R3D_OK;
+}
+
+int r3d_voxelset_clear(r3d_voxelset* vs) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  int rc = r3d_ctx_enter(vs->ctx);
+  if (rc) return rc;
+  R3D_HIP(hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), vs->ctx->stream));
+  R3D_HIP(hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), vs->ctx->stream));
+  return R3D_OK;
+}
+
+int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  int rc = r3d_ctx_enter(vs->ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
+  if (n_points == 0) return R3D_OK;
+  R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
+  const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
+  int blocks = vs->ctx->num_cus * 8;
+  if ((int64_t)blocks > n_tiles) blocks = (int)n_tiles;
+  hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, d_xyz, n_points, vs->factor,
+                     vs->d_table, vs->log2cap, vs->d_counters);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+int r3d_voxelset_insert_host(r3d_voxelset* vs, const float* h_xyz, int64_t n_points) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  int rc = r3d_ctx_enter(vs->ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
+  if (n_points == 0) return R3D_OK;
+  R3D_REQUIRE(h_xyz != nullptr, "NULL host pointer");
+  void* d = nullptr;
+  if ((rc = r3d_scratch(vs->ctx, 0, (size_t)n_points * 12, &d))) return rc;
+  R3D_HIP(hipMemcpyAsync(d, h_xyz, (size_t)n_points * 12, hipMemcpyHostToDevice, vs->ctx->stream));
+  if ((rc = r3d_voxelset_insert(vs, static_cast<const float*>(d), n_points))) return rc;
+  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
+  return R3D_OK;
+}
+
+int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, int64_t* n_overflow) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  int rc = r3d_ctx_enter(vs->ctx);
+  if (rc) return rc;
+  unsigned long long c[4];
+  R3D_HIP(hipMemcpyAsync(c, vs->d_counters, sizeof(c), hipMemcpyDeviceToHost, vs->ctx->stream));
+  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
+  if (n_voxels) *n_voxels = (int64_t)c[0];
+  if (n_ignored) *n_ignored = (int64_t)c[1];
+  if (n_overflow) *n_overflow = (int64_t)c[2];
+  return R3D_OK;
+}
+
+int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, int64_t* n_out) {
+  R3D_REQUIRE(vs != nullptr && n_out != nullptr, "NULL argument");
+  int64_t n = 0, ign = 0, over = 0;
+  int rc = r3d_voxelset_stats(vs, &n, &ign, &over);
+  if (rc) return rc;
+  *n_out = n;
+  if (over > 0) {
+    r3d_set_error("voxel set overflowed (%lld points found no slot): create it with a larger capacity", (long long)over);
+    return R3D_ERR_NOMEM;
+  }
+  if (!h_codes_sorted) return R3D_OK;
+  R3D_REQUIRE(cap >= n, "buffer holds %lld codes, set has %lld", (long long)cap, (long long)n);
+  if (n == 0) return R3D_OK;
+  void* d_list = nullptr;
+  if ((rc = r3d_scratch(vs->ctx, 1, (size_t)n * sizeof(uint64_t), &d_list))) return rc;
+  R3D_HIP(hipMemsetAsync(vs->d_counters + 3, 0, sizeof(unsigned long long), vs->ctx->stream));
+  int blocks = vs->ctx->num_cus * 8;
+  const uint64_t need = (vs->capacity + kThreads - 1) / kThreads;
+  if ((uint64_t)blocks > need) blocks = (int)need;
+  hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, vs->d_table, vs->capacity,
+                     static_cast<uint64_t*>(d_list), vs->d_counters);
+  R3D_HIP(hipGetLastError());
+  R3D_HIP(hipMemcpyAsync(h_codes_sorted, d_list, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, vs->ctx->stream));
+  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
+  parallel_sort(h_codes_sorted, n);
+  return R3D_OK;
+}
+
+int r3d_octree_format_bt(const uint64_t* h_codes_sorted, int64_t n_codes, double resolution, char* h_buf,
+                         size_t buf_cap, size_t* n_bytes_out, int64_t* n_nodes_out) {
+  if (n_codes < 0 || (n_codes > 0 && !h_codes_sorted) || !n_bytes_out || !(resolution > 0.0)) {
+    r3d_set_error("r3d_octree_format_bt: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  std::string out;
+  int64_t nodes = 0;
+  int rc = build_bt(h_codes_sorted, n_codes, resolution, &out, &nodes);
+  if (rc) return rc;
+  *n_bytes_out = out.size();
+  if (n_nodes_out) *n_nodes_out = nodes;
+  if (!h_buf) return R3D_OK;
+  if (buf_cap < out.size()) {
+    r3d_set_error("r3d_octree_format_bt: buffer of %zu bytes is too small for %zu", buf_cap, out.size());
+    return R3D_ERR_NOMEM;
+  }
+  memcpy(h_buf, out.data(), out.size());
+  return R3D_OK;
+}
+
+int r3d_octree_write_bt(const char* path, const uint64_t* h_codes_sorted, int64_t n_codes, double resolution,
+                        int64_t* n_nodes_out) {
+  if (!path || n_codes < 0 || (n_codes > 0 && !h_codes_sorted) || !(resolution > 0.0)) {
+    r3d_set_error("r3d_octree_write_bt: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  std::string out;
+  int64_t nodes = 0;
+  int rc = build_bt(h_codes_sorted, n_codes, resolution, &out, &nodes);
+  if (rc) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    r3d_set_error("r3d_octree_write_bt: cannot open '%s'", path);
+    return R3D_ERR_INVALID;
+  }
+  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+  if (fclose(f) != 0 || !ok) {
+    r3d_set_error("r3d_octree_write_bt: short write to '%s'", path);
+    return R3D_ERR_INVALID;
+  }
+  if (n_nodes_out) *n_nodes_out = nodes;
+  return R3D_OK;
+}
+
+}  // extern "C"

@@ -162,6 +162,31 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
 int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
                        char* h_buf, size_t buf_cap, size_t* n_bytes_out);
 
+/* ---- f2: occupied-voxel set + OctoMap binary export.  Replaces the per-point tree.updateNode(xyz, True) loop,
+ * updateInnerOccupancy() and writeBinary() of octomap/txt_transfer_octomap.py:16-36 and
+ * octomap/ply_transfer_octomap.py:16-48 (arithmetic in the un-vendored OctoMap library; restated from its
+ * published semantics: float coordinates, key = (int)floor((1/res)*x) + 32768 per axis, depth 16, hits only).
+ * The set lives in HBM as an open-addressing hash table of 48-bit Morton codes; `capacity` = slots
+ * (rounded up to a power of two; >= 2x the expected number of distinct voxels keeps probing short). */
+typedef struct r3d_voxelset r3d_voxelset;
+int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_voxelset** vs_out);
+int r3d_voxelset_destroy(r3d_voxelset* vs);
+int r3d_voxelset_clear(r3d_voxelset* vs);
+/* insert float32 xyz points (asynchronous on the ctx stream; may be called once per frame batch) */
+int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points);
+int r3d_voxelset_insert_host(r3d_voxelset* vs, const float* h_xyz, int64_t n_points);
+/* synchronises; any pointer may be NULL.  n_ignored = points outside the 2^16 key range or non-finite
+ * (OctoMap drops them); n_overflow > 0 means the table was too small and the set is incomplete. */
+int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, int64_t* n_overflow);
+/* distinct voxels as ascending 48-bit Morton codes (3 bits per level, x lowest: OctoMap's child index order).
+ * h_codes_sorted == NULL only reports the count. */
+int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, int64_t* n_out);
+/* OctoMap ".bt" bytes (header + pruned maximum-likelihood tree, depth first) for ascending unique codes. */
+int r3d_octree_format_bt(const uint64_t* h_codes_sorted, int64_t n_codes, double resolution, char* h_buf,
+                         size_t buf_cap, size_t* n_bytes_out, int64_t* n_nodes_out);
+int r3d_octree_write_bt(const char* path, const uint64_t* h_codes_sorted, int64_t n_codes, double resolution,
+                        int64_t* n_nodes_out);
+
 #ifdef __cplusplus
 }
 #endif

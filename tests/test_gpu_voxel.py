@@ -1,0 +1,127 @@
+"""GPU: occupied-voxel set kernel + the OctoMap drop-in scripts against oracle/octomap_ref.py
+(parity unpinned by the reference: the OctoMap library is absent; see the oracle's header)."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import PKG, ROOT, r3d as _r3d
+from oracle import octomap_ref as OM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def V():
+    return importlib.import_module(PKG + ".voxelmap")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _r3d().Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,spread", [(1, 1.0), (7, 0.2), (1000, 1.0), (4097, 3.0), (300000, 8.0), (1000000, 2.0)])
+def test_voxel_set_matches_oracle(V, ctx, n, spread):
+    rng = np.random.default_rng(n)
+    pts = (rng.normal(size=(n, 3)) * spread).astype(np.float32)
+    vs = V.VoxelSet(0.1, max(1024, 2 * n), ctx)
+    vs.insert(pts)
+    st = vs.stats()
+    want, dropped = OM.occupied_set(pts)
+    assert st == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}
+    np.testing.assert_array_equal(vs.codes(), want)
+    vs.insert(pts[: n // 2])                                   # re-inserting changes nothing
+    assert vs.stats()["voxels"] == len(want)
+    vs.clear()
+    assert vs.stats()["voxels"] == 0
+    vs.close()
+
+
+def test_out_of_range_nonfinite_and_duplicates(V, ctx):
+    pts = np.array([[-0.05, 0.0, 0.1], [3276.75, 0, 0], [3276.85, 0, 0], [-3276.75, 0, 0], [-3276.9, 0, 0],
+                    [np.nan, 0, 0], [np.inf, 0, 0], [0.01, 0.02, 0.03], [0.04, 0.05, 0.06]] * 50, np.float32)
+    vs = V.VoxelSet(0.1, 4096, ctx)
+    vs.insert(pts)
+    want, dropped = OM.occupied_set(pts)
+    assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}
+    assert dropped == 4 * 50 and len(want) == 4
+    np.testing.assert_array_equal(vs.codes(), want)
+    vs.close()
+
+
+def test_overflow_is_reported_and_voxelize_regrows(V, ctx):
+    R = _r3d()
+    rng = np.random.default_rng(0)
+    pts = (rng.random((20000, 3)) * 50).astype(np.float32)
+    vs = V.VoxelSet(0.1, 1024, ctx)
+    vs.insert(pts)
+    assert vs.stats()["overflow"] > 0
+    with pytest.raises(R.R3DError):
+        vs.codes()
+    vs.close()
+    codes, st = V.voxelize(pts, 0.1, ctx)
+    np.testing.assert_array_equal(codes, OM.occupied_set(pts)[0])
+
+
+def test_other_resolution(V, ctx):
+    rng = np.random.default_rng(1)
+    pts = (rng.normal(size=(5000, 3)) * 4).astype(np.float32)
+    codes, _ = V.voxelize(pts, 0.25, ctx)
+    np.testing.assert_array_equal(codes, OM.occupied_set(pts, 0.25)[0])
+    assert V.format_bt(codes, 0.25) == OM.write_bt_bytes(codes, 0.25)
+
+
+def test_fused_cloud_to_bt_on_device(V, ctx):
+    """depth -> world cloud -> voxel set without leaving HBM, .bt equals the oracle's for the oracle's cloud."""
+    R = _r3d()
+    from oracle import fusion_ref as O
+    rng = np.random.default_rng(2)
+    F, H, W = 4, 48, 64
+    d = rng.integers(1, 60, size=(F, H, W), dtype=np.uint8)
+    q = rng.normal(size=(F, 4))
+    t = rng.normal(size=(F, 3))
+    K = (60.0, 60.0, 32, 24)
+    cam = ctx.camera(H, W, *K)
+    d_depth = ctx.alloc(d.nbytes).upload(d)
+    tab = R.pose_table(q, t)
+    d_pose = ctx.alloc(tab.nbytes).upload(tab)
+    d_out = ctx.alloc(F * H * W * 12)
+    R.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+    vs = V.VoxelSet(0.1, 1 << 16, ctx)
+    vs.insert_device(d_out.ptr, F * H * W)
+    codes = vs.codes()
+    world32 = O.fuse_frames(d, q, t, *K).astype(np.float32)
+    got32 = d_out.download(np.float32, F * H * W * 3).reshape(-1, 3)
+    np.testing.assert_array_equal(codes, OM.occupied_set(got32)[0])
+    # against the oracle's own cloud: identical unless a coordinate sits within an f32 ulp of a voxel face
+    want = OM.occupied_set(world32)[0]
+    assert len(np.setxor1d(codes, want)) <= 4
+    vs.close()
+
+
+def run_script(rel, cwd, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, PKG, rel)] + list(args), cwd=cwd, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_octomap_dropin_scripts(tmp_path, golden_dir):
+    R = _r3d()
+    scene = os.path.join(golden_dir, "scene3")
+    os.makedirs(tmp_path / "bt")
+    world_txt = os.path.join(scene, "point_world", "small_worldpoint_5_23_5.txt")
+    run_script("octomap/txt_transfer_octomap.py", str(tmp_path), world_txt, "bt/w.bt")
+    pts = R.cloud_io.read_xyz_txt(world_txt).astype(np.float32)
+    assert (tmp_path / "bt" / "w.bt").read_bytes() == OM.write_bt_bytes(OM.occupied_set(pts)[0])[0]
+    ply = os.path.join(scene, "ply", "small_035_p8.ply")
+    run_script("octomap/ply_transfer_octomap.py", str(tmp_path), ply, "bt/p.bt")
+    verts = R.cloud_io.read_ply(ply).astype(np.float32)[1:]         # the reference skips 8 lines: first vertex lost
+    assert (tmp_path / "bt" / "p.bt").read_bytes() == OM.write_bt_bytes(OM.occupied_set(verts)[0])[0]
+    run_script("other_tools/ply_transfer_octomap.py", str(tmp_path), ply, "bt/p2.bt")
+    assert (tmp_path / "bt" / "p2.bt").read_bytes() == (tmp_path / "bt" / "p.bt").read_bytes()

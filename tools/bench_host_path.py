@@ -17,6 +17,7 @@ depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
 q = rng.normal(size=(F, 4))
 t = rng.normal(size=(F, 3)) * 10
 ctx = r3d.Context(0)
+t0 = time.perf_counter(); tab = r3d.pose_table(q, t); print("pose_table (host, %d frames): %.2f ms" % (F, (time.perf_counter() - t0) * 1e3))
 for dt in (np.float32, np.float64):
     for rep in range(4):
         t0 = time.perf_counter()
@@ -24,6 +25,13 @@ for dt in (np.float32, np.float64):
         dt_s = time.perf_counter() - t0
         print("%s rep %d: %.1f ms  %.2f Gpoints/s  (D2H-equivalent %.1f GB/s)" % (np.dtype(dt).name, rep, dt_s * 1e3,
               F * H * W / dt_s / 1e9, out.nbytes / dt_s / 1e9))
+    pre = np.zeros((F * H * W, 3), dt)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        r3d.fuse_frames(depth, q, t, out_dtype=dt, ctx=ctx, out=pre)
+        dt_s = time.perf_counter() - t0
+        print("%s pageable pre-touched out rep %d: %.1f ms  %.2f Gpoints/s  (%.1f GB/s)" % (np.dtype(dt).name, rep,
+              dt_s * 1e3, F * H * W / dt_s / 1e9, pre.nbytes / dt_s / 1e9))
     if hasattr(ctx, "pinned_empty"):
         pin = ctx.pinned_empty((F * H * W, 3), dt)
         for rep in range(3):
