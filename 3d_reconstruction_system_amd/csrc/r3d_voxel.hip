@@ -3,7 +3,7 @@
 // Replaces the per-point `tree.updateNode(xyz, True)` loop, `updateInnerOccupancy()` and
 // `writeBinary()` of octomap/txt_transfer_octomap.py:16-36 (== octomap/ply_transfer_octomap.py:16-48).
 // The arithmetic of that path lives in the third-party OctoMap library (not vendored, not pinned by the
-// reference): restated from its published semantics, parity unpinned (oracle/octomap_ref.py).
+// reference): restated from its published semantics; parity unpinned.
 //
 // A hits-only tree written with writeBinary() depends only on the SET of voxels that received a point
 // (toMaxLikelihood makes every hit leaf "occupied"), so the GPU's job is a set insert:
