@@ -16,6 +16,7 @@
 // The host sorts the (much smaller) unique list and emits the pruned octree depth-first: a child subtree
 // is a pruned leaf exactly when its code range holds 8^(levels below) codes.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <string>
 #include <thread>
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
                                                                 unsigned long long* __restrict__ counters) {
   const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
   const int lane = threadIdx.x & 63;
+  // statistics stay in registers and reach the three global counters once per wave: a per-insert
+  // atomicAdd on one word would cap the kernel at that word's ~0.09 G atomics/s
+  unsigned n_new = 0, n_ignored = 0, n_over = 0;
   const int64_t n_tiles = (n + kThreads * 4 - 1) / (kThreads * 4);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t base = tile * (kThreads * 4) + threadIdx.x;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       uint64_t code = kEmpty;
       bool live = i < n;
       if (live && !voxel_code(p[r], factor, &code)) {
-        atomicAdd(&counters[1], 1ull);
+        ++n_ignored;
         live = false;
         code = kEmpty;
       }
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
           const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
                                          (unsigned long long)code);
           if (old == kEmpty) {
-            atomicAdd(&counters[0], 1ull);
+            ++n_new;
             done = true;
           } else if (old == code) {
             done = true;
@@ -107,18 +111,38 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
             slot = (slot + 1) & mask;
           }
         }
-        if (!done) atomicAdd(&counters[2], 1ull);
+        if (!done) ++n_over;
       }
     }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_ignored += __shfl_down(n_ignored, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  if (lane == 0) {
+    if (n_new) atomicAdd(&counters[0], (unsigned long long)n_new);
+    if (n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);
+    if (n_over) atomicAdd(&counters[2], (unsigned long long)n_over);
   }
 }
 
 __global__ __launch_bounds__(kThreads) void voxel_compact_kernel(const uint64_t* __restrict__ table, uint64_t capacity,
                                                                  uint64_t* __restrict__ out,
                                                                  unsigned long long* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  // capacity is a power of two >= 1024: every wave runs the same number of full iterations
   for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * kThreads) {
     const uint64_t v = table[i];
-    if (v != kEmpty) out[atomicAdd(&counters[3], 1ull)] = v;
+    const bool hit = v != kEmpty;
+    const unsigned long long ballot = __ballot(hit);
+    if (ballot) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&counters[3], (unsigned long long)__popcll(ballot));  // one cursor bump per wave
+      base = __shfl(base, 0, 64);
+      if (hit) out[base + __popcll(ballot & ((1ull << lane) - 1))] = v;
+    }
   }
 }
 
@@ -160,7 +184,8 @@ struct BtWriter {
     return levels <= 20 && count == ((int64_t)1 << (3 * levels));
   }
 
-  void node(int64_t lo, int64_t hi, int depth) {
+  // one node record: child boundaries, the two mask bytes, and which children are inner nodes
+  int record(int64_t lo, int64_t hi, int depth, int64_t inner[8][2]) {
     ++n_nodes;
     const int shift = 3 * (kDepth - 1 - depth);
     int64_t bounds[9];
@@ -172,7 +197,6 @@ struct BtWriter {
       bounds[c] = first - codes;
     }
     unsigned char b[2] = {0, 0};
-    int64_t inner[8][2];
     int n_inner = 0;
     for (int c = 0; c < 8; ++c) {
       const int64_t clo = bounds[c], chi = bounds[c + 1];
@@ -189,9 +213,83 @@ struct BtWriter {
     }
     body.push_back((char)b[0]);
     body.push_back((char)b[1]);
+    return n_inner;
+  }
+
+  void node(int64_t lo, int64_t hi, int depth) {
+    int64_t inner[8][2];
+    const int n_inner = record(lo, hi, depth, inner);
     for (int k = 0; k < n_inner; ++k) node(inner[k][0], inner[k][1], depth + 1);
   }
 };
+
+// Depth-first order means a subtree's bytes are one contiguous run: the subtrees hanging below `split_depth`
+// are serialised by worker threads and spliced in order.
+void build_parallel(const uint64_t* codes, int64_t n, std::string* body, int64_t* n_nodes) {
+  constexpr int kSplitDepth = 3;  // up to 512 independent subtrees
+  struct Piece {
+    bool is_task;
+    int64_t lo, hi;
+    std::string bytes;
+    int64_t nodes = 0;
+  };
+  std::vector<Piece> pieces;
+  BtWriter top;
+  top.codes = codes;
+  // walk the top levels sequentially; every inner child at kSplitDepth becomes a task
+  struct Frame {
+    int64_t lo, hi;
+    int depth;
+  };
+  std::vector<Frame> stack;
+  stack.push_back({0, n, 0});
+  while (!stack.empty()) {
+    const Frame f = stack.back();
+    stack.pop_back();
+    if (f.depth >= kSplitDepth || f.hi - f.lo < 4096) {
+      if (!top.body.empty()) {
+        pieces.push_back({false, 0, 0, std::move(top.body), 0});
+        top.body.clear();
+      }
+      pieces.push_back({true, f.lo, f.hi, std::string(), 0});
+      pieces.back().nodes = f.depth;  // stash the depth until the worker overwrites it
+      continue;
+    }
+    int64_t inner[8][2];
+    const int n_inner = top.record(f.lo, f.hi, f.depth, inner);
+    for (int k = n_inner - 1; k >= 0; --k) stack.push_back({inner[k][0], inner[k][1], f.depth + 1});  // DFS order
+  }
+  if (!top.body.empty()) pieces.push_back({false, 0, 0, std::move(top.body), 0});
+  unsigned hw = std::thread::hardware_concurrency();
+  const unsigned n_workers = std::max(1u, std::min(hw == 0 ? 1u : hw, 32u));
+  std::vector<std::thread> pool;
+  std::atomic<size_t> next{0};
+  for (unsigned w = 0; w < n_workers; ++w)
+    pool.emplace_back([&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= pieces.size()) return;
+        Piece& p = pieces[i];
+        if (!p.is_task) continue;
+        BtWriter sub;
+        sub.codes = codes;
+        sub.node(p.lo, p.hi, (int)p.nodes);
+        p.bytes = std::move(sub.body);
+        p.nodes = sub.n_nodes;
+      }
+    });
+  for (auto& t : pool) t.join();
+  size_t total = 0;
+  int64_t nodes = top.n_nodes;
+  for (const auto& p : pieces) {
+    total += p.bytes.size();
+    if (p.is_task) nodes += p.nodes;
+  }
+  body->clear();
+  body->reserve(total);
+  for (const auto& p : pieces) body->append(p.bytes);
+  *n_nodes = nodes;
+}
 
 int build_bt(const uint64_t* codes, int64_t n, double res, std::string* out, int64_t* n_nodes) {
   for (int64_t i = 1; i < n; ++i)
@@ -203,14 +301,16 @@ int build_bt(const uint64_t* codes, int64_t n, double res, std::string* out, int
     r3d_set_error("Morton code above 48 bits");
     return R3D_ERR_INVALID;
   }
-  BtWriter w;
-  w.codes = codes;
+  struct {
+    std::string body;
+    int64_t n_nodes = 0;
+  } w;
   if (n > 0) {
     if (BtWriter::full(n, 0)) {
       w.n_nodes = 1;
       w.body.assign(2, '\0');
     } else {
-      w.node(0, n, 0);
+      build_parallel(codes, n, &w.body, &w.n_nodes);
     }
   }
   char head[256];
