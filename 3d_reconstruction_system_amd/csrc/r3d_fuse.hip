@@ -42,6 +42,8 @@ struct FuseDims {
   uint32_t n_frames;
   uint32_t w_magic;         // floor(x / width) = (x * w_magic) >> w_shift for x < 2^31 (make_magic)
   uint32_t w_shift;
+  uint32_t w_shift32;       // w_shift - 32: j = umulhi(p, w_magic) >> w_shift32 when width >= 2
+  uint32_t width_is_one;    // width == 1 has w_shift == 31: every pixel is its own row
   uint32_t t_magic;         // floor(tile / tiles_per_frame), same scheme
   uint32_t t_shift;
   uint32_t total_tiles;     // tiles_per_frame * n_frames (< 2^31)
@@ -349,10 +351,69 @@ struct Xyz3<double> {
   }
 };
 
-template <typename DT, typename OT, bool POSE, int MODE>
-__global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
+// VARIANT 6 (A/B): one tile of the lane-per-pixel kernel with batched loads.  WHOLE = all 1024 pixels exist: straight-line code with every load of
+// the tile (4 depth elements, 4 u, 4 v) in flight before the first use.  Otherwise each pixel is predicated.
+// SCALE1: depth_scale == 1.0 (the reference's case) skips the multiply -- x*1.0 is exact, so results are identical.
+template <typename DT, typename OT, bool POSE, int MODE, bool SCALE1, bool WHOLE>
+__device__ __forceinline__ void lane_tile(const DT* __restrict__ dptr, OT* __restrict__ optr, const double* __restrict__ u,
+                                          const double* __restrict__ v, const Pose& P, const FuseDims& dm, uint32_t px0,
+                                          uint32_t tid) {
+  DT raw[kPx];
+  double uu[kPx], vv[kPx];
+  bool live[kPx];
+#pragma unroll
+  for (int r = 0; r < kPx; ++r) {
+    const uint32_t l = r * kThreads + tid;  // pixel within the tile: a 32-bit lane offset from a scalar base
+    const uint32_t p = px0 + l;
+    live[r] = WHOLE || p < dm.hw;
+    const uint32_t pc = live[r] ? p : px0;  // clamp: dead lanes read a valid element and store nothing
+    const uint32_t j = dm.width_is_one ? pc : (__umulhi(pc, dm.w_magic) >> dm.w_shift32);
+    const uint32_t i = pc - j * dm.width;
+    raw[r] = dptr[pc - px0];
+    uu[r] = u[i];
+    vv[r] = v[j];
+  }
+#pragma unroll
+  for (int r = 0; r < kPx; ++r) {
+    const uint32_t l = r * kThreads + tid;
+    double z = (double)raw[r];
+    if (!SCALE1) z *= dm.scale;
+    double w[3];
+    point<POSE>(z, uu[r], vv[r], P, w);
+    if (live[r]) Xyz3<OT>::template store<MODE>(optr + l * 3, w);
+  }
+}
+
+template <typename DT, typename OT, bool POSE, int MODE, bool SCALE1>
+__global__ __launch_bounds__(kThreads) void fuse_lane_batched_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
                                                              const double* __restrict__ u, const double* __restrict__ v,
                                                              const double* __restrict__ pose, const FuseDims dm) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
+    // wave-uniform part (scalar unit): which frame, where the tile starts, its base addresses
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
+    const uint32_t px0 = tf * kTile;
+    const uint64_t gbase = (uint64_t)frame * dm.hw + px0;
+    const DT* __restrict__ dptr = depth + gbase;
+    OT* __restrict__ optr = out + gbase * 3;
+    Pose P;
+    load_pose<POSE>(pose, frame, P);
+    if (px0 + kTile <= dm.hw)
+      lane_tile<DT, OT, POSE, MODE, SCALE1, true>(dptr, optr, u, v, P, dm, px0, tid);
+    else
+      lane_tile<DT, OT, POSE, MODE, SCALE1, false>(dptr, optr, u, v, P, dm, px0, tid);
+  }
+}
+
+// VARIANT 5 (default for f32 xyz): lane-per-pixel rounds, per-pixel predicates.  Measured fastest of the three
+// lane-per-pixel forms in interleaved same-process rounds (profiles/variants_r01.md): 0.093 ms vs 0.097 (scalar
+// bases, variant 7) vs 0.101-0.106 (all 12 loads of a tile batched up front, variant 6) -- fewer instructions
+// did NOT help; the store stream's cadence did.
+template <typename DT, typename OT, bool POSE, int MODE>
+__global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
+                                                                const double* __restrict__ u, const double* __restrict__ v,
+                                                                const double* __restrict__ pose, const FuseDims dm) {
   const uint32_t tid = threadIdx.x;
   for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
     const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
@@ -380,6 +441,45 @@ __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restric
   }
 }
 
+// VARIANT 7 (A/B): variant 5's per-pixel structure with the cheap scalar/integer savings only --
+// scalar tile bases + 32-bit lane offsets, umulhi row split, no scale multiply when depth_scale == 1.
+template <typename DT, typename OT, bool POSE, int MODE, bool SCALE1>
+__global__ __launch_bounds__(kThreads) void fuse_lane_sbase_kernel(const DT* __restrict__ depth, OT* __restrict__ out,
+                                                                const double* __restrict__ u, const double* __restrict__ v,
+                                                                const double* __restrict__ pose, const FuseDims dm) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
+    const uint32_t px0 = tf * kTile;
+    const uint64_t gbase = (uint64_t)frame * dm.hw + px0;
+    const DT* __restrict__ dptr = depth + gbase;
+    OT* __restrict__ optr = out + gbase * 3;
+    Pose P;
+    load_pose<POSE>(pose, frame, P);
+    DT raw[kPx];
+#pragma unroll
+    for (int r = 0; r < kPx; ++r) {
+      const uint32_t l = r * kThreads + tid;
+      raw[r] = px0 + l < dm.hw ? dptr[l] : DT(0);
+    }
+#pragma unroll
+    for (int r = 0; r < kPx; ++r) {
+      const uint32_t l = r * kThreads + tid;
+      const uint32_t p = px0 + l;
+      if (p < dm.hw) {
+        const uint32_t j = dm.width_is_one ? p : (__umulhi(p, dm.w_magic) >> dm.w_shift32);
+        const uint32_t i = p - j * dm.width;
+        double z = (double)raw[r];
+        if (!SCALE1) z *= dm.scale;
+        double w[3];
+        point<POSE>(z, u[i], v[j], P, w);
+        Xyz3<OT>::template store<MODE>(optr + l * 3, w);
+      }
+    }
+  }
+}
+
 struct FusePtrs {
   const void* depth;
   void* out;
@@ -400,6 +500,16 @@ void launch_one(const FusePtrs& p, const FuseDims& dm, int blocks, hipStream_t s
 
 template <typename DT, typename OT, bool POSE, int MODE>
 void launch_lane(const FusePtrs& p, const FuseDims& dm, int blocks, hipStream_t s) {
+  if (dm.scale == 1.0)
+    hipLaunchKernelGGL((fuse_lane_batched_kernel<DT, OT, POSE, MODE, true>), dim3(blocks), dim3(kThreads), 0, s,
+                       static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
+  else
+    hipLaunchKernelGGL((fuse_lane_batched_kernel<DT, OT, POSE, MODE, false>), dim3(blocks), dim3(kThreads), 0, s,
+                       static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
+}
+
+template <typename DT, typename OT, bool POSE, int MODE>
+void launch_lane_orig(const FusePtrs& p, const FuseDims& dm, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((fuse_lane_kernel<DT, OT, POSE, MODE>), dim3(blocks), dim3(kThreads), 0, s,
                      static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
 }
@@ -407,12 +517,25 @@ void launch_lane(const FusePtrs& p, const FuseDims& dm, int blocks, hipStream_t 
 template <typename DT, typename OT, bool POSE>
 void launch_variant(const FusePtrs& p, const FuseDims& dm, int variant, int blocks, int ntmode, hipStream_t s) {
   const bool nt = ntmode != 0;
+  if (variant == 7) {
+    if (dm.scale == 1.0)
+      hipLaunchKernelGGL((fuse_lane_sbase_kernel<DT, OT, POSE, 3, true>), dim3(blocks), dim3(kThreads), 0, s,
+                         static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
+    else
+      hipLaunchKernelGGL((fuse_lane_sbase_kernel<DT, OT, POSE, 3, false>), dim3(blocks), dim3(kThreads), 0, s,
+                         static_cast<const DT*>(p.depth), static_cast<OT*>(p.out), p.u, p.v, p.pose, dm);
+    return;
+  }
+  if (variant == 6) {
+    launch_lane<DT, OT, POSE, 3>(p, dm, blocks, s);
+    return;
+  }
   if (variant == 5) {
     switch (ntmode) {
-      case 0: launch_lane<DT, OT, POSE, 0>(p, dm, blocks, s); break;
-      case 2: launch_lane<DT, OT, POSE, 2>(p, dm, blocks, s); break;
-      case 3: launch_lane<DT, OT, POSE, 3>(p, dm, blocks, s); break;
-      default: launch_lane<DT, OT, POSE, 1>(p, dm, blocks, s); break;
+      case 0: launch_lane_orig<DT, OT, POSE, 0>(p, dm, blocks, s); break;
+      case 2: launch_lane_orig<DT, OT, POSE, 2>(p, dm, blocks, s); break;
+      case 1: launch_lane_orig<DT, OT, POSE, 1>(p, dm, blocks, s); break;
+      default: launch_lane_orig<DT, OT, POSE, 3>(p, dm, blocks, s); break;
     }
     return;
   }
@@ -469,10 +592,22 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   const size_t dsz = r3d_depth_size(depth_dtype);
   const bool vec_ok = (cam->width % 4 == 0) && (((uintptr_t)d_depth % (4 * dsz)) == 0) && (((uintptr_t)d_out % 16) == 0);
   int variant = ctx->fuse_variant;
-  if (variant < 1 || variant > 5) variant = 5;  // measured best on MI355X (profiles/variants_r01.md)
-  if (!vec_ok && variant != 5) variant = 1;
   int ntmode = ctx->nontemporal;
-  if (ctx->fuse_variant == 0) ntmode = 3;      // auto: lane-per-pixel kernel with one nontemporal x3 store
+  bool one_tile_per_block = false;
+  if (variant < 1 || variant > 7) {
+    // auto, from the A/B in profiles/variants_r01.md: f32 xyz -> lane-per-pixel kernel with one nontemporal
+    // 12-byte store per lane (6.6-7.0 TB/s); f64 xyz -> 24-byte lane stride does not combine, the
+    // LDS-transposed 16-byte-store kernel at one tile per workgroup wins (5.4 vs 2.7 TB/s)
+    if (out_dtype == R3D_F64 && vec_ok) {
+      variant = 3;
+      ntmode = 0;
+      one_tile_per_block = true;
+    } else {
+      variant = 5;
+      ntmode = 3;
+    }
+  }
+  if (!vec_ok && variant < 5) variant = 1;
   const uint32_t tile = variant == 4 ? kWaveTile : kTile;
   FusePtrs p{d_depth, d_out, cam->d_u, cam->d_v, with_pose ? d_pose : nullptr};
   FuseDims dm;
@@ -482,13 +617,16 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   dm.tiles_per_frame = (uint32_t)((hw + tile - 1) / tile);
   dm.n_frames = (uint32_t)n_frames;
   make_magic(dm.width, &dm.w_magic, &dm.w_shift);
+  dm.width_is_one = dm.width == 1;
+  dm.w_shift32 = dm.width_is_one ? 0 : dm.w_shift - 32;
   make_magic(dm.tiles_per_frame, &dm.t_magic, &dm.t_shift);
   const uint64_t total_tiles = (uint64_t)dm.tiles_per_frame * n_frames;
   R3D_REQUIRE(total_tiles < ((uint64_t)1 << 31), "batch too large for one launch (%llu tiles); split the frames",
               (unsigned long long)total_tiles);
   dm.total_tiles = (uint32_t)total_tiles;
   const uint64_t tiles_per_block = variant == 4 ? kThreads / 64 : 1;
-  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : (uint64_t)ctx->num_cus * 8;
+  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks
+                                         : one_tile_per_block ? ~(uint64_t)0 : (uint64_t)ctx->num_cus * 8;
   const uint64_t max_blocks = (total_tiles + tiles_per_block - 1) / tiles_per_block;
   if (blocks > max_blocks) blocks = max_blocks;
   if (with_pose)

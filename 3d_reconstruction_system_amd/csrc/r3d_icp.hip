@@ -202,12 +202,20 @@ __global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __res
   }
 }
 
-__global__ void accumulate_final_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ sums) {
-  if (threadIdx.x < kSums) {
-    double v = 0.0;
-    for (int b = 0; b < n_blocks; ++b) v += partials[(int64_t)b * kSums + threadIdx.x];
-    sums[threadIdx.x] = v;
+// One workgroup per sum: 256 lanes stride over the per-workgroup partials in a fixed order, then a fixed LDS tree.
+__global__ __launch_bounds__(kThreads) void accumulate_final_kernel(const double* __restrict__ partials, int n_blocks,
+                                                                    double* __restrict__ sums) {
+  __shared__ double red[kThreads];
+  const int k = blockIdx.x;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < n_blocks; b += kThreads) v += partials[(int64_t)b * kSums + k];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int half = kThreads / 2; half > 0; half >>= 1) {
+    if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) sums[k] = red[0];
 }
 
 }  // namespace
@@ -309,7 +317,7 @@ int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const fl
   double* d_sums = d_part + (size_t)blocks * kSums;
   hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx,
                      gated ? d_d2 : nullptr, max_d2, d_part);
-  hipLaunchKernelGGL(accumulate_final_kernel, dim3(1), dim3(64), 0, ctx->stream, d_part, blocks, d_sums);
+  hipLaunchKernelGGL(accumulate_final_kernel, dim3(kSums), dim3(kThreads), 0, ctx->stream, d_part, blocks, d_sums);
   R3D_HIP(hipGetLastError());
   R3D_HIP(hipMemcpyAsync(h_sums, d_sums, kSums * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   R3D_HIP(hipStreamSynchronize(ctx->stream));

@@ -66,8 +66,11 @@ int r3d_ctx_create(int device, void* stream, int flags, r3d_ctx** ctx_out);
 int r3d_ctx_destroy(r3d_ctx* ctx);
 int r3d_ctx_sync(r3d_ctx* ctx);
 int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
-/* tuning knobs (integers): "fuse_variant" {0 auto,1 scalar,2 vec4 direct,3 vec4 LDS-transposed},
- * "fuse_blocks" (grid cap, 0 = auto), "nontemporal" {0,1}, "nn_variant". Unknown key -> R3D_ERR_INVALID. */
+/* tuning knobs (integers; 0 = auto everywhere): "fuse_variant" {1 scalar any-width, 2 vec4 direct stores, 3 LDS-tile
+ * 16-B stores, 4 LDS-wave, 5 lane-per-pixel (default for f32 xyz), 6 lane-per-pixel with batched loads, 7 lane-per-pixel
+ * with scalar bases}, "nontemporal" (store mode of variant 5: 0 x3, 1 3 x nt scalar, 2 3 x scalar, 3 nt x3), "fuse_blocks",
+ * "apply_variant" {0 lane-per-point, 1 LDS-tile}, "apply_blocks", "nn_variant" (sources per lane 1/2/4), "nn_blocks".
+ * Every variant of a kernel produces bit-identical results.  Unknown key -> R3D_ERR_INVALID. */
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);
 int r3d_ctx_get_tuning(r3d_ctx* ctx, const char* key, int* value_out);
 

@@ -79,7 +79,7 @@ def test_variants_bitwise_equal(R, ctx, shape, odtype):
     q = rng.normal(size=(shape[0], 4))
     t = rng.normal(size=(shape[0], 3)) * 10
     outs = []
-    for variant in (1, 2, 3, 4, 5):
+    for variant in (1, 2, 3, 4, 5, 6, 7):
         for nt in ((0, 1, 2, 3) if variant == 5 else (0, 1)):
             ctx.set_tuning("fuse_variant", variant)
             ctx.set_tuning("nontemporal", nt)
