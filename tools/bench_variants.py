@@ -33,9 +33,9 @@ def bench_fuse(ctx, F, H, W, rounds, iters, odt=np.float32):
     d_out = ctx.alloc(n * 3 * osz)
     cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
     configs = []
-    for variant in (5, 6, 7):
+    for variant in (3, 5, 6, 7):
         for nt in (3,):
-            for blocks in (2048, 4096):
+            for blocks in (2048,):
 
                 configs.append((variant, nt, blocks))
     results = {c: [] for c in configs}
