@@ -1,0 +1,18 @@
+"""CPU: include/r3d.h is valid C99 on its own and a C consumer links against libr3d_hip.so (it runs only as far
+as the no-GPU exit here; the GPU run is tests/test_gpu_c_consumer.py)."""
+import os
+import subprocess
+
+from helpers import PKG, ROOT
+
+
+def test_header_compiles_as_c99_and_consumer_links(tmp_path):
+    exe = str(tmp_path / "cabi_smoke")
+    libdir = os.path.join(ROOT, PKG)
+    build = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c", "cabi_smoke.c"), "-o", exe, "-L", libdir, "-lr3d_hip", "-lm",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode in (0, 77), run.stdout + run.stderr      # 77 = no GPU visible: clean skip, no crash
+    assert "r3d version 100" in run.stdout
