@@ -77,6 +77,7 @@ SIGNATURES = {
     "r3d_voxelset_insert_host": (_i, [_vp, _vp, _i64]),
     "r3d_voxelset_stats": (_i, [_vp, _vp, _vp, _vp]),
     "r3d_voxelset_codes": (_i, [_vp, _vp, _i64, _vp]),
+    "r3d_sort_u64": (_i, [_vp, _vp, _i64, _i]),
     "r3d_octree_format_bt": (_i, [_vp, _i64, _d, _vp, _sz, _psz, _vp]),
     "r3d_octree_write_bt": (_i, [C.c_char_p, _vp, _i64, _d, _vp]),
 }

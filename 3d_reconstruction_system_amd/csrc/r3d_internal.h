@@ -73,5 +73,8 @@ int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p);
 int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
                       void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch);
 
+// Stable LSD radix sort of 64-bit keys by their low `bits` bits (r3d_sort.hip); d_tmp holds n keys.
+int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits);
+
 static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
 static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

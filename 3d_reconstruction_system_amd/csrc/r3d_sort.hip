@@ -1,0 +1,168 @@
+// LSD radix sort of 64-bit keys in HBM for gfx950 (MI355X): 8-bit digits, stable, three kernels per pass.
+//
+// Used by the voxel path (csrc/r3d_voxel.hip) to put the distinct 48-bit Morton codes in octree order on the
+// GPU instead of on the host.  HBM-bound: per pass 8 B/key read for the histogram, 8 B read + 8 B written by the
+// scatter = 24 B/key/pass; 6 passes cover 48 bits.
+//
+//   digit_histogram_kernel  tile of 4096 keys per workgroup -> 256-bin LDS histogram -> hist[bin][workgroup]
+//   digit_scan_kernel       one wave per bin: exclusive prefix over workgroups (wave shuffle scan), bin totals;
+//                           a final single-wave pass turns totals into bin bases
+//   digit_scatter_kernel    re-reads the tile in 16 rounds of 256 keys; inside a round every lane finds the lanes of
+//                           its wave with the same digit by 8 ballots, the rank among them by popcount, waves are
+//                           ordered through a [4][256] LDS count table; destination = bin base + workgroup prefix +
+//                           running count of earlier rounds + rank.  Order of equal digits is preserved (stable).
+#include "r3d_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRounds = 16;
+constexpr int kTile = kThreads * kRounds;  // keys per workgroup
+constexpr int kBins = 256;
+
+__global__ __launch_bounds__(kThreads) void digit_histogram_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                                   uint32_t* __restrict__ hist, int n_blocks) {
+  __shared__ uint32_t bins[kBins];
+  bins[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+#pragma unroll 4
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = base + r * kThreads + threadIdx.x;
+    if (i < n) atomicAdd(&bins[(keys[i] >> shift) & 0xff], 1u);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x] = bins[threadIdx.x];
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// grid = kBins workgroups of one wave: bin b's counts over the workgroups become exclusive prefixes in place
+__global__ __launch_bounds__(64) void digit_scan_kernel(uint32_t* __restrict__ hist, int n_blocks, uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x;
+  uint32_t* row = hist + (int64_t)blockIdx.x * n_blocks;
+  uint32_t running = 0;
+  for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+    const int b = b0 + lane;
+    const uint32_t v = b < n_blocks ? row[b] : 0;
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    if (b < n_blocks) row[b] = running + inc - v;
+    running += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) totals[blockIdx.x] = running;
+}
+
+// one wave: totals[256] -> exclusive bases[256]
+__global__ __launch_bounds__(64) void bin_base_kernel(const uint32_t* __restrict__ totals, uint64_t* __restrict__ bases) {
+  const int lane = threadIdx.x;
+  uint64_t running = 0;
+  for (int b0 = 0; b0 < kBins; b0 += 64) {
+    const uint32_t v = totals[b0 + lane];
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    bases[b0 + lane] = running + inc - v;
+    running += __shfl(inc, 63, 64);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                                 const uint32_t* __restrict__ hist, int n_blocks,
+                                                                 const uint64_t* __restrict__ bases,
+                                                                 uint64_t* __restrict__ out) {
+  __shared__ uint64_t dest[kBins];                // next free output slot of every bin for this workgroup
+  __shared__ uint32_t cnt[kThreads / 64][kBins];  // per-wave digit counts of the current round
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  dest[threadIdx.x] = bases[threadIdx.x] + hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = base + r * kThreads + threadIdx.x;
+    const bool live = i < n;
+    const uint64_t key = live ? keys[i] : 0;
+    const uint32_t digit = (uint32_t)(key >> shift) & 0xff;
+    // lanes of this wave that hold the same digit (dead lanes match nobody)
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((digit >> b) & 1);
+      peers &= ((digit >> b) & 1) ? m : ~m;
+    }
+    const uint32_t rank = __popcll(peers & ((1ull << lane) - 1));
+    if (live && rank == 0) cnt[wave][digit] = __popcll(peers);  // the lowest peer lane publishes the wave's count
+    __syncthreads();
+    if (live) {
+      uint32_t before = 0;
+#pragma unroll
+      for (int w = 0; w < kThreads / 64; ++w) before += (w < wave) ? cnt[w][digit] : 0;
+      out[dest[digit] + before + rank] = key;
+    }
+    __syncthreads();
+    {
+      uint32_t total = 0;
+#pragma unroll
+      for (int w = 0; w < kThreads / 64; ++w) total += cnt[w][threadIdx.x];
+      dest[threadIdx.x] += total;
+    }
+    // the next round's zeroing of cnt is ordered behind this update by the barrier at its top
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// Sorts d_keys[0..n) ascending by their low `bits` bits (bits rounded up to a multiple of 8, <= 64).
+// d_tmp: scratch of n keys.  The result is in d_keys when the number of passes is even, else it is copied back.
+int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits) {
+  if (n <= 1) return R3D_OK;
+  const int passes = (bits + 7) / 8;
+  const int64_t n_blocks64 = (n + kTile - 1) / kTile;
+  R3D_REQUIRE(n_blocks64 < ((int64_t)1 << 31), "too many keys for one sort");
+  const int n_blocks = (int)n_blocks64;
+  void* ws = nullptr;
+  const size_t hist_bytes = (size_t)kBins * n_blocks * sizeof(uint32_t);
+  int rc = r3d_scratch(ctx, 3, hist_bytes + kBins * sizeof(uint32_t) + kBins * sizeof(uint64_t) + 64, &ws);
+  if (rc) return rc;
+  uint32_t* hist = static_cast<uint32_t*>(ws);
+  uint64_t* bases = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + ((hist_bytes + 15) & ~(size_t)15));
+  uint32_t* totals = reinterpret_cast<uint32_t*>(bases + kBins);
+  uint64_t* src = d_keys;
+  uint64_t* dst = d_tmp;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(64), 0, ctx->stream, hist, n_blocks, totals);
+    hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, ctx->stream, totals, bases);
+    hipLaunchKernelGGL(digit_scatter_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks,
+                       bases, dst);
+    uint64_t* t = src;
+    src = dst;
+    dst = t;
+  }
+  R3D_HIP(hipGetLastError());
+  if (src != d_keys) R3D_HIP(hipMemcpyAsync(d_keys, src, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  return R3D_OK;
+}
+
+extern "C" {
+
+int r3d_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, int64_t n_keys, int key_bits) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_keys >= 0, "n_keys must be >= 0");
+  R3D_REQUIRE(key_bits >= 1 && key_bits <= 64, "key_bits must be in [1,64]");
+  if (n_keys <= 1) return R3D_OK;
+  R3D_REQUIRE(d_keys != nullptr, "NULL device pointer");
+  void* tmp = nullptr;
+  if ((rc = r3d_scratch(ctx, 2, (size_t)n_keys * sizeof(uint64_t), &tmp))) return rc;
+  return r3d_radix_sort_u64(ctx, d_keys, static_cast<uint64_t*>(tmp), n_keys, key_bits);
+}
+
+}  // extern "C"

@@ -13,8 +13,8 @@
 //     lane holds the same code drop out, the rest go into an open-addressing hash set in HBM
 //     (64-bit atomicCAS, multiplicative hash, linear probing).
 //   * voxel_compact_kernel: table -> dense list of codes.
-// The host sorts the (much smaller) unique list and emits the pruned octree depth-first: a child subtree
-// is a pruned leaf exactly when its code range holds 8^(levels below) codes.
+// The distinct codes are radix-sorted on the GPU (r3d_sort.hip); the host emits the pruned octree depth-first:
+// a child subtree is a pruned leaf exactly when its code range holds 8^(levels below) codes.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -143,31 +143,6 @@ __global__ __launch_bounds__(kThreads) void voxel_compact_kernel(const uint64_t*
       base = __shfl(base, 0, 64);
       if (hit) out[base + __popcll(ballot & ((1ull << lane) - 1))] = v;
     }
-  }
-}
-
-void parallel_sort(uint64_t* a, int64_t n) {
-  unsigned hw = std::thread::hardware_concurrency();
-  unsigned parts = 1;
-  while (parts * 2 <= std::min(hw == 0 ? 1u : hw, 16u) && n / (parts * 2) >= 65536) parts *= 2;
-  if (parts == 1) {
-    std::sort(a, a + n);
-    return;
-  }
-  std::vector<int64_t> cut(parts + 1);
-  for (unsigned p = 0; p <= parts; ++p) cut[p] = n * p / parts;
-  {
-    std::vector<std::thread> pool;
-    for (unsigned p = 0; p < parts; ++p) pool.emplace_back([=, &cut]() { std::sort(a + cut[p], a + cut[p + 1]); });
-    for (auto& t : pool) t.join();
-  }
-  for (unsigned width = 1; width < parts; width *= 2) {
-    std::vector<std::thread> pool;
-    for (unsigned p = 0; p + width < parts; p += 2 * width) {
-      const int64_t lo = cut[p], mid = cut[p + width], hi = cut[std::min(p + 2 * width, parts)];
-      pool.emplace_back([=]() { std::inplace_merge(a + lo, a + mid, a + hi); });
-    }
-    for (auto& t : pool) t.join();
   }
 }
 
@@ -435,8 +410,9 @@ int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, 
   if (!h_codes_sorted) return R3D_OK;
   R3D_REQUIRE(cap >= n, "buffer holds %lld codes, set has %lld", (long long)cap, (long long)n);
   if (n == 0) return R3D_OK;
-  void* d_list = nullptr;
+  void *d_list = nullptr, *d_tmp = nullptr;
   if ((rc = r3d_scratch(vs->ctx, 1, (size_t)n * sizeof(uint64_t), &d_list))) return rc;
+  if ((rc = r3d_scratch(vs->ctx, 2, (size_t)n * sizeof(uint64_t), &d_tmp))) return rc;
   R3D_HIP(hipMemsetAsync(vs->d_counters + 3, 0, sizeof(unsigned long long), vs->ctx->stream));
   int blocks = vs->ctx->num_cus * 8;
   const uint64_t need = (vs->capacity + kThreads - 1) / kThreads;
@@ -444,9 +420,10 @@ int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, 
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, vs->d_table, vs->capacity,
                      static_cast<uint64_t*>(d_list), vs->d_counters);
   R3D_HIP(hipGetLastError());
+  // octree order = ascending Morton code: 48 significant bits, six 8-bit passes on the GPU
+  if ((rc = r3d_radix_sort_u64(vs->ctx, static_cast<uint64_t*>(d_list), static_cast<uint64_t*>(d_tmp), n, 48))) return rc;
   R3D_HIP(hipMemcpyAsync(h_codes_sorted, d_list, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, vs->ctx->stream));
   R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
-  parallel_sort(h_codes_sorted, n);
   return R3D_OK;
 }
 

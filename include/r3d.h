@@ -184,6 +184,9 @@ int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, 
 /* distinct voxels as ascending 48-bit Morton codes (3 bits per level, x lowest: OctoMap's child index order).
  * h_codes_sorted == NULL only reports the count. */
 int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, int64_t* n_out);
+/* In-place ascending sort of 64-bit keys in HBM by their low key_bits bits (stable LSD radix sort, 8-bit digits;
+ * asynchronous on the ctx stream).  Building block of r3d_voxelset_codes, exported for tests and reuse. */
+int r3d_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, int64_t n_keys, int key_bits);
 /* OctoMap ".bt" bytes (header + pruned maximum-likelihood tree, depth first) for ascending unique codes. */
 int r3d_octree_format_bt(const uint64_t* h_codes_sorted, int64_t n_codes, double resolution, char* h_buf,
                          size_t buf_cap, size_t* n_bytes_out, int64_t* n_nodes_out);

@@ -125,3 +125,23 @@ def test_octomap_dropin_scripts(tmp_path, golden_dir):
     assert (tmp_path / "bt" / "p.bt").read_bytes() == OM.write_bt_bytes(OM.occupied_set(verts)[0])[0]
     run_script("other_tools/ply_transfer_octomap.py", str(tmp_path), ply, "bt/p2.bt")
     assert (tmp_path / "bt" / "p2.bt").read_bytes() == (tmp_path / "bt" / "p.bt").read_bytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 4095, 4096, 4097, 70001, 1500000])
+@pytest.mark.parametrize("bits", [48, 64, 20])
+def test_radix_sort_u64(ctx, n, bits):
+    import ctypes as C
+    L = importlib.import_module(PKG + "._lib")
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)
+    if bits < 64:
+        keys &= np.uint64((1 << bits) - 1)
+    if n > 10:
+        keys[n // 2:n // 2 + 5] = keys[0]                        # duplicates
+    buf = ctx.alloc(max(n * 8, 16))
+    if n:
+        buf.upload(keys)
+    L.check(ctx.lib.r3d_sort_u64(ctx.handle, buf.ptr, n, bits))
+    got = buf.download(np.uint64, n)
+    np.testing.assert_array_equal(got, np.sort(keys))
+    buf.free()
