@@ -1,0 +1,511 @@
+// Exact nearest neighbour with spatial culling for gfx950 (MI355X): the brute-force LDS-tiled sweep of
+// r3d_icp.hip, but over Morton-sorted clouds so that whole 1024-target tiles are skipped when their
+// bounding box is provably farther than the best distance found so far.
+//
+// NOT IN THE REFERENCE (ICP estimation is build-defined).  Results are identical to r3d_icp_nn:
+// the same fp32 expression d2 = fma(dz,dz,fma(dy,dy,dx*dx)) decides, lowest ORIGINAL target index wins exact ties.
+//
+//   build (once per target cloud):  bounding box -> 64-bit keys (Morton code of the quantised point | index) ->
+//       GPU radix sort (r3d_sort.hip) -> targets gathered in key order as float4 (x,y,z,original index) ->
+//       per-tile bounding boxes (tile = 1024 consecutive sorted targets) and first Morton code of every tile.
+//   query:  sources get the same keys and sort, so a workgroup's 256*S sources are spatially compact.  The
+//       workgroup starts at the tile whose Morton range contains its first source and walks outward
+//       (t0, t0+1, t0-1, ...).  Per tile every lane computes a lower bound of its distance to the tile's box;
+//       the tile is loaded into LDS and swept only if some lane of the workgroup could still improve
+//       (bound * (1 - 16u) <= best).  The sweep is the r3d_icp.hip inner loop: 6 VALU + 1/2 min3 per pair,
+//       minimum tracked per group of 32 sorted targets.
+//   resolve: the winning group is re-evaluated exactly; equal distances pick the lowest original index.  A source
+//       that saw the SAME minimum in two different groups (an exact tie across groups) is handed to a small exact
+//       fallback kernel that scans all targets in original order.
+#include <cmath>
+
+#include "r3d_internal.h"
+
+struct r3d_nn_index {
+  r3d_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int64_t n_tiles = 0;
+  int idx_bits = 1, axis_bits = 16;
+  float* d_tgt = nullptr;      // [n][3] original order (fallback scan)
+  float4* d_tgt4 = nullptr;    // [n_tiles*1024] sorted, w = original index bits; padding has x = +inf
+  float* d_tile_box = nullptr; // [n_tiles][6] lo xyz, hi xyz
+  float* d_sub_box = nullptr;  // [n_tiles*4][6] boxes of the 256-target quarters of every tile
+  uint64_t* d_tile_code = nullptr;  // [n_tiles] Morton code (without index bits) of the tile's first target
+  float* d_frame = nullptr;    // [8]: lo xyz, scale xyz, unused: quantisation frame shared by both clouds
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTile = 1024;
+constexpr int kGroup = 32;
+constexpr int kSub = 256;  // targets per sub-tile (wave-level culling inside a swept tile)
+constexpr float kShrink = 1.0f - 16.0f * 5.9604645e-8f;  // (1 - 16u): makes the box bound a strict lower bound
+
+struct __attribute__((packed, aligned(4))) P3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ int float_order(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float order_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// ---- build -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bbox_kernel(const float* __restrict__ xyz, int64_t n, int* __restrict__ box6) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const P3 p = reinterpret_cast<const P3*>(xyz)[i];
+    const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      if (isfinite(v[a])) {
+        lo[a] = fminf(lo[a], v[a]);
+        hi[a] = fmaxf(hi[a], v[a]);
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&box6[a], float_order(lo[a]));
+      atomicMax(&box6[3 + a], float_order(hi[a]));
+    }
+  }
+}
+
+__global__ void frame_kernel(const int* __restrict__ box6, int axis_bits, float* __restrict__ frame) {
+  if (threadIdx.x < 3) {
+    const float lo = order_float(box6[threadIdx.x]), hi = order_float(box6[3 + threadIdx.x]);
+    const float ext = hi - lo;
+    frame[threadIdx.x] = lo;
+    frame[3 + threadIdx.x] = (ext > 0.f && isfinite(ext)) ? (float)((1 << axis_bits) - 1) / ext : 0.f;
+  }
+}
+
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {
+  uint64_t x = v & 0xffffu;
+  x = (x | x << 16) & 0x0000ff0000ffull;
+  x = (x | x << 8) & 0x00f00f00f00full;
+  x = (x | x << 4) & 0x0c30c30c30c3ull;
+  x = (x | x << 2) & 0x249249249249ull;
+  return x;
+}
+
+__device__ __forceinline__ uint64_t point_code(const P3& p, const float* __restrict__ frame, int axis_bits) {
+  const float top = (float)((1 << axis_bits) - 1);
+  const float q[3] = {(p.x - frame[0]) * frame[3], (p.y - frame[1]) * frame[4], (p.z - frame[2]) * frame[5]};
+  uint32_t k[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) k[a] = (uint32_t)fminf(fmaxf(q[a], 0.f), top);  // NaN -> 0
+  return spread3(k[0]) | (spread3(k[1]) << 1) | (spread3(k[2]) << 2);
+}
+
+__global__ __launch_bounds__(kThreads) void keys_kernel(const float* __restrict__ xyz, int64_t n, const float* __restrict__ frame,
+                                                        int axis_bits, int idx_bits, uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const P3 p = reinterpret_cast<const P3*>(xyz)[i];
+  keys[i] = (point_code(p, frame, axis_bits) << idx_bits) | (uint64_t)i;
+}
+
+// sorted keys -> float4 (x, y, z, original index); slots past n are padded with x = +inf so they never win
+__global__ __launch_bounds__(kThreads) void gather4_kernel(const float* __restrict__ xyz, const uint64_t* __restrict__ keys,
+                                                           int64_t n, int64_t n_padded, int idx_bits, float4* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n_padded) return;
+  if (j < n) {
+    const uint32_t i = (uint32_t)(keys[j] & (((uint64_t)1 << idx_bits) - 1));
+    const P3 p = reinterpret_cast<const P3*>(xyz)[i];
+    out[j] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
+  } else {
+    out[j] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(0xffffffffu));
+  }
+}
+
+// one workgroup per tile: bounding box of its (finite) targets and the Morton code of its first target
+__global__ __launch_bounds__(kThreads) void tile_box_kernel(const float4* __restrict__ tgt4, const uint64_t* __restrict__ keys,
+                                                            int64_t n, int idx_bits, int span, float* __restrict__ tile_box,
+                                                            uint64_t* __restrict__ tile_code) {
+  __shared__ float red[6][kThreads / 64];
+  const int64_t base = (int64_t)blockIdx.x * span;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = threadIdx.x; k < span; k += kThreads) {
+    if (base + k < n) {
+      const float4 p = tgt4[base + k];
+      const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(lo[a], v[a]);  // fminf/fmaxf drop NaN operands
+        hi[a] = fmaxf(hi[a], v[a]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red[a][threadIdx.x >> 6] = lo[a];
+      red[3 + a][threadIdx.x >> 6] = hi[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[threadIdx.x][0];
+    for (int w = 1; w < kThreads / 64; ++w) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+    tile_box[(int64_t)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+  if (threadIdx.x == 0 && tile_code) tile_code[blockIdx.x] = keys[base] >> idx_bits;
+}
+
+// ---- query -------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(kThreads) void nn_cull_kernel(const float4* __restrict__ src4, int64_t n_src,
+                                                           const uint64_t* __restrict__ src_keys, int src_idx_bits,
+                                                           const float4* __restrict__ tgt4, int64_t n_tgt, int64_t n_tiles,
+                                                           const float* __restrict__ tile_box,
+                                                           const float* __restrict__ sub_box,
+                                                           const uint64_t* __restrict__ tile_code,
+                                                           uint32_t* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                           uint32_t* __restrict__ tie_list, unsigned* __restrict__ tie_count,
+                                                           unsigned long long* __restrict__ stats) {
+  __shared__ __attribute__((aligned(16))) float tx[kTile];
+  __shared__ __attribute__((aligned(16))) float ty[kTile];
+  __shared__ __attribute__((aligned(16))) float tz[kTile];
+  __shared__ int start_tile;
+
+  const uint32_t tid = threadIdx.x;
+  const int64_t s_base = (int64_t)blockIdx.x * (kThreads * S);
+  float sx[S], sy[S], sz[S], best[S];
+  uint32_t best_group[S];
+  bool tie[S], ok[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t i = s_base + (int64_t)s * kThreads + tid;
+    ok[s] = i < n_src;
+    const float4 p = ok[s] ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sx[s] = p.x; sy[s] = p.y; sz[s] = p.z;
+    best[s] = INFINITY;
+    best_group[s] = 0;
+    tie[s] = false;
+  }
+  if (tid == 0) {
+    // tile whose Morton range holds this workgroup's first source: last tile with first code <= code
+    const uint64_t code = src_keys[s_base] >> src_idx_bits;
+    int64_t lo = 0, hi = n_tiles;  // answer in [lo, hi)
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (tile_code[mid] <= code) lo = mid; else hi = mid;
+    }
+    start_tile = (int)lo;
+  }
+  __syncthreads();
+  const int64_t t0 = start_tile;
+  unsigned swept = 0;
+
+  // outward walk: t0, t0+1, t0-1, t0+2, ...
+  for (int64_t step = 0; step < 2 * n_tiles; ++step) {
+    const int64_t tile = (step & 1) ? t0 + ((step + 1) >> 1) : t0 - (step >> 1);
+    if (tile < 0 || tile >= n_tiles) continue;  // uniform
+    const float* box = tile_box + tile * 6;
+    const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
+    bool need = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float ex = fmaxf(fmaxf(blo[0] - sx[s], sx[s] - bhi[0]), 0.f);
+      const float ey = fmaxf(fmaxf(blo[1] - sy[s], sy[s] - bhi[1]), 0.f);
+      const float ez = fmaxf(fmaxf(blo[2] - sz[s], sz[s] - bhi[2]), 0.f);
+      const float lb = fmaf(ez, ez, fmaf(ey, ey, ex * ex)) * kShrink;
+      need |= ok[s] && !(lb > best[s]);  // NaN bounds never allow a skip
+    }
+    if (!__syncthreads_or(need)) continue;  // nobody in the workgroup can improve inside this tile
+    ++swept;
+    const int64_t t_base = tile * kTile;
+    for (uint32_t k = tid; k < kTile; k += kThreads) {
+      const float4 p = tgt4[t_base + k];
+      tx[k] = p.x; ty[k] = p.y; tz[k] = p.z;
+    }
+    __syncthreads();
+    if (__any(need)) {
+      const uint32_t group0 = (uint32_t)(t_base / kGroup);
+      for (int g = 0; g < kTile / kGroup; ++g) {
+        if ((g & (kSub / kGroup - 1)) == 0) {
+          // entering a 256-target quarter: the whole WAVE skips it when no lane can improve inside its box
+          const float* sb = sub_box + (tile * (kTile / kSub) + g / (kSub / kGroup)) * 6;
+          bool want = false;
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const float ex = fmaxf(fmaxf(sb[0] - sx[s], sx[s] - sb[3]), 0.f);
+            const float ey = fmaxf(fmaxf(sb[1] - sy[s], sy[s] - sb[4]), 0.f);
+            const float ez = fmaxf(fmaxf(sb[2] - sz[s], sz[s] - sb[5]), 0.f);
+            want |= ok[s] && !(fmaf(ez, ez, fmaf(ey, ey, ex * ex)) * kShrink > best[s]);
+          }
+          if (!__any(want)) {
+            g += kSub / kGroup - 1;
+            continue;
+          }
+        }
+        float gmin[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) gmin[s] = INFINITY;
+#pragma unroll
+        for (int q = 0; q < kGroup / 4; ++q) {
+          const float4 X = reinterpret_cast<const float4*>(tx)[g * (kGroup / 4) + q];
+          const float4 Y = reinterpret_cast<const float4*>(ty)[g * (kGroup / 4) + q];
+          const float4 Z = reinterpret_cast<const float4*>(tz)[g * (kGroup / 4) + q];
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            float dx, dy, dz;
+            dx = sx[s] - X.x; dy = sy[s] - Y.x; dz = sz[s] - Z.x;
+            const float d0 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            dx = sx[s] - X.y; dy = sy[s] - Y.y; dz = sz[s] - Z.y;
+            const float d1 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            dx = sx[s] - X.z; dy = sy[s] - Y.z; dz = sz[s] - Z.z;
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            dx = sx[s] - X.w; dy = sy[s] - Y.w; dz = sz[s] - Z.w;
+            const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            gmin[s] = fminf(fminf(gmin[s], d0), d1);
+            gmin[s] = fminf(fminf(gmin[s], d2), d3);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          if (gmin[s] < best[s]) {
+            best[s] = gmin[s];
+            best_group[s] = group0 + g;
+            tie[s] = false;
+          } else if (gmin[s] == best[s] && best_group[s] != group0 + g) {
+            tie[s] = true;  // the same minimum in another group: original-index order must decide
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // resolve inside the winning group: exact distance, lowest original index among equals
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t i = s_base + (int64_t)s * kThreads + tid;
+    if (!ok[s]) continue;
+    const uint32_t orig = __float_as_uint(src4[i].w);
+    const int64_t g0 = (int64_t)best_group[s] * kGroup;
+    uint32_t found = 0xffffffffu;
+    for (int k = 0; k < kGroup; ++k) {
+      const float4 p = tgt4[g0 + k];
+      const float dx = sx[s] - p.x, dy = sy[s] - p.y, dz = sz[s] - p.z;
+      const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      if (d == best[s]) found = min(found, __float_as_uint(p.w));
+    }
+    if (found == 0xffffffffu || tie[s]) {
+      // no finite distance at all (NaN input) or a cross-group tie: the exact fallback scans everything
+      tie_list[atomicAdd(tie_count, 1u)] = orig;
+    } else {
+      idx_out[orig] = found;
+      if (d2_out) d2_out[orig] = best[s];
+    }
+  }
+  if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)swept);
+}
+
+// one wave per listed source: all targets in ORIGINAL order, strict < per lane (ascending indices), then
+// (distance, index) lexicographic minimum across the wave == r3d_icp_nn's answer
+__global__ __launch_bounds__(64) void nn_tie_fallback_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                             int64_t n_tgt, const uint32_t* __restrict__ tie_list,
+                                                             const unsigned* __restrict__ tie_count,
+                                                             uint32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+  const unsigned n_list = *tie_count;
+  for (unsigned e = blockIdx.x; e < n_list; e += gridDim.x) {
+    const uint32_t i = tie_list[e];
+    const float sx = src[(int64_t)i * 3], sy = src[(int64_t)i * 3 + 1], sz = src[(int64_t)i * 3 + 2];
+    float best = INFINITY;
+    uint32_t bi = 0xffffffffu;
+    for (int64_t t = threadIdx.x; t < n_tgt; t += 64) {
+      const float dx = sx - tgt[t * 3], dy = sy - tgt[t * 3 + 1], dz = sz - tgt[t * 3 + 2];
+      const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      if (d < best) {
+        best = d;
+        bi = (uint32_t)t;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_down(best, off, 64);
+      const uint32_t oi = __shfl_down(bi, off, 64);
+      if (ob < best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (threadIdx.x == 0) {
+      idx_out[i] = bi == 0xffffffffu ? 0u : bi;  // all-NaN row: r3d_icp_nn reports index 0 too
+      if (d2_out) d2_out[i] = best;
+    }
+  }
+}
+
+int bits_for(int64_t n) {
+  int b = 1;
+  while (((int64_t)1 << b) < n) ++b;
+  return b;
+}
+
+// keys + sort for a cloud in the index's quantisation frame; result in d_keys (sorted)
+int sorted_keys(r3d_ctx* ctx, const float* d_xyz, int64_t n, const float* d_frame, int axis_bits, int idx_bits,
+                uint64_t* d_keys, uint64_t* d_tmp) {
+  hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz, n,
+                     d_frame, axis_bits, idx_bits, d_keys);
+  R3D_HIP(hipGetLastError());
+  return r3d_radix_sort_u64(ctx, d_keys, d_tmp, n, 3 * axis_bits + idx_bits);
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_nn_index_destroy(r3d_nn_index* ix) {
+  if (!ix) return R3D_OK;
+  if (ix->ctx) {
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+  }
+  if (ix->d_tgt) (void)hipFree(ix->d_tgt);
+  if (ix->d_tgt4) (void)hipFree(ix->d_tgt4);
+  if (ix->d_tile_box) (void)hipFree(ix->d_tile_box);
+  if (ix->d_sub_box) (void)hipFree(ix->d_sub_box);
+  if (ix->d_tile_code) (void)hipFree(ix->d_tile_code);
+  if (ix->d_frame) (void)hipFree(ix->d_frame);
+  delete ix;
+  return R3D_OK;
+}
+
+int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_index** ix_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(ix_out != nullptr, "ix_out is NULL");
+  *ix_out = nullptr;
+  R3D_REQUIRE(n_tgt >= 1, "target cloud is empty");
+  R3D_REQUIRE(n_tgt < ((int64_t)1 << 32), "target cloud too large for uint32 indices");
+  R3D_REQUIRE(d_tgt != nullptr, "NULL device pointer");
+  r3d_nn_index* ix = new (std::nothrow) r3d_nn_index();
+  if (!ix) {
+    r3d_set_error("host allocation failed");
+    return R3D_ERR_NOMEM;
+  }
+  ix->ctx = ctx;
+  ix->n = n_tgt;
+  ix->n_tiles = (n_tgt + kTile - 1) / kTile;
+  ix->idx_bits = bits_for(n_tgt);
+  ix->axis_bits = 10;  // 2^30 cells order any cloud finely enough for tile coherence and leave 34 bits for indices
+  const int64_t n_pad = ix->n_tiles * kTile;
+  hipError_t e = hipMalloc((void**)&ix->d_tgt, (size_t)n_tgt * 12);
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tgt4, (size_t)n_pad * sizeof(float4));
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tile_box, (size_t)ix->n_tiles * 6 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sub_box, (size_t)ix->n_tiles * (kTile / kSub) * 6 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tile_code, (size_t)ix->n_tiles * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_frame, 16 * sizeof(float));
+  if (e != hipSuccess) {
+    r3d_nn_index_destroy(ix);
+    return r3d_fail_hip(e, "nn index allocation", __FILE__, __LINE__);
+  }
+  void *keys = nullptr, *tmp = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, (size_t)n_tgt * 8, &keys)) || (rc = r3d_scratch(ctx, 2, (size_t)n_tgt * 8, &tmp))) {
+    r3d_nn_index_destroy(ix);
+    return rc;
+  }
+  hipStream_t st = ctx->stream;
+  int* box6 = reinterpret_cast<int*>(ix->d_frame + 8);
+  const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  e = hipMemcpyAsync(ix->d_tgt, d_tgt, (size_t)n_tgt * 12, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(box6, init, sizeof(init), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // `init` lives on this stack frame
+  if (e != hipSuccess) {
+    r3d_nn_index_destroy(ix);
+    return r3d_fail_hip(e, "nn index setup", __FILE__, __LINE__);
+  }
+  int blocks = (int)std::min<int64_t>((n_tgt + kThreads - 1) / kThreads, (int64_t)ctx->num_cus * 8);
+  hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(kThreads), 0, st, ix->d_tgt, n_tgt, box6);
+  hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(64), 0, st, box6, ix->axis_bits, ix->d_frame);
+  rc = sorted_keys(ctx, ix->d_tgt, n_tgt, ix->d_frame, ix->axis_bits, ix->idx_bits, (uint64_t*)keys, (uint64_t*)tmp);
+  if (rc) {
+    r3d_nn_index_destroy(ix);
+    return rc;
+  }
+  hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ix->d_tgt,
+                     (const uint64_t*)keys, n_tgt, n_pad, ix->idx_bits, ix->d_tgt4);
+  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ix->n_tiles), dim3(kThreads), 0, st, ix->d_tgt4, (const uint64_t*)keys,
+                     n_tgt, ix->idx_bits, kTile, ix->d_tile_box, ix->d_tile_code);
+  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)(ix->n_tiles * (kTile / kSub))), dim3(kThreads), 0, st, ix->d_tgt4,
+                     (const uint64_t*)keys, n_tgt, ix->idx_bits, kSub, ix->d_sub_box, (uint64_t*)nullptr);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // the scratch key buffers are reused by later calls
+  if (e != hipSuccess) {
+    r3d_nn_index_destroy(ix);
+    return r3d_fail_hip(e, "nn index build", __FILE__, __LINE__);
+  }
+  *ix_out = ix;
+  return R3D_OK;
+}
+
+int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                       int64_t* h_tiles_swept) {
+  R3D_REQUIRE(ix != nullptr, "nn index is NULL");
+  r3d_ctx* ctx = ix->ctx;
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_src >= 0, "negative cloud size");
+  if (h_tiles_swept) *h_tiles_swept = 0;
+  if (n_src == 0) return R3D_OK;
+  R3D_REQUIRE(n_src < ((int64_t)1 << 32), "source cloud too large");
+  R3D_REQUIRE(d_src && d_idx_out, "NULL device pointer");
+  const int src_idx_bits = bits_for(n_src);
+  const int axis_bits = ix->axis_bits;
+  void *keys = nullptr, *tmp = nullptr, *src4 = nullptr, *misc = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, (size_t)n_src * 8, &keys))) return rc;
+  if ((rc = r3d_scratch(ctx, 2, (size_t)n_src * 8, &tmp))) return rc;
+  if ((rc = r3d_scratch(ctx, 1, (size_t)n_src * sizeof(float4), &src4))) return rc;
+  if ((rc = r3d_scratch(ctx, 5, (size_t)n_src * 4 + 64, &misc))) return rc;
+  hipStream_t st = ctx->stream;
+  // source keys use the index's quantisation frame, so source and tile codes are directly comparable
+  if ((rc = sorted_keys(ctx, d_src, n_src, ix->d_frame, axis_bits, src_idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) return rc;
+  hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_src + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_src,
+                     (const uint64_t*)keys, n_src, n_src, src_idx_bits, (float4*)src4);
+  unsigned long long* stats = static_cast<unsigned long long*>(misc);       // [0] tile sweeps
+  unsigned* tie_count = reinterpret_cast<unsigned*>(stats + 2);
+  uint32_t* tie_list = reinterpret_cast<uint32_t*>(stats + 4);
+  R3D_HIP(hipMemsetAsync(misc, 0, 32, st));
+  int S = ctx->nn_variant;
+  if (S != 1 && S != 2 && S != 4) S = 1;
+  const int64_t per_block = (int64_t)kThreads * S;
+  const unsigned blocks = (unsigned)((n_src + per_block - 1) / per_block);
+#define R3D_LAUNCH_CULL(SS)                                                                                            \
+  hipLaunchKernelGGL((nn_cull_kernel<SS>), dim3(blocks), dim3(kThreads), 0, st, (const float4*)src4, n_src,           \
+                     (const uint64_t*)keys, src_idx_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box, ix->d_sub_box,   \
+                     ix->d_tile_code,                                                                              \
+                     d_idx_out, d_d2_out, tie_list, tie_count, stats)
+  if (S == 1) R3D_LAUNCH_CULL(1);
+  else if (S == 2) R3D_LAUNCH_CULL(2);
+  else R3D_LAUNCH_CULL(4);
+#undef R3D_LAUNCH_CULL
+  hipLaunchKernelGGL(nn_tie_fallback_kernel, dim3(ctx->num_cus * 4), dim3(64), 0, st, d_src, ix->d_tgt, ix->n, tie_list,
+                     tie_count, d_idx_out, d_d2_out);
+  R3D_HIP(hipGetLastError());
+  if (h_tiles_swept) {
+    unsigned long long v = 0;
+    R3D_HIP(hipMemcpyAsync(&v, stats, sizeof(v), hipMemcpyDeviceToHost, st));
+    R3D_HIP(hipStreamSynchronize(st));
+    *h_tiles_swept = (int64_t)v;
+  }
+  return R3D_OK;
+}
+
+}  // extern "C"

@@ -39,10 +39,38 @@ def umeyama_from_sums(sums, with_scale=True):
     return T
 
 
-class IcpDevice:
-    """Source / target clouds resident on one GPU."""
+class NNIndex:
+    """Spatially culled exact nearest-neighbour index over a device-resident target cloud (r3d_nn_index)."""
 
-    def __init__(self, src, tgt, ctx=None):
+    def __init__(self, ctx, d_tgt_ptr, n_tgt):
+        self.ctx = ctx
+        h = C.c_void_p()
+        L.check(ctx.lib.r3d_nn_index_create(ctx.handle, d_tgt_ptr, int(n_tgt), C.byref(h)))
+        self.handle = h.value
+
+    def query(self, d_src_ptr, n_src, d_idx_ptr, d_d2_ptr, want_stats=False):
+        swept = C.c_int64()
+        L.check(self.ctx.lib.r3d_nn_index_query(self.handle, d_src_ptr, int(n_src), d_idx_ptr, d_d2_ptr,
+                                                C.byref(swept) if want_stats else None))
+        return swept.value
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.r3d_nn_index_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IcpDevice:
+    """Source / target clouds resident on one GPU.  culled=True (default) answers NN queries through the
+    Morton-tile index (same results, far fewer pair evaluations); culled=False runs the plain brute-force sweep."""
+
+    def __init__(self, src, tgt, ctx=None, culled=True):
         self.ctx = ctx or default_context()
         src = np.ascontiguousarray(src, dtype=np.float32)
         tgt = np.ascontiguousarray(tgt, dtype=np.float32)
@@ -56,11 +84,15 @@ class IcpDevice:
         self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
         self.d_idx = c.alloc(max(self.n * 4, 16))
         self.d_d2 = c.alloc(max(self.n * 4, 16))
+        self.index = NNIndex(c, self.d_tgt.ptr, self.m) if culled else None
 
-    def nn(self):
+    def nn(self, want_stats=False):
         c = self.ctx
+        if self.index is not None:
+            return self.index.query(self.d_src.ptr, self.n, self.d_idx.ptr, self.d_d2.ptr, want_stats)
         L.check(c.lib.r3d_icp_nn(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
                                  self.d_d2.ptr))
+        return 0
 
     def sums(self, max_d2=-1.0):
         c = self.ctx
@@ -83,12 +115,15 @@ class IcpDevice:
         return self.d_src.download(np.float32, self.n * 3).reshape(-1, 3)
 
     def free(self):
+        if self.index is not None:
+            self.index.close()
         for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2):
             b.free()
 
 
-def nearest_neighbours(src, tgt, ctx=None):
-    """(idx uint32 [N], d2 float32 [N]): brute-force squared-L2 nearest target of every source point."""
+def nearest_neighbours(src, tgt, ctx=None, culled=False):
+    """(idx uint32 [N], d2 float32 [N]): squared-L2 nearest target of every source point, lowest index on ties.
+    culled=False: plain brute-force sweep (r3d_icp_nn_host); culled=True: Morton-tile index, same answer."""
     ctx = ctx or default_context()
     src = np.ascontiguousarray(src, dtype=np.float32)
     tgt = np.ascontiguousarray(tgt, dtype=np.float32)
@@ -96,16 +131,23 @@ def nearest_neighbours(src, tgt, ctx=None):
     d2 = np.empty(src.shape[0], dtype=np.float32)
     if src.shape[0] == 0:
         return idx, d2
+    if culled:
+        dev = IcpDevice(src, tgt, ctx, culled=True)
+        try:
+            dev.nn()
+            return dev.download()
+        finally:
+            dev.free()
     L.check(ctx.lib.r3d_icp_nn_host(ctx.handle, src.ctypes.data, src.shape[0], tgt.ctypes.data, tgt.shape[0],
                                     idx.ctypes.data, d2.ctypes.data))
     return idx, d2
 
 
-def icp_similarity(src, tgt, max_iter=30, tol=1e-7, with_scale=True, trim_d2=None, ctx=None):
+def icp_similarity(src, tgt, max_iter=30, tol=1e-7, with_scale=True, trim_d2=None, ctx=None, culled=True):
     """Iterate NN + Umeyama until the RMS match distance stops improving by more than `tol`
     (relative).  Returns (T 4x4 mapping src -> tgt, info dict).  trim_d2: ignore pairs whose
     squared distance exceeds it (None = use all)."""
-    dev = IcpDevice(src, tgt, ctx)
+    dev = IcpDevice(src, tgt, ctx, culled)
     T_total = np.eye(4)
     history = []
     prev = None

@@ -140,6 +140,16 @@ int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_t
                uint32_t* d_idx_out, float* d_d2_out);
 int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float* h_tgt, int64_t n_tgt,
                     uint32_t* h_idx_out, float* h_d2_out);
+/* The same answer as r3d_icp_nn with spatial culling: the target cloud is Morton-sorted once into 1024-point tiles
+ * with bounding boxes; a query sorts its sources the same way and sweeps only tiles whose box can still hold a
+ * closer point.  Exactness is kept: identical fp32 distance expression, lowest original target index on ties
+ * (cross-tile ties go through an exact fallback).  create synchronises; query is asynchronous on the ctx stream
+ * unless h_tiles_swept != NULL (then it synchronises and reports how many tile sweeps all workgroups did). */
+typedef struct r3d_nn_index r3d_nn_index;
+int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_index** index_out);
+int r3d_nn_index_destroy(r3d_nn_index* index);
+int r3d_nn_index_query(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                       int64_t* h_tiles_swept);
 /* r3d_icp_accumulate: the 18 fp64 sums Umeyama needs over the matched pairs (p=src[k], q=tgt[idx[k]]),
  * pairs with d2 > max_d2 skipped when max_d2 >= 0 (d_d2 may be NULL when max_d2 < 0):
  *   sums[0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p_a*q_b (a major), [16]=sum |p|^2, [17]=sum |q|^2.

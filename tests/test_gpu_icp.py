@@ -43,14 +43,59 @@ def assert_nn_valid(src, tgt, idx, d2):
 
 @pytest.mark.parametrize("n,m", [(1, 1), (5, 3), (64, 1000), (300, 1024), (1000, 1025), (2500, 5000), (4097, 33)])
 @pytest.mark.parametrize("S", [0, 1, 2, 4])
-def test_nn_matches_oracle(icp, ctx, n, m, S):
+@pytest.mark.parametrize("culled", [False, True])
+def test_nn_matches_oracle(icp, ctx, n, m, S, culled):
     rng = np.random.default_rng(n * 7 + m)
     src = (rng.random((n, 3)) * 20).astype(np.float32)
     tgt = (rng.random((m, 3)) * 20).astype(np.float32)
     ctx.set_tuning("nn_variant", S)
-    idx, d2 = icp.nearest_neighbours(src, tgt, ctx=ctx)
+    idx, d2 = icp.nearest_neighbours(src, tgt, ctx=ctx, culled=culled)
     ctx.set_tuning("nn_variant", 0)
     assert_nn_valid(src, tgt, idx, d2)
+
+
+@pytest.mark.parametrize("n,m,shape", [(30000, 40000, "cube"), (20000, 60000, "sheet"), (50000, 50000, "clusters")])
+def test_culled_equals_brute_force_bitwise(icp, ctx, n, m, shape):
+    """The culled index must reproduce the brute-force kernel exactly (indices and distances), on clouds with very
+    different spatial structure, and it must actually skip most tiles."""
+    rng = np.random.default_rng(m)
+    if shape == "cube":
+        tgt = rng.random((m, 3)) * 20
+        src = rng.random((n, 3)) * 22 - 1
+    elif shape == "sheet":                                   # a thin slab: degenerate boxes
+        tgt = np.stack([rng.random(m) * 30, rng.random(m) * 30, rng.normal(size=m) * 0.01], 1)
+        src = np.stack([rng.random(n) * 30, rng.random(n) * 30, rng.normal(size=n) * 0.5], 1)
+    else:
+        centres = rng.normal(size=(12, 3)) * 15
+        tgt = centres[rng.integers(0, 12, m)] + rng.normal(size=(m, 3)) * 0.3
+        src = centres[rng.integers(0, 12, n)] + rng.normal(size=(n, 3)) * 0.6
+    src, tgt = src.astype(np.float32), tgt.astype(np.float32)
+    dev_b = icp.IcpDevice(src, tgt, ctx, culled=False)
+    dev_b.nn()
+    bi, bd = dev_b.download()
+    dev_b.free()
+    dev_c = icp.IcpDevice(src, tgt, ctx, culled=True)
+    swept = dev_c.nn(want_stats=True)
+    ci, cd = dev_c.download()
+    dev_c.free()
+    np.testing.assert_array_equal(ci, bi)
+    np.testing.assert_array_equal(cd, bd)
+    n_tiles = -(-m // 1024)
+    n_groups = -(-n // 256)
+    assert swept < 0.35 * n_tiles * n_groups, (swept, n_tiles * n_groups)
+
+
+def test_culled_cross_tile_ties_and_duplicates(icp, ctx):
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 6, (300, 3)).astype(np.float32)      # heavy duplication on an integer lattice
+    tgt = np.tile(base, (20, 1))                                 # every point at 20 original indices, many tiles
+    src = np.concatenate([base + np.float32(0.25), base])        # equidistant neighbours + exact hits
+    idx_b, d2_b = icp.nearest_neighbours(src, tgt, ctx=ctx, culled=False)
+    idx_c, d2_c = icp.nearest_neighbours(src, tgt, ctx=ctx, culled=True)
+    np.testing.assert_array_equal(idx_c, idx_b)
+    np.testing.assert_array_equal(d2_c, d2_b)
+    np.testing.assert_array_equal(idx_c, OI.nearest_neighbours(src, tgt)[0])
+    assert idx_c.max() < 300
 
 
 def test_nn_ties_pick_lowest_index(icp, ctx):

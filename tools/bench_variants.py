@@ -136,6 +136,25 @@ def bench_nn(ctx, n, m, rounds):
                   % (S, blocks, med, n * m / med / 1e9, n * m * 8 / med / 1e9))
     ctx.set_tuning("nn_variant", 0)
     ctx.set_tuning("nn_blocks", 0)
+    icp = importlib.import_module("3d_reconstruction_system_amd.icp")
+    import time
+    for label, s_arr in (("uniform cube", src), ("ICP-like: target subset moved by s=1.01, 0.5 deg", None)):
+        if s_arr is None:
+            s_arr = (tgt[rng.permutation(m)[:n]] * 1.01 + 0.02).astype(np.float32)
+        t0 = time.perf_counter()
+        dev = icp.IcpDevice(s_arr, tgt, ctx, culled=True)
+        ctx.sync()
+        t_build = (time.perf_counter() - t0) * 1e3
+        for S in (1, 2, 4):
+            ctx.set_tuning("nn_variant", S)
+            ts = [time_ms(ctx, dev.nn, 3) for _ in range(rounds)]
+            swept = dev.nn(want_stats=True)
+            blocks = -(-n // (256 * S))
+            print("culled %-50s S=%d  med %.3f ms (= %.0f Tpairs/s brute-force equivalent), "
+                  "%.1f of %d tiles swept per workgroup; upload+index build %.1f ms"
+                  % (label, S, np.median(ts), n * m / np.median(ts) / 1e9, swept / blocks, -(-m // 1024), t_build))
+        ctx.set_tuning("nn_variant", 0)
+        dev.free()
 
 
 def bench_voxel(ctx, F, H, W, rounds):

@@ -74,10 +74,16 @@ def main():
     m = 500000
     tgt = (rng.random((m, 3)) * 20).astype(np.float32)
     src = (tgt[rng.permutation(m)] * 1.01 + 0.02).astype(np.float32)
-    dev = icp.IcpDevice(src, tgt, ctx)
+    dev = icp.IcpDevice(src, tgt, ctx, culled=False)
     ms = timed(ctx, dev.nn, 3)
-    out["icp_nn_500k"] = {"ms": ms, "Tpairs": m * m / ms / 1e9, "TFLOPs_at_8_flop_per_pair": m * m * 8 / ms / 1e9,
-                          "bound": "fp32 VALU"}
+    out["icp_nn_bruteforce_500k"] = {"ms": ms, "Tpairs": m * m / ms / 1e9, "TFLOPs_at_8_flop_per_pair": m * m * 8 / ms / 1e9,
+                                     "bound": "fp32 VALU"}
+    devc = icp.IcpDevice(src, tgt, ctx, culled=True)
+    ms = timed(ctx, devc.nn, 10)
+    swept = devc.nn(want_stats=True)
+    out["icp_nn_culled_500k"] = {"ms": ms, "tile_sweeps_per_workgroup": swept / -(-m // 256), "tiles": -(-m // 1024),
+                                 "note": "same indices and distances as the brute-force sweep"}
+    devc.free()
     import time
     t0 = time.perf_counter()
     for _ in range(20):
