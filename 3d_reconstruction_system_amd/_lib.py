@@ -71,6 +71,7 @@ SIGNATURES = {
     "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),
     "r3d_format_ply": (_i, [_vp, _i, _i64, _vp, _sz, _psz]),
     "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),
+    "r3d_write_ply_rgb": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),
     "r3d_write_xyz_txt": (_i, [C.c_char_p, _vp, _i, _i64, _vp, _i, _i]),
     "r3d_format_xyz_txt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _sz, _psz]),
     "r3d_voxelset_create": (_i, [_vp, _d, _i64, _pvp]),

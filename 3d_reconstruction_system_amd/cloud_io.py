@@ -109,6 +109,16 @@ def write_ply(path, xyz):
     L.check(L.load().r3d_write_ply(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0]))
 
 
+def write_ply_rgb(path, xyz, rgb):
+    """Coloured PLY in the reference layout (p2c:55-91): rgb is [N,3] uint8 (R,G,B), alpha column is the literal 0."""
+    xyz = _cloud(xyz)
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    if rgb.shape[0] != xyz.shape[0]:
+        raise ValueError("colour image has %d pixels, cloud has %d points" % (rgb.shape[0], xyz.shape[0]))
+    L.check(L.load().r3d_write_ply_rgb(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), rgb.ctypes.data,
+                                       xyz.shape[0]))
+
+
 def read_xyz_txt(path):
     """[N,3] float64 from `X,Y,Z\\n` lines (first three comma-separated fields, as c2w:97-98)."""
     with open(path, 'r') as f:

@@ -203,6 +203,32 @@ void txt_rows(const T* xyz, const void* z_raw, int z_dtype, int64_t lo, int64_t 
   out->resize(p - base);
 }
 
+template <typename T>
+void format_rows_rgb(const T* xyz, const unsigned char* rgb, int64_t lo, int64_t hi, std::string* out) {
+  out->resize((size_t)(hi - lo) * 80 + 1300);
+  char* base = &(*out)[0];
+  char* p = base;
+  for (int64_t i = lo; i < hi; ++i) {
+    if ((size_t)(p - base) + 1300 > out->size()) {
+      const size_t used = p - base;
+      out->resize(out->size() * 2 + 1300);
+      base = &(*out)[0];
+      p = base + used;
+    }
+    for (int a = 0; a < 3; ++a) {
+      p = fmt4(p, (double)xyz[i * 3 + a]);
+      *p++ = ' ';
+    }
+    for (int a = 0; a < 3; ++a) {
+      p = put_uint(p, rgb[i * 3 + a]);
+      *p++ = ' ';
+    }
+    *p++ = '0';
+    *p++ = '\n';
+  }
+  out->resize(p - base);
+}
+
 int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, std::vector<std::string>* chunks) {
   char head[256];
   snprintf(head, sizeof(head),
@@ -266,6 +292,63 @@ int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, 
     p += c.size();
   }
   memcpy(p, "\n    ", 5);
+  return R3D_OK;
+}
+
+int r3d_write_ply_rgb(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int64_t n_points) {
+  if (!path || n_points < 0 || (n_points > 0 && (!h_xyz || !h_rgb)) || (dtype != R3D_F32 && dtype != R3D_F64)) {
+    r3d_set_error("r3d_write_ply_rgb: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    r3d_set_error("r3d_write_ply_rgb: cannot open '%s' for writing", path);
+    return R3D_ERR_INVALID;
+  }
+  bool ok = true;
+  try {
+    char head[400];
+    snprintf(head, sizeof(head),
+             "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
+             "    property float z\n    property uchar red\n    property uchar green\n    property uchar blue\n"
+             "    property uchar alpha\n    end_header\n    ",
+             (long long)n_points);
+    ok = fwrite(head, 1, strlen(head), f) == strlen(head);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    const int64_t slab = (int64_t)4 << 20;
+    for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
+      const int64_t cnt = std::min(slab, n_points - s0);
+      const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 65536));
+      std::vector<std::string> chunks((size_t)n_chunks);
+      std::vector<std::thread> pool;
+      for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
+        auto work = [=, &chunks]() {
+          if (dtype == R3D_F32)
+            format_rows_rgb(static_cast<const float*>(h_xyz), h_rgb, lo, hi, &chunks[(size_t)c]);
+          else
+            format_rows_rgb(static_cast<const double*>(h_xyz), h_rgb, lo, hi, &chunks[(size_t)c]);
+        };
+        if (n_chunks == 1)
+          work();
+        else
+          pool.emplace_back(work);
+      }
+      for (auto& t : pool) t.join();
+      for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+    }
+    ok = ok && fwrite("\n    ", 1, 5, f) == 5;
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    r3d_set_error("r3d_write_ply_rgb: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
+  if (fclose(f) != 0) ok = false;
+  if (!ok) {
+    r3d_set_error("r3d_write_ply_rgb: short write to '%s'", path);
+    return R3D_ERR_INVALID;
+  }
   return R3D_OK;
 }
 

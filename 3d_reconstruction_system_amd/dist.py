@@ -140,3 +140,30 @@ class ShardedFusion:
                              out[done * per:(done + c) * per])
             done += c
         return out
+
+
+def all_gather_voxel_codes(codes, group=None):
+    """Union of every rank's occupied-voxel set (config 5: frames sharded, ONE map).  codes: this rank's distinct Morton
+    codes (uint64 NumPy array, any order).  Each rank inserts its own shard of the world cloud into its own HBM hash
+    set (voxelmap.VoxelSet) -- 12 B/point never leave the GPU -- and only the distinct codes (8 B/voxel) cross the
+    fabric: all-gather of padded int64 tensors, then sort + unique.  Returns the ascending union on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(np.ascontiguousarray(codes, dtype=np.uint64).view(np.int64)).to(dev)
+    n_local = torch.tensor([mine.numel()], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts) if counts else 0
+    if longest == 0:
+        return np.zeros(0, dtype=np.uint64)
+    padded = torch.zeros(longest, dtype=torch.int64, device=dev)
+    padded[:mine.numel()] = mine
+    gathered = torch.empty(world * longest, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    parts = [gathered[r * longest:r * longest + c] for r, c in enumerate(counts) if c]
+    merged = torch.cat(parts).cpu().numpy().view(np.uint64)
+    return np.unique(merged)

@@ -53,22 +53,7 @@ def genply_noRGB(gtxyz, imgpath, pc_file):
     xyz = _as_xyz(gtxyz)
     if img.shape[0] * img.shape[1] != xyz.shape[0]:
         raise ValueError("colour image has %d pixels, cloud has %d points" % (img.shape[0] * img.shape[1], xyz.shape[0]))
-    rgb = img.reshape(-1, 3)
-    rows = ["%.4f %.4f %.4f %d %d %d 0\n" % (p[0], p[1], p[2], c[0], c[1], c[2]) for p, c in zip(xyz, rgb)]
-    with open(pc_file, "w") as f:
-        f.write('''ply
-    format ascii 1.0
-    element vertex %d
-    property float x
-    property float y
-    property float z
-    property uchar red
-    property uchar green
-    property uchar blue
-    property uchar alpha
-    end_header
-    %s
-    ''' % (len(rows), "".join(rows)))
+    r3d.cloud_io.write_ply_rgb(pc_file, xyz, img.reshape(-1, 3))
     print("Write into .ply file Done.", time.time() - t1)
 
 

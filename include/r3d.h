@@ -165,6 +165,9 @@ int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, 
                    size_t* n_bytes_out);
 /* Same bytes straight to a file (formatted and written in slabs; replaces the open/write of c2w:122-132). */
 int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_points);
+/* f4: the coloured layout of genply_noRGB() (pixel_to_camera.py:55-91): uchar red/green/blue/alpha header lines and
+ * "%.4f %.4f %.4f R G B 0\n" rows; h_rgb is [n][3] uint8 in R,G,B order, point k takes colour k. */
+int r3d_write_ply_rgb(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int64_t n_points);
 /* "X,Y,Z\n" lines with Python repr() float formatting -- the camera / world txt of
  * camera_to_world.py:80-81, 103-104 and transfer_T_icp.py:87,93.  If h_z_raw != NULL the third column
  * is printed as that raw integer raster value (the reference's camera txt prints str(np.uint8));

@@ -61,6 +61,14 @@ def main():
             refused = "no CPU" in str(e) or "MI355X" in str(e)
     else:
         refused = True
+    # config-5 style map union: every rank voxelises its own shard (oracle stands in for the HIP hash set here),
+    # only distinct codes are exchanged, the union equals the single-process set
+    from oracle import octomap_ref as OM
+    per = H * W
+    my_pts = want[lo * per:hi * per].astype(np.float32)
+    my_codes = OM.occupied_set(my_pts)[0] if hi > lo else np.zeros(0, np.uint64)
+    union = D.all_gather_voxel_codes(my_codes)
+    ok = ok and np.array_equal(union, OM.occupied_set(want.astype(np.float32))[0] if n_frames else np.zeros(0, np.uint64))
     with open("%s.rank%d" % (out_path, rank), "w") as f:
         f.write("ok=%d refused=%d lo=%d hi=%d\n" % (ok, refused, lo, hi))
     dist.barrier()

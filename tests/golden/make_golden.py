@@ -177,6 +177,13 @@ def main():
     plytmp = os.path.join(HERE, "p2c_first7.ply")
     with contextlib.redirect_stdout(io.StringIO()):
         p2c.genply_RGB([xs[:7], ys[:7], zs[:7]], plytmp)
+    # p2c.genply_noRGB (the COLOURED writer) references an `Image` it never imports (p2c:58); with PIL's Image
+    # placed in its namespace (environment shim, like cv2) it runs: 6 points + a 2x3 RGB image
+    p2c.Image = Image
+    rgb = np.random.default_rng(1).integers(0, 256, (2, 3, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(os.path.join(HERE, "p2c_rgb_2x3.png"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        p2c.genply_noRGB([xs[:6], ys[:6], zs[:6]], os.path.join(HERE, "p2c_rgb_2x3.png"), os.path.join(HERE, "p2c_first6_rgb.ply"))
     try:
         p2c.gentxtcord(tmp, d480[:192])
         g5["short_raster_error"] = None

@@ -104,6 +104,9 @@ def test_pixel_to_camera_functions(tmp_path, golden_dir):
     lines = (tmp_path / "c.ply").read_text().split("\n")
     assert lines[2].strip() == "element vertex 6" and lines[9].strip() == "property uchar alpha"
     assert lines[11].split() == ["%.4f" % xs[0], "%.4f" % ys[0], "%.4f" % zs[0]] + [str(v) for v in rgb[0, 0]] + ["0"]
+    # and the reference's own bytes for its own image
+    p2c.genply_noRGB([xs[:6], ys[:6], zs[:6]], os.path.join(golden_dir, "p2c_rgb_2x3.png"), str(tmp_path / "g.ply"))
+    assert (tmp_path / "g.ply").read_bytes() == open(os.path.join(golden_dir, "p2c_first6_rgb.ply"), "rb").read()
 
 
 def test_transfer_T_icp_script_reproduces_reference_files(tmp_path, golden_dir):

@@ -145,3 +145,20 @@ def test_type_checks_happen_before_any_device_work(R):
         R.unproject(np.zeros((4,), np.uint8))
     with pytest.raises(ValueError):
         R.cloud_io.write_xyz_txt("/tmp/x.txt", np.zeros((3, 2)))
+
+
+def test_coloured_ply_matches_reference_bytes(R, golden_dir, tmp_path):
+    """genply_noRGB's layout (p2c:55-91), pinned by running the reference with PIL's Image put into its namespace."""
+    import json
+    from PIL import Image
+    g = json.load(open(os.path.join(golden_dir, "p2c_480x640.json")))
+    depth = np.random.default_rng(g["seed"]).integers(1, 256, tuple(g["shape"]), dtype=np.uint8)
+    cam = O.unproject(depth)[:6]
+    rgb = np.array(Image.open(os.path.join(golden_dir, "p2c_rgb_2x3.png")).convert("RGB")).reshape(-1, 3)
+    want = open(os.path.join(golden_dir, "p2c_first6_rgb.ply"), "rb").read()
+    R.cloud_io.write_ply_rgb(str(tmp_path / "c.ply"), cam, rgb)
+    assert (tmp_path / "c.ply").read_bytes() == want
+    R.cloud_io.write_ply_rgb(str(tmp_path / "c32.ply"), cam.astype(np.float32), rgb)
+    assert (tmp_path / "c32.ply").read_bytes() == want          # these values survive the f32 round trip at 4 decimals
+    with pytest.raises(ValueError):
+        R.cloud_io.write_ply_rgb(str(tmp_path / "bad.ply"), cam, rgb[:5])
