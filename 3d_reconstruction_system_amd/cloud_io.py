@@ -35,6 +35,40 @@ def read_depth_gray(path):
     return np.ascontiguousarray(img)
 
 
+def read_depth_batch(paths, out=None):
+    """[F,H,W] raster batch for a list of depth PNGs with IMREAD_GRAYSCALE meaning (c2w:160).  8-bit greyscale PNGs --
+    the reference's input -- are inflated and unfiltered by the library's host threads straight into one contiguous
+    (optionally pinned) buffer; any other flavour goes through cv2/PIL file by file."""
+    paths = [os.fspath(p) for p in paths]
+    if not paths:
+        return np.empty((0, 0, 0), np.uint8)
+    lib = L.load()
+    h, w, bits = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.r3d_png_gray_info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(bits))
+    if rc == L.OK and bits.value == 8:
+        shape = (len(paths), h.value, w.value)
+        if out is None:
+            out = np.empty(shape, np.uint8)
+        elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        rc = lib.r3d_png_gray_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value, 8)
+        if rc == L.OK:
+            return out
+        if rc != L.ERR_UNSUPPORTED:
+            L.check(rc)
+    elif rc not in (L.OK, L.ERR_UNSUPPORTED):
+        if not os.path.exists(paths[0]):
+            raise FileNotFoundError("cannot read depth image %r" % paths[0])
+        L.check(rc)
+    rasters = [read_depth_gray(p) for p in paths]          # colour / 16-bit / palette / interlaced files
+    for p, r in zip(paths, rasters):
+        if r.shape != rasters[0].shape:
+            raise ValueError("depth %s is %s, expected %s: all frames of one pose file share a camera"
+                             % (p, r.shape, rasters[0].shape))
+    return np.stack(rasters)
+
+
 def read_depth_unchanged(path):
     """IMREAD_UNCHANGED: channels in BGR order like OpenCV (p2c:133 then takes channel 1)."""
     try:

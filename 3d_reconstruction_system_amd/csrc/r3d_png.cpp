@@ -1,0 +1,205 @@
+// f3 ingestion: grey PNG -> raster, on host threads (zlib inflate + PNG unfiltering).
+//
+// Replaces `cv.imread('./depth/'+name, cv.IMREAD_GRAYSCALE)` of camera_to_world.py:160 for the files that path
+// actually reads: non-interlaced greyscale PNGs (colour type 0) of 8 bits (-> uint8, identical to OpenCV) or
+// 16 bits (-> uint16 big-endian samples converted to host order; OpenCV would reduce these to 8 bits, the caller
+// decides).  Anything else (colour, palette, alpha, interlace) returns R3D_ERR_UNSUPPORTED so the Python host can
+// fall back to cv2/PIL, whose colour->grey conversions are theirs to define.
+// A batch of files is decoded straight into one [n][H][W] buffer (e.g. pinned memory) by a thread pool.
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "r3d.h"
+
+void r3d_set_error(const char* fmt, ...);
+
+namespace {
+
+struct PngInfo {
+  uint32_t width = 0, height = 0;
+  int bit_depth = 0, colour_type = 0, interlace = 0;
+};
+
+uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// reads the file, returns concatenated IDAT payload; rc: 0 ok, else R3D_ERR_*; msg set
+int read_png(const char* path, PngInfo* info, std::vector<unsigned char>* idat, std::string* msg) {
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    *msg = std::string("cannot open '") + path + "'";
+    return R3D_ERR_INVALID;
+  }
+  std::vector<unsigned char> file;
+  {
+    unsigned char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + n);
+  }
+  fclose(f);
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8) != 0) {
+    *msg = std::string("'") + path + "' is not a PNG file";
+    return R3D_ERR_INVALID;
+  }
+  size_t pos = 8;
+  bool have_ihdr = false;
+  while (pos + 12 <= file.size()) {
+    const uint32_t len = be32(&file[pos]);
+    const unsigned char* type = &file[pos + 4];
+    if (pos + 12 + (size_t)len > file.size()) break;
+    const unsigned char* data = &file[pos + 8];
+    if (!memcmp(type, "IHDR", 4) && len >= 13) {
+      info->width = be32(data);
+      info->height = be32(data + 4);
+      info->bit_depth = data[8];
+      info->colour_type = data[9];
+      info->interlace = data[12];
+      have_ihdr = true;
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat->insert(idat->end(), data, data + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (!have_ihdr || idat->empty()) {
+    *msg = std::string("'") + path + "': truncated PNG";
+    return R3D_ERR_INVALID;
+  }
+  return R3D_OK;
+}
+
+inline int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// decode one grey PNG into out (row-major, H*W samples of bits/8 bytes, host byte order)
+int decode_gray(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
+  PngInfo info;
+  std::vector<unsigned char> idat;
+  int rc = read_png(path, &info, &idat, msg);
+  if (rc) return rc;
+  if (h_out) *h_out = (int)info.height;
+  if (w_out) *w_out = (int)info.width;
+  if (bits_out) *bits_out = info.bit_depth;
+  if (info.colour_type != 0 || info.interlace != 0 || (info.bit_depth != 8 && info.bit_depth != 16)) {
+    *msg = std::string("'") + path + "': only non-interlaced 8/16-bit greyscale PNGs are decoded natively";
+    return R3D_ERR_UNSUPPORTED;
+  }
+  if (!out) return R3D_OK;  // header query
+  const size_t bpp = info.bit_depth / 8, stride = (size_t)info.width * bpp;
+  const size_t need = stride * info.height;
+  if (cap_bytes < need) {
+    *msg = std::string("'") + path + "': output buffer too small";
+    return R3D_ERR_NOMEM;
+  }
+  std::vector<unsigned char> raw((stride + 1) * info.height);
+  uLongf raw_len = (uLongf)raw.size();
+  const int z = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+  if (z != Z_OK || raw_len != raw.size()) {
+    *msg = std::string("'") + path + "': zlib inflate failed";
+    return R3D_ERR_INVALID;
+  }
+  unsigned char* dst = static_cast<unsigned char*>(out);
+  for (uint32_t y = 0; y < info.height; ++y) {
+    const unsigned char* src = &raw[(stride + 1) * y];
+    const int filter = src[0];
+    unsigned char* row = dst + stride * y;
+    const unsigned char* up = y ? row - stride : nullptr;
+    ++src;
+    for (size_t x = 0; x < stride; ++x) {
+      const int a = x >= bpp ? row[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+      int v = src[x];
+      switch (filter) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: v += paeth(a, b, c); break;
+        default:
+          *msg = std::string("'") + path + "': bad PNG filter type";
+          return R3D_ERR_INVALID;
+      }
+      row[x] = (unsigned char)v;
+    }
+  }
+  if (bpp == 2) {  // PNG samples are big-endian
+    for (size_t k = 0; k < need; k += 2) {
+      const unsigned char t = dst[k];
+      dst[k] = dst[k + 1];
+      dst[k + 1] = t;
+    }
+  }
+  return R3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_png_gray_info(const char* path, int* height, int* width, int* bit_depth) {
+  if (!path) {
+    r3d_set_error("r3d_png_gray_info: path is NULL");
+    return R3D_ERR_INVALID;
+  }
+  std::string msg;
+  const int rc = decode_gray(path, nullptr, 0, height, width, bit_depth, &msg);
+  if (rc) r3d_set_error("%s", msg.c_str());
+  return rc;
+}
+
+int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out, int height, int width, int bit_depth) {
+  if (n_files < 0 || (n_files > 0 && (!paths || !h_out)) || height <= 0 || width <= 0 || (bit_depth != 8 && bit_depth != 16)) {
+    r3d_set_error("r3d_png_gray_decode_batch: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  const size_t frame_bytes = (size_t)height * width * (bit_depth / 8);
+  unsigned hw = std::thread::hardware_concurrency();
+  const unsigned n_threads = std::max(1u, std::min<unsigned>(hw == 0 ? 1 : hw, std::min(32, n_files)));
+  std::atomic<int> next{0}, first_rc{R3D_OK};
+  std::string first_msg;
+  std::atomic<bool> have_msg{false};
+  auto worker = [&]() {
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= n_files || first_rc.load() != R3D_OK) return;
+      int h = 0, w = 0, bits = 0;
+      std::string msg;
+      int rc = paths[k] ? decode_gray(paths[k], static_cast<char*>(h_out) + frame_bytes * k, frame_bytes, &h, &w, &bits, &msg)
+                        : R3D_ERR_INVALID;
+      if (rc == R3D_OK && (h != height || w != width || bits != bit_depth)) {
+        rc = R3D_ERR_INVALID;
+        msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + "x" +
+              std::to_string(bits) + " bits, the batch expects " + std::to_string(width) + "x" + std::to_string(height) + "x" +
+              std::to_string(bit_depth);
+      }
+      if (rc != R3D_OK) {
+        int expected = R3D_OK;
+        if (first_rc.compare_exchange_strong(expected, rc)) {
+          first_msg = msg.empty() ? "bad path" : msg;
+          have_msg.store(true);
+        }
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  if (first_rc.load() != R3D_OK) {
+    r3d_set_error("%s", have_msg.load() ? first_msg.c_str() : "PNG decode failed");
+    return first_rc.load();
+  }
+  return R3D_OK;
+}
+
+}  // extern "C"

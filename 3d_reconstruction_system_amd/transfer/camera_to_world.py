@@ -87,13 +87,7 @@ def fuse_pose_file(qt_path, depth_dir='./depth/', out_dtype=np.float64):
     names, quats, ts = r3d.read_pose_file(qt_path)
     if not names:
         return names, np.empty((0, 0, 0), np.uint8), np.empty((0, 3), out_dtype)
-    rasters = [r3d.cloud_io.read_depth_gray(os.path.join(depth_dir, n)) for n in names]
-    shape = rasters[0].shape
-    for n, r in zip(names, rasters):
-        if r.shape != shape:
-            raise ValueError("depth %s is %s, expected %s: all frames of one pose file share a camera"
-                             % (n, r.shape, shape))
-    depths = np.stack(rasters)
+    depths = r3d.cloud_io.read_depth_batch([os.path.join(depth_dir, n) for n in names])
     world = r3d.fuse_frames(depths, quats, ts, intrinsics=_common.intrinsics(), out_dtype=out_dtype,
                             ctx=_common.context())
     return names, depths, world

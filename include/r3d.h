@@ -178,6 +178,14 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
 int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
                        char* h_buf, size_t buf_cap, size_t* n_bytes_out);
 
+/* ---- f3 ingestion: the depth rasters of camera_to_world.py:160 (`cv.imread(path, IMREAD_GRAYSCALE)`) decoded by host
+ * threads.  Native path: non-interlaced greyscale PNG, 8 bits (-> uint8, same bytes as OpenCV) or 16 bits (-> uint16);
+ * any other PNG flavour returns R3D_ERR_UNSUPPORTED (the Python host then falls back to cv2 / PIL).
+ * r3d_png_gray_info: header only.  r3d_png_gray_decode_batch: n files of identical height x width x bit_depth into one
+ * contiguous [n][height][width] buffer (pageable or pinned). */
+int r3d_png_gray_info(const char* path, int* height, int* width, int* bit_depth);
+int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out, int height, int width, int bit_depth);
+
 /* ---- f2: occupied-voxel set + OctoMap binary export.  Replaces the per-point tree.updateNode(xyz, True) loop,
  * updateInnerOccupancy() and writeBinary() of octomap/txt_transfer_octomap.py:16-36 and
  * octomap/ply_transfer_octomap.py:16-48 (arithmetic in the un-vendored OctoMap library; restated from its
