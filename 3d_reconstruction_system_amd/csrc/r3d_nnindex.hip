@@ -432,7 +432,8 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
     r3d_nn_index_destroy(ix);
     return r3d_fail_hip(e, "nn index setup", __FILE__, __LINE__);
   }
-  int blocks = (int)std::min<int64_t>((n_tgt + kThreads - 1) / kThreads, (int64_t)ctx->num_cus * 8);
+  // few workgroups: every wave ends with six same-address atomics
+  int blocks = (int)std::min<int64_t>((n_tgt + kThreads - 1) / kThreads, (int64_t)ctx->num_cus);
   hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(kThreads), 0, st, ix->d_tgt, n_tgt, box6);
   hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(64), 0, st, box6, ix->axis_bits, ix->d_frame);
   rc = sorted_keys(ctx, ix->d_tgt, n_tgt, ix->d_frame, ix->axis_bits, ix->idx_bits, (uint64_t*)keys, (uint64_t*)tmp);
