@@ -67,7 +67,8 @@ SIGNATURES = {
     "r3d_icp_nn_host": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "r3d_nn_index_create": (_i, [_vp, _vp, _i64, _pvp]),
     "r3d_nn_index_destroy": (_i, [_vp]),
-    "r3d_nn_index_query": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "r3d_nn_index_query": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
+    "r3d_nn_index_sort_cloud": (_i, [_vp, _vp, _i64, _vp]),
     "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),
     "r3d_format_ply": (_i, [_vp, _i, _i64, _vp, _sz, _psz]),
     "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),

@@ -168,9 +168,12 @@ __global__ __launch_bounds__(kThreads) void tile_box_kernel(const float4* __rest
 }
 
 // ---- query -------------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(kThreads) void nn_cull_kernel(const float4* __restrict__ src4, int64_t n_src,
-                                                           const uint64_t* __restrict__ src_keys, int src_idx_bits,
+// SRC4: sources come as float4 (x, y, z, original index) in sorted order (one-off queries sort a copy);
+// otherwise plain xyz whose order the caller keeps spatially coherent (r3d_nn_index_sort_cloud) -- results
+// then land at the same positions.
+template <int S, bool SRC4>
+__global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restrict__ src_any, int64_t n_src,
+                                                           const float* __restrict__ frame, int axis_bits,
                                                            const float4* __restrict__ tgt4, int64_t n_tgt, int64_t n_tiles,
                                                            const float* __restrict__ tile_box,
                                                            const float* __restrict__ sub_box,
@@ -192,15 +195,20 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const float4* __restr
   for (int s = 0; s < S; ++s) {
     const int64_t i = s_base + (int64_t)s * kThreads + tid;
     ok[s] = i < n_src;
-    const float4 p = ok[s] ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    sx[s] = p.x; sy[s] = p.y; sz[s] = p.z;
+    if (SRC4) {
+      const float4 p = ok[s] ? static_cast<const float4*>(src_any)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      sx[s] = p.x; sy[s] = p.y; sz[s] = p.z;
+    } else {
+      const P3 p = ok[s] ? static_cast<const P3*>(src_any)[i] : P3{0.f, 0.f, 0.f};
+      sx[s] = p.x; sy[s] = p.y; sz[s] = p.z;
+    }
     best[s] = INFINITY;
     best_group[s] = 0;
     tie[s] = false;
   }
   if (tid == 0) {
     // tile whose Morton range holds this workgroup's first source: last tile with first code <= code
-    const uint64_t code = src_keys[s_base] >> src_idx_bits;
+    const uint64_t code = point_code(P3{sx[0], sy[0], sz[0]}, frame, axis_bits);
     int64_t lo = 0, hi = n_tiles;  // answer in [lo, hi)
     while (hi - lo > 1) {
       const int64_t mid = (lo + hi) >> 1;
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const float4* __restr
   for (int s = 0; s < S; ++s) {
     const int64_t i = s_base + (int64_t)s * kThreads + tid;
     if (!ok[s]) continue;
-    const uint32_t orig = __float_as_uint(src4[i].w);
+    const uint32_t orig = SRC4 ? __float_as_uint(static_cast<const float4*>(src_any)[i].w) : (uint32_t)i;
     const int64_t g0 = (int64_t)best_group[s] * kGroup;
     uint32_t found = 0xffffffffu;
     for (int k = 0; k < kGroup; ++k) {
@@ -458,7 +466,7 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
 }
 
 int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                       int64_t* h_tiles_swept) {
+                       int presorted, int64_t* h_tiles_swept) {
   R3D_REQUIRE(ix != nullptr, "nn index is NULL");
   r3d_ctx* ctx = ix->ctx;
   int rc = r3d_ctx_enter(ctx);
@@ -468,19 +476,21 @@ int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint
   if (n_src == 0) return R3D_OK;
   R3D_REQUIRE(n_src < ((int64_t)1 << 32), "source cloud too large");
   R3D_REQUIRE(d_src && d_idx_out, "NULL device pointer");
-  const int src_idx_bits = bits_for(n_src);
-  const int axis_bits = ix->axis_bits;
-  void *keys = nullptr, *tmp = nullptr, *src4 = nullptr, *misc = nullptr;
-  if ((rc = r3d_scratch(ctx, 0, (size_t)n_src * 8, &keys))) return rc;
-  if ((rc = r3d_scratch(ctx, 2, (size_t)n_src * 8, &tmp))) return rc;
-  if ((rc = r3d_scratch(ctx, 1, (size_t)n_src * sizeof(float4), &src4))) return rc;
-  if ((rc = r3d_scratch(ctx, 5, (size_t)n_src * 4 + 64, &misc))) return rc;
   hipStream_t st = ctx->stream;
-  // source keys use the index's quantisation frame, so source and tile codes are directly comparable
-  if ((rc = sorted_keys(ctx, d_src, n_src, ix->d_frame, axis_bits, src_idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) return rc;
-  hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_src + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_src,
-                     (const uint64_t*)keys, n_src, n_src, src_idx_bits, (float4*)src4);
-  unsigned long long* stats = static_cast<unsigned long long*>(misc);       // [0] tile sweeps
+  void *src4 = nullptr, *misc = nullptr;
+  if (!presorted) {
+    // one-off query: sort a float4 copy of the sources into index order (results are scattered back by index)
+    const int src_idx_bits = bits_for(n_src);
+    void *keys = nullptr, *tmp = nullptr;
+    if ((rc = r3d_scratch(ctx, 0, (size_t)n_src * 8, &keys))) return rc;
+    if ((rc = r3d_scratch(ctx, 2, (size_t)n_src * 8, &tmp))) return rc;
+    if ((rc = r3d_scratch(ctx, 1, (size_t)n_src * sizeof(float4), &src4))) return rc;
+    if ((rc = sorted_keys(ctx, d_src, n_src, ix->d_frame, ix->axis_bits, src_idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) return rc;
+    hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_src + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_src,
+                       (const uint64_t*)keys, n_src, n_src, src_idx_bits, (float4*)src4);
+  }
+  if ((rc = r3d_scratch(ctx, 5, (size_t)n_src * 4 + 64, &misc))) return rc;
+  unsigned long long* stats = static_cast<unsigned long long*>(misc);  // [0] tile sweeps
   unsigned* tie_count = reinterpret_cast<unsigned*>(stats + 2);
   uint32_t* tie_list = reinterpret_cast<uint32_t*>(stats + 4);
   R3D_HIP(hipMemsetAsync(misc, 0, 32, st));
@@ -488,14 +498,19 @@ int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint
   if (S != 1 && S != 2 && S != 4) S = 1;
   const int64_t per_block = (int64_t)kThreads * S;
   const unsigned blocks = (unsigned)((n_src + per_block - 1) / per_block);
-#define R3D_LAUNCH_CULL(SS)                                                                                            \
-  hipLaunchKernelGGL((nn_cull_kernel<SS>), dim3(blocks), dim3(kThreads), 0, st, (const float4*)src4, n_src,           \
-                     (const uint64_t*)keys, src_idx_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box, ix->d_sub_box,   \
-                     ix->d_tile_code,                                                                              \
-                     d_idx_out, d_d2_out, tie_list, tie_count, stats)
-  if (S == 1) R3D_LAUNCH_CULL(1);
-  else if (S == 2) R3D_LAUNCH_CULL(2);
-  else R3D_LAUNCH_CULL(4);
+#define R3D_LAUNCH_CULL(SS, FMT, PTR)                                                                                  \
+  hipLaunchKernelGGL((nn_cull_kernel<SS, FMT>), dim3(blocks), dim3(kThreads), 0, st, (const void*)(PTR), n_src,        \
+                     (const float*)ix->d_frame, ix->axis_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box,         \
+                     ix->d_sub_box, ix->d_tile_code, d_idx_out, d_d2_out, tie_list, tie_count, stats)
+  if (presorted) {
+    if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
+    else if (S == 2) R3D_LAUNCH_CULL(2, false, d_src);
+    else R3D_LAUNCH_CULL(4, false, d_src);
+  } else {
+    if (S == 1) R3D_LAUNCH_CULL(1, true, src4);
+    else if (S == 2) R3D_LAUNCH_CULL(2, true, src4);
+    else R3D_LAUNCH_CULL(4, true, src4);
+  }
 #undef R3D_LAUNCH_CULL
   hipLaunchKernelGGL(nn_tie_fallback_kernel, dim3(ctx->num_cus * 4), dim3(64), 0, st, d_src, ix->d_tgt, ix->n, tie_list,
                      tie_count, d_idx_out, d_d2_out);
@@ -506,6 +521,38 @@ int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint
     R3D_HIP(hipStreamSynchronize(st));
     *h_tiles_swept = (int64_t)v;
   }
+  return R3D_OK;
+}
+
+// gathers xyz rows by the index part of sorted keys
+__global__ __launch_bounds__(kThreads) void gather3_kernel(const float* __restrict__ xyz, const uint64_t* __restrict__ keys,
+                                                           int64_t n, int idx_bits, float* __restrict__ out,
+                                                           uint32_t* __restrict__ perm) {
+  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = (uint32_t)(keys[j] & (((uint64_t)1 << idx_bits) - 1));
+  reinterpret_cast<P3*>(out)[j] = reinterpret_cast<const P3*>(xyz)[i];
+  if (perm) perm[j] = i;
+}
+
+int r3d_nn_index_sort_cloud(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t* d_perm_out) {
+  R3D_REQUIRE(ix != nullptr, "nn index is NULL");
+  r3d_ctx* ctx = ix->ctx;
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n >= 0 && n < ((int64_t)1 << 32), "bad cloud size");
+  if (n == 0) return R3D_OK;
+  R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
+  const int idx_bits = bits_for(n);
+  void *keys = nullptr, *tmp = nullptr, *copy = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, (size_t)n * 8, &keys))) return rc;
+  if ((rc = r3d_scratch(ctx, 2, (size_t)n * 8, &tmp))) return rc;
+  if ((rc = r3d_scratch(ctx, 1, (size_t)n * 12, &copy))) return rc;
+  if ((rc = sorted_keys(ctx, d_xyz, n, ix->d_frame, ix->axis_bits, idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) return rc;
+  R3D_HIP(hipMemcpyAsync(copy, d_xyz, (size_t)n * 12, hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(gather3_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                     (const float*)copy, (const uint64_t*)keys, n, idx_bits, d_xyz, d_perm_out);
+  R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
 

@@ -48,11 +48,14 @@ class NNIndex:
         L.check(ctx.lib.r3d_nn_index_create(ctx.handle, d_tgt_ptr, int(n_tgt), C.byref(h)))
         self.handle = h.value
 
-    def query(self, d_src_ptr, n_src, d_idx_ptr, d_d2_ptr, want_stats=False):
+    def query(self, d_src_ptr, n_src, d_idx_ptr, d_d2_ptr, want_stats=False, presorted=False):
         swept = C.c_int64()
         L.check(self.ctx.lib.r3d_nn_index_query(self.handle, d_src_ptr, int(n_src), d_idx_ptr, d_d2_ptr,
-                                                C.byref(swept) if want_stats else None))
+                                                1 if presorted else 0, C.byref(swept) if want_stats else None))
         return swept.value
+
+    def sort_cloud(self, d_xyz_ptr, n, d_perm_ptr=None):
+        L.check(self.ctx.lib.r3d_nn_index_sort_cloud(self.handle, d_xyz_ptr, int(n), d_perm_ptr))
 
     def close(self):
         if self.handle:
@@ -85,11 +88,17 @@ class IcpDevice:
         self.d_idx = c.alloc(max(self.n * 4, 16))
         self.d_d2 = c.alloc(max(self.n * 4, 16))
         self.index = NNIndex(c, self.d_tgt.ptr, self.m) if culled else None
+        self.d_perm = None
+        if self.index is not None and self.n:
+            # put the source cloud into the index's Morton order ONCE: rigid / similarity moves keep every
+            # workgroup's 256 sources a compact blob, so no later query needs to sort.  d_perm maps back.
+            self.d_perm = c.alloc(self.n * 4)
+            self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
 
     def nn(self, want_stats=False):
         c = self.ctx
         if self.index is not None:
-            return self.index.query(self.d_src.ptr, self.n, self.d_idx.ptr, self.d_d2.ptr, want_stats)
+            return self.index.query(self.d_src.ptr, self.n, self.d_idx.ptr, self.d_d2.ptr, want_stats, presorted=True)
         L.check(c.lib.r3d_icp_nn(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
                                  self.d_d2.ptr))
         return 0
@@ -106,19 +115,30 @@ class IcpDevice:
         T = np.ascontiguousarray(T, dtype=np.float64)
         L.check(c.lib.r3d_apply_T(c.handle, self.d_src.ptr, L.F32, self.n, T.ctypes.data, self.d_src.ptr, L.F32))
 
+    def _unpermute(self, a):
+        if self.d_perm is None:
+            return a
+        perm = self.d_perm.download(np.uint32, self.n)
+        out = np.empty_like(a)
+        out[perm] = a
+        return out
+
     def download(self):
+        """(idx, d2) in the ORIGINAL source order."""
         idx = self.d_idx.download(np.uint32, self.n)
         d2 = self.d_d2.download(np.float32, self.n)
-        return idx, d2
+        return self._unpermute(idx), self._unpermute(d2)
 
     def source(self):
-        return self.d_src.download(np.float32, self.n * 3).reshape(-1, 3)
+        """Current source cloud in the original order."""
+        return self._unpermute(self.d_src.download(np.float32, self.n * 3).reshape(-1, 3))
 
     def free(self):
         if self.index is not None:
             self.index.close()
-        for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2):
-            b.free()
+        for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2, self.d_perm):
+            if b is not None:
+                b.free()
 
 
 def nearest_neighbours(src, tgt, ctx=None, culled=False):

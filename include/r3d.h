@@ -148,8 +148,15 @@ int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float
 typedef struct r3d_nn_index r3d_nn_index;
 int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_index** index_out);
 int r3d_nn_index_destroy(r3d_nn_index* index);
+/* presorted = 0: the call sorts a copy of the sources into index order itself (any source order is fine).
+ * presorted = 1: the caller keeps the sources spatially coherent -- r3d_nn_index_sort_cloud once, then rigid /
+ * similarity moves of the whole cloud (ICP) preserve it -- and the sort is skipped.  Results are the same either way
+ * and always land at the source's position in d_src. */
 int r3d_nn_index_query(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                       int64_t* h_tiles_swept);
+                       int presorted, int64_t* h_tiles_swept);
+/* Permutes an xyz cloud in place into the index's Morton order; d_perm_out (optional, [n] uint32) receives the original
+ * position of every row.  Asynchronous on the ctx stream. */
+int r3d_nn_index_sort_cloud(r3d_nn_index* index, float* d_xyz, int64_t n_points, uint32_t* d_perm_out);
 /* r3d_icp_accumulate: the 18 fp64 sums Umeyama needs over the matched pairs (p=src[k], q=tgt[idx[k]]),
  * pairs with d2 > max_d2 skipped when max_d2 >= 0 (d_d2 may be NULL when max_d2 < 0):
  *   sums[0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p_a*q_b (a major), [16]=sum |p|^2, [17]=sum |q|^2.

@@ -85,6 +85,35 @@ def test_culled_equals_brute_force_bitwise(icp, ctx, n, m, shape):
     assert swept < 0.35 * n_tiles * n_groups, (swept, n_tiles * n_groups)
 
 
+def test_index_query_unsorted_sources_and_permutation(icp, ctx):
+    """The stateless path (presorted=0: the query sorts a copy itself) and the in-place sort + permutation."""
+    rng = np.random.default_rng(31)
+    tgt = (rng.random((30000, 3)) * 10).astype(np.float32)
+    src = (rng.random((7000, 3)) * 10).astype(np.float32)
+    want_i, want_d = OI.nearest_neighbours(src, tgt)
+    d_tgt = ctx.alloc(tgt.nbytes).upload(tgt)
+    d_src = ctx.alloc(src.nbytes).upload(src)
+    d_idx, d_d2 = ctx.alloc(src.shape[0] * 4), ctx.alloc(src.shape[0] * 4)
+    ix = icp.NNIndex(ctx, d_tgt.ptr, tgt.shape[0])
+    ix.query(d_src.ptr, src.shape[0], d_idx.ptr, d_d2.ptr, presorted=False)
+    np.testing.assert_array_equal(d_idx.download(np.uint32, src.shape[0]), want_i)
+    np.testing.assert_allclose(d_d2.download(np.float32, src.shape[0]), want_d, rtol=2e-7)
+    # a deliberately incoherent order still gives the right answer with presorted=1 (only slower)
+    ix.query(d_src.ptr, src.shape[0], d_idx.ptr, d_d2.ptr, presorted=True)
+    np.testing.assert_array_equal(d_idx.download(np.uint32, src.shape[0]), want_i)
+    d_perm = ctx.alloc(src.shape[0] * 4)
+    ix.sort_cloud(d_src.ptr, src.shape[0], d_perm.ptr)
+    perm = d_perm.download(np.uint32, src.shape[0])
+    assert sorted(perm.tolist()) == list(range(src.shape[0]))
+    np.testing.assert_array_equal(d_src.download(np.float32, src.size).reshape(-1, 3), src[perm])
+    swept = ix.query(d_src.ptr, src.shape[0], d_idx.ptr, d_d2.ptr, want_stats=True, presorted=True)
+    np.testing.assert_array_equal(d_idx.download(np.uint32, src.shape[0]), want_i[perm])
+    assert swept < 0.5 * (-(-src.shape[0] // 256)) * (-(-tgt.shape[0] // 1024))
+    ix.close()
+    for b in (d_tgt, d_src, d_idx, d_d2, d_perm):
+        b.free()
+
+
 def test_culled_cross_tile_ties_and_duplicates(icp, ctx):
     rng = np.random.default_rng(9)
     base = rng.integers(0, 6, (300, 3)).astype(np.float32)      # heavy duplication on an integer lattice
@@ -142,7 +171,7 @@ def test_known_correspondences_give_the_closed_form_answer(icp, ctx):
     """src is an exact similarity image (s=1.7, 10 deg, |t|=0.5: SURVEY C3) of a subset of tgt.  With the
     TRUE correspondences the 18 sums from the GPU must give (s, R, t) back to fp32 data precision."""
     src, tgt, T_true, pick = OI.synthetic_pair(n_tgt=6000, n_src=4000, s=1.7, angle_deg=10.0, t_norm=0.5)
-    dev = icp.IcpDevice(src, tgt, ctx)
+    dev = icp.IcpDevice(src, tgt, ctx, culled=False)      # keep the source order: d_idx is uploaded by hand
     dev.d_idx.upload(pick.astype(np.uint32))
     sums = dev.sums()
     dev.free()
