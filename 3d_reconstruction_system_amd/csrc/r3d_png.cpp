@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -81,8 +82,22 @@ inline int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// decode one grey PNG into out (row-major, H*W samples of bits/8 bytes, host byte order)
+int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg);
+
+// decode one grey PNG into out (row-major, H*W samples of bits/8 bytes, host byte order); never throws
 int decode_gray(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
+  try {
+    return decode_gray_impl(path, out, cap_bytes, h_out, w_out, bits_out, msg);
+  } catch (const std::exception& e) {
+    try {
+      *msg = std::string("'") + path + "': " + e.what();
+    } catch (...) {
+    }
+    return R3D_ERR_NOMEM;
+  }
+}
+
+int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
   PngInfo info;
   std::vector<unsigned char> idat;
   int rc = read_png(path, &info, &idat, msg);
@@ -90,6 +105,10 @@ int decode_gray(const char* path, void* out, size_t cap_bytes, int* h_out, int* 
   if (h_out) *h_out = (int)info.height;
   if (w_out) *w_out = (int)info.width;
   if (bits_out) *bits_out = info.bit_depth;
+  if (info.width == 0 || info.height == 0 || info.width > (1u << 20) || info.height > (1u << 20)) {
+    *msg = std::string("'") + path + "': implausible PNG dimensions";
+    return R3D_ERR_INVALID;
+  }
   if (info.colour_type != 0 || info.interlace != 0 || (info.bit_depth != 8 && info.bit_depth != 16)) {
     *msg = std::string("'") + path + "': only non-interlaced 8/16-bit greyscale PNGs are decoded natively";
     return R3D_ERR_UNSUPPORTED;

@@ -1,0 +1,88 @@
+// ASan/UBSan driver for the host-only translation units of the library (formatters, PNG decoder):
+//   g++ -std=c++17 -g -fsanitize=address,undefined -Iinclude tests/c/host_fuzz.cpp \
+//       3d_reconstruction_system_amd/csrc/r3d_format.cpp 3d_reconstruction_system_amd/csrc/r3d_png.cpp -lz -lpthread -o host_fuzz
+// (GPU sanitizers are not available on the pool; the host code is where unchecked buffers could hide.)
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "r3d.h"
+
+static char g_err[512];
+void r3d_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int main(int argc, char** argv) {
+  std::mt19937_64 rng(1);
+  // formatters on hostile values
+  std::vector<double> v;
+  const double special[] = {0.0, -0.0, 1e-320, 4.9e-324, 1.7976931348623157e308, -1.7976931348623157e308, INFINITY, -INFINITY,
+                            NAN, 0.00005, 0.00015, 1099511627775.99995, 1099511627776.0, 9.999949999e-5, 1e16, 1e-5, 123456789012345680.0};
+  for (double s : special) v.push_back(s);
+  for (int i = 0; i < 300000; ++i) {
+    uint64_t bits = rng();
+    double d;
+    memcpy(&d, &bits, 8);
+    v.push_back(d);
+  }
+  while (v.size() % 3) v.push_back(1.0);
+  const int64_t n = (int64_t)v.size() / 3;
+  size_t nb = 0;
+  if (r3d_format_ply(v.data(), R3D_F64, n, nullptr, 0, &nb) != R3D_OK) return 1;
+  std::vector<char> buf(nb);
+  if (r3d_format_ply(v.data(), R3D_F64, n, buf.data(), nb, &nb) != R3D_OK) return 1;
+  if (r3d_format_ply(v.data(), R3D_F64, n, buf.data(), nb - 1, &nb) != R3D_ERR_NOMEM) return 1;
+  if (r3d_format_xyz_txt(v.data(), R3D_F64, n, nullptr, 0, nullptr, 0, &nb) != R3D_OK) return 1;
+  buf.resize(nb);
+  if (r3d_format_xyz_txt(v.data(), R3D_F64, n, nullptr, 0, buf.data(), nb, &nb) != R3D_OK) return 1;
+  std::vector<float> vf(v.size());
+  for (size_t i = 0; i < v.size(); ++i) vf[i] = (float)v[i];
+  std::vector<unsigned char> rgb(v.size());
+  for (auto& c : rgb) c = (unsigned char)rng();
+  if (r3d_write_ply_rgb("/tmp/r3d_fuzz_rgb.ply", vf.data(), R3D_F32, rgb.data(), n) != R3D_OK) return 1;
+  if (r3d_write_ply("/tmp/r3d_fuzz.ply", vf.data(), R3D_F32, n) != R3D_OK) return 1;
+  std::vector<uint16_t> zraw((size_t)n);
+  for (auto& z : zraw) z = (uint16_t)rng();
+  if (r3d_write_xyz_txt("/tmp/r3d_fuzz.txt", vf.data(), R3D_F32, n, zraw.data(), R3D_DEPTH_U16, 0) != R3D_OK) return 1;
+  // PNG decoder on a valid file (argv[1]) and on corrupted copies of it
+  if (argc > 1) {
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    std::vector<unsigned char> png;
+    unsigned char tmp[4096];
+    size_t k;
+    while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) png.insert(png.end(), tmp, tmp + k);
+    fclose(f);
+    int h = 0, w = 0, bits = 0;
+    if (r3d_png_gray_info(argv[1], &h, &w, &bits) != R3D_OK) return 3;
+    std::vector<unsigned char> out((size_t)h * w * (bits / 8));
+    const char* one[1] = {argv[1]};
+    if (r3d_png_gray_decode_batch(one, 1, out.data(), h, w, bits) != R3D_OK) return 4;
+    int survived = 0;
+    for (int trial = 0; trial < 400; ++trial) {
+      std::vector<unsigned char> bad = png;
+      const int flips = 1 + (int)(rng() % 8);
+      for (int j = 0; j < flips; ++j) bad[rng() % bad.size()] = (unsigned char)rng();
+      if (trial % 7 == 0) bad.resize(rng() % bad.size());
+      FILE* g = fopen("/tmp/r3d_fuzz.png", "wb");
+      fwrite(bad.data(), 1, bad.size(), g);
+      fclose(g);
+      const char* p[1] = {"/tmp/r3d_fuzz.png"};
+      int hh = 0, ww = 0, bb = 0;
+      if (r3d_png_gray_info(p[0], &hh, &ww, &bb) == R3D_OK && hh == h && ww == w && bb == bits)
+        survived += r3d_png_gray_decode_batch(p, 1, out.data(), h, w, bits) == R3D_OK;
+    }
+    printf("corrupted PNG trials decoded without error: %d of 400 (no crash either way)\n", survived);
+  }
+  printf("host fuzz OK: %lld points formatted\n", (long long)n);
+  return 0;
+}

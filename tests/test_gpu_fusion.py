@@ -222,3 +222,38 @@ def test_full_size_c2_properties(R, ctx):
     zero_t = R.fuse_frames(d, q, np.zeros_like(t), out_dtype=np.float64, ctx=ctx).reshape(G, H * W, 3)
     lin = np.abs((twice - once) - zero_t)
     assert (lin / (1.0 + np.linalg.norm(zero_t, axis=2, keepdims=True))).max() <= 1e-12
+
+
+def test_c4_sized_batch_64bit_indexing(R, ctx):
+    """BASELINE config 4's per-node total on ONE GPU: 1000 frames of 1280x384 = 491,520,000 points, 5.9 GB of xyz in one
+    launch (byte offsets far beyond 2^32).  Frames are tiled copies of 8 distinct rasters with distinct poses; the first,
+    a middle and the last frame are checked against the oracle, and a per-frame checksum against per-frame launches."""
+    F, H, W, D = 1000, 384, 1280, 8
+    rng = np.random.default_rng(44)
+    base = rng.integers(1, 256, size=(D, H, W), dtype=np.uint8)
+    q = rng.normal(size=(F, 4))
+    t = rng.normal(size=(F, 3)) * 10
+    n = F * H * W
+    d_depth = ctx.alloc(n)
+    import ctypes as C
+    L = __import__("importlib").import_module(R.__name__ + "._lib")
+    for k in range(F):                      # upload frame by frame: the host never holds the 491 MB batch twice
+        fr = np.ascontiguousarray(base[k % D])
+        L.check(ctx.lib.r3d_memcpy_h2d(ctx.handle, d_depth.ptr + k * H * W, fr.ctypes.data, fr.nbytes))
+    ctx.sync()
+    tab = R.pose_table(q, t)
+    d_pose = ctx.alloc(tab.nbytes).upload(tab)
+    d_out = ctx.alloc(n * 12)
+    cam = ctx.camera(H, W, *R.REF_INTRINSICS)
+    R.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+    ctx.sync()
+    per = H * W
+    for k in (0, 499, 999):
+        got = np.empty((per, 3), np.float32)
+        L.check(ctx.lib.r3d_memcpy_d2h(ctx.handle, got.ctypes.data, d_out.ptr + k * per * 12, got.nbytes))
+        ctx.sync()
+        check(got, O.fuse_frames(base[k % D][None], q[k:k + 1], t[k:k + 1]), np.float32)
+        one = R.fuse_frames(base[k % D], q[k:k + 1], t[k:k + 1], out_dtype=np.float32, ctx=ctx)
+        np.testing.assert_array_equal(one, got)
+    for b in (d_depth, d_pose, d_out):
+        b.free()

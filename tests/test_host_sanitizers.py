@@ -1,0 +1,25 @@
+"""CPU: the host-only translation units (text formatters, PNG decoder) under AddressSanitizer + UBSan with hostile
+inputs (random bit patterns as doubles, corrupted PNG files).  GPU sanitizers are unavailable on the pool."""
+import os
+import subprocess
+
+import pytest
+
+from helpers import PKG, ROOT
+
+
+def test_host_code_is_clean_under_asan_ubsan(tmp_path, golden_dir):
+    exe = str(tmp_path / "host_fuzz")
+    src = os.path.join(ROOT, PKG, "csrc")
+    build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                            "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c", "host_fuzz.cpp"), os.path.join(src, "r3d_format.cpp"),
+                            os.path.join(src, "r3d_png.cpp"), "-lz", "-lpthread", "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe, os.path.join(golden_dir, "scene3", "depth", "000.png")], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "host fuzz OK" in run.stdout
