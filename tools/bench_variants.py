@@ -35,7 +35,7 @@ def bench_fuse(ctx, F, H, W, rounds, iters, odt=np.float32):
     configs = []
     for variant in (3, 5, 6, 7):
         for nt in (3,):
-            for blocks in (2048,):
+            for blocks in (2048, 4096):
 
                 configs.append((variant, nt, blocks))
     results = {c: [] for c in configs}
