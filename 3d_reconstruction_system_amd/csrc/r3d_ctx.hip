@@ -148,6 +148,7 @@ static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "nn_blocks")) return &ctx->nn_blocks;
   if (!strcmp(key, "apply_blocks")) return &ctx->apply_blocks;
   if (!strcmp(key, "apply_variant")) return &ctx->apply_variant;
+  if (!strcmp(key, "voxel_dedupe")) return &ctx->voxel_dedupe;
   return nullptr;
 }
 

@@ -65,9 +65,16 @@ __device__ __forceinline__ bool voxel_code(const P3& p, double factor, uint64_t*
   return true;
 }
 
+constexpr int kLdsSlots = 2048;  // per-workgroup dedupe table: 2x the 1024 points of a tile
+
+// DEDUPE: a workgroup first funnels its tile's 1024 codes through a small LDS hash set; only the first lane to
+// claim a code goes on to the global table.  Real clouds put tens to hundreds of points into one 10 cm voxel,
+// so this removes most of the scattered 64-bit global atomics (the kernel's bound) for the price of LDS atomics.
+template <bool DEDUPE>
 __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __restrict__ xyz, int64_t n, double factor,
                                                                 uint64_t* __restrict__ table, int log2cap,
                                                                 unsigned long long* __restrict__ counters) {
+  __shared__ unsigned long long local_set[DEDUPE ? kLdsSlots : 1];
   const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
   const int lane = threadIdx.x & 63;
   // statistics stay in registers and reach the three global counters once per wave: a per-insert
@@ -75,6 +82,11 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
   unsigned n_new = 0, n_ignored = 0, n_over = 0;
   const int64_t n_tiles = (n + kThreads * 4 - 1) / (kThreads * 4);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (DEDUPE) {
+      __syncthreads();  // the previous tile's lookups are done
+      for (int k = threadIdx.x; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
+      __syncthreads();
+    }
     const int64_t base = tile * (kThreads * 4) + threadIdx.x;
     P3 p[4];
 #pragma unroll
@@ -96,6 +108,22 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       // code leaves the insert to it
       const uint64_t prev = __shfl_up(code, 1, 64);
       if (live && lane > 0 && prev == code) live = false;
+      if (DEDUPE && live) {
+        uint32_t slot = (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
+        bool mine = false, done = false;
+        for (int probe = 0; probe < kLdsSlots && !done; ++probe) {
+          const unsigned long long old = atomicCAS(&local_set[slot], (unsigned long long)kEmpty, (unsigned long long)code);
+          if (old == kEmpty) {
+            mine = true;
+            done = true;
+          } else if (old == code) {
+            done = true;  // another lane of this tile already carries it to the global table
+          } else {
+            slot = (slot + 1) & (kLdsSlots - 1);
+          }
+        }
+        live = mine || !done;  // a full local table (cannot happen: 1024 codes, 2048 slots) would fall through
+      }
       if (live) {
         uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
         bool done = false;
@@ -363,8 +391,12 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
   int blocks = vs->ctx->num_cus * 8;
   if ((int64_t)blocks > n_tiles) blocks = (int)n_tiles;
-  hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, d_xyz, n_points, vs->factor,
-                     vs->d_table, vs->log2cap, vs->d_counters);
+  if (vs->ctx->voxel_dedupe != 1)  // 0 auto / 2 on: LDS dedupe; 1: off
+    hipLaunchKernelGGL(voxel_insert_kernel<true>, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, d_xyz, n_points,
+                       vs->factor, vs->d_table, vs->log2cap, vs->d_counters);
+  else
+    hipLaunchKernelGGL(voxel_insert_kernel<false>, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, d_xyz, n_points,
+                       vs->factor, vs->d_table, vs->log2cap, vs->d_counters);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

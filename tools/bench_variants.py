@@ -162,26 +162,33 @@ def bench_voxel(ctx, F, H, W, rounds):
     L = importlib.import_module("3d_reconstruction_system_amd._lib")
     rng = np.random.default_rng(1234)
     n = F * H * W
-    for label, hi in (("depth 1..255 (sparse: most points their own voxel)", 256), ("depth 1..15 (dense: many points per voxel)", 16)):
-        depth = rng.integers(1, hi, size=(F, H, W), dtype=np.uint8)
+    jj, ii = np.mgrid[0:H, 0:W]
+    smooth = np.clip(40 + 30 * np.sin(ii / 97.0) * np.cos(jj / 61.0), 1, 255).astype(np.uint8)   # surfaces, like a real depth map
+    for label, hi, scale in (("depth 1..255 random (sparse: most points their own voxel)", 256, 1.0),
+                             ("depth 1..15 random (about 4 points per voxel)", 16, 1.0),
+                             ("smooth surfaces, depth in 2 cm units (0.2-2 m: real indoor scale)", 0, 0.02)):
+        depth = rng.integers(1, hi, size=(F, H, W), dtype=np.uint8) if hi else np.broadcast_to(smooth, (F, H, W)).copy()
         table = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)))
         d_depth = ctx.alloc(n).upload(depth)
         d_pose = ctx.alloc(table.nbytes).upload(table)
         d_out = ctx.alloc(n * 12)
         cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
-        r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+        r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32, depth_scale=scale)
         vs = V.VoxelSet(0.1, 2 * n, ctx)
-        ts = []
-        for _ in range(rounds):
-            vs.clear()
-            ctx.sync()
-            ctx.timer_start()
-            vs.insert_device(d_out.ptr, n)
-            ts.append(ctx.timer_stop())
-        st = vs.stats()
-        med = np.median(ts)
-        print("voxel insert, %s: %.1f Mpts -> %d voxels, med %.3f ms, %.1f Gpts/s, %.1f GB/s at 12 B/pt"
-              % (label, n / 1e6, st["voxels"], med, n / med / 1e6, n * 12 / med / 1e6))
+        for dd in (1, 2):
+            ctx.set_tuning("voxel_dedupe", dd)
+            ts = []
+            for _ in range(rounds):
+                vs.clear()
+                ctx.sync()
+                ctx.timer_start()
+                vs.insert_device(d_out.ptr, n)
+                ts.append(ctx.timer_stop())
+            st = vs.stats()
+            med = np.median(ts)
+            print("voxel insert [%s], %s: %.1f Mpts -> %d voxels, med %.3f ms, %.1f Gpts/s, %.1f GB/s at 12 B/pt"
+                  % ("LDS dedupe" if dd == 2 else "direct    ", label, n / 1e6, st["voxels"], med, n / med / 1e6, n * 12 / med / 1e6))
+        ctx.set_tuning("voxel_dedupe", 0)
         import time
         t0 = time.perf_counter()
         codes = vs.codes()
