@@ -8,22 +8,22 @@
 // Roofline: HBM.  Algorithmic traffic 13 B/point for u8 depth + f32 xyz (1 read, 12 written);
 // 14 / 16 B for u16 / f32 depth; +12 B/point with f64 output.
 //
-// Layout and mapping
+// Layout and mapping (default kernel, "variant 5"; the others are kept selectable for A/B, all bit-identical)
 //   * depth is [F][H][W] contiguous, output is [F*H*W][3] AoS (12 B/point, not a power of two).
-//   * a TILE is 1024 consecutive pixels of one frame = one 256-thread workgroup, 4 pixels per
-//     lane: one 4-byte (u8) / 8-byte (u16) / 16-byte (f32) load per lane, 256 B..1 KiB per
-//     wave instruction, fully coalesced.
-//   * the lane's 4 points (48 B) are staged through LDS and leave as 3 x 16-B stores per lane at
-//     consecutive 16-B slots: every wave store instruction writes 1 KiB contiguous instead of 64
-//     16-B pieces 48 B apart.  Variant 4 (default) does this per WAVE with no workgroup barrier and
-//     with the next tile's depth load already in flight; variant 3 per workgroup with barriers;
-//     variant 2 stores the 48 B directly; variant 1 is the scalar any-width path.
-//   * the grid is capped (persistent-style) and strides over tiles; tile -> (frame, tile in
-//     frame) is advanced incrementally on the scalar unit, the per-frame pose (96 B) comes in
-//     through scalar loads, and the per-lane row/column split is one mulhi (magic division).
-//   * arithmetic: fp64 registers, the reference's evaluation order, -ffp-contract=off, one
-//     rounding to f32 on store.  fp64 VALU is ~4 cycles per wave instruction; ~19 of them per
-//     pixel keep the vector unit ~25 % busy at the HBM rate, so the kernel stays bandwidth-bound.
+//   * a TILE is 1024 consecutive pixels of one frame = one 256-thread workgroup.  Lane `tid` takes pixels
+//     tid, tid+256, tid+512, tid+768, so in every round a wave holds 64 CONSECUTIVE pixels: the read is one
+//     coalesced element per lane, the write ONE 12-byte nontemporal store per lane at a 12-byte lane stride =
+//     768 contiguous bytes per wave instruction.  No LDS, no barrier, ~30 VGPRs.
+//   * the grid is capped at 8 workgroups per CU and strides over tiles; tile -> (frame, tile in frame) and
+//     pixel -> (row, column) are magic-number divisions (host-computed), the per-frame pose (96 B) comes in
+//     through scalar loads (wave-uniform address, const __restrict__).
+//   * arithmetic: fp64 registers, the reference's evaluation order, -ffp-contract=off, one rounding on store.
+//     ~19 fp64 instructions per pixel keep the SIMDs ~40 % busy at the HBM rate; the kernel sits on the store
+//     stream (within 5-8 % of hipMemset for the same bytes; profiles/variants_r01.md).
+//   * variants: 1 scalar any-width (also the fallback for widths not divisible by 4 in variants 2-4);
+//     2 four pixels per lane, direct 48-byte stores; 3 four pixels per lane, LDS-transposed 16-byte stores per
+//     workgroup (default for f64 xyz, one tile per workgroup); 4 the same per wave, no barrier; 5 lane-per-pixel
+//     (default for f32 xyz); 6 lane-per-pixel with all loads batched; 7 lane-per-pixel with scalar tile bases.
 #include <type_traits>
 
 #include "r3d_internal.h"
