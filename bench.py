@@ -71,6 +71,77 @@ def pmc_traffic():
         return None
 
 
+def secondary(a):
+    """One JSON line for a secondary kernel (single GPU, HIP-event stopwatch of the library on its own stream)."""
+    r3d = importlib.import_module("3d_reconstruction_system_amd")
+    ctx = r3d.Context(0)
+    rng = np.random.default_rng(1234)
+
+    def timed(fn, iters):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(iters):
+            fn()
+        return ctx.timer_stop() / iters
+
+    if a.workload == "apply":
+        n = FRAMES_PER_GPU * H * W
+        d_in = ctx.alloc(n * 12).upload((rng.normal(size=(n, 3)) * 50).astype(np.float32))
+        d_out = ctx.alloc(n * 12)
+        T = np.eye(4)
+        T[:3, :3] *= 1.7
+        T[:3, 3] = (1, 2, 3)
+        ms = timed(lambda: r3d.apply_T_device(ctx, d_in.ptr, np.float32, n, T, d_out.ptr, np.float32), max(a.steps // 10, 20))
+        gbs = n * 24 / ms / 1e6
+        line = {"metric": "Mpoints/s apply-T (4x4 on a 49.2 Mpoint f32 cloud)", "value": round(n / ms / 1e3, 1), "unit": "Mpoints/s",
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "apply_lane_kernel<f32,f32>",
+                             "kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": n * 24}}
+    elif a.workload == "icp":
+        icp = importlib.import_module("3d_reconstruction_system_amd.icp")
+        m = 500000
+        tgt = (rng.random((m, 3)) * 20).astype(np.float32)
+        src = (tgt[rng.permutation(m)] * 1.01 + 0.02).astype(np.float32)
+        dev_b = icp.IcpDevice(src, tgt, ctx, culled=False)
+        ms_b = timed(dev_b.nn, 3)
+        dev_b.free()
+        dev_c = icp.IcpDevice(src, tgt, ctx, culled=True)
+        ms_c = timed(dev_c.nn, 20)
+        dev_c.free()
+        tf = m * m * 8 / ms_b / 1e9
+        line = {"metric": "ICP nearest neighbour, 500k x 500k points (C3)", "value": round(m / ms_c / 1e3, 1),
+                "unit": "Mqueries/s (culled exact NN)", "culled_ms": round(ms_c, 4), "bruteforce_ms": round(ms_b, 3),
+                "roofline": {"bound": "valu", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                             "traffic": None, "kernel": "nn_kernel<4> (brute force, 8 flop/pair)", "kernel_ms": round(ms_b, 3)}}
+    else:
+        V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
+        F = FRAMES_PER_GPU
+        n = F * H * W
+        depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
+        tab = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)))
+        d_depth, d_pose, d_xyz = ctx.alloc(n).upload(depth), ctx.alloc(tab.nbytes).upload(tab), ctx.alloc(n * 12)
+        cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
+        r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
+        vs = V.VoxelSet(0.1, 2 * n, ctx)
+
+        def both():
+            vs.clear()
+            vs.insert_device(d_xyz.ptr, n)
+        ms = timed(both, 10) - timed(vs.clear, 10)
+        both()
+        st = vs.stats()
+        line = {"metric": "Mpoints/s voxel insert (C2 cloud, 0.1 m, worst case ~1 voxel per point)", "value": round(n / ms / 1e3, 1),
+                "unit": "Mpoints/s", "voxels": st["voxels"], "kernel_ms": round(ms, 4),
+                "roofline": {"bound": "scattered 64-bit atomics", "achieved": round(st["voxels"] / ms / 1e6, 2), "peak": 19.1,
+                             "unit": "Ginserts/s", "frac": round(st["voxels"] / ms / 1e6 / 19.1, 4), "traffic": None,
+                             "kernel": "voxel_insert_kernel"}}
+    line.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic", "dtype": "f64" if a.workload == "apply" else "f32",
+                 "config": {"workload": a.workload}})
+    print(json.dumps(line), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +154,12 @@ def main():
                          "'outputs' = fuse own frames then all-gather xyz (12 B/point over xGMI); 'none' = shards stay put")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel"],
+                    help="fuse (default, the headline C2 line); the others print one JSON line for a secondary kernel on "
+                         "one GPU: apply = 4x4 apply on the C2 cloud, icp = C3 (two 500k clouds), voxel = occupancy insert")
     a = ap.parse_args()
+    if a.workload != "fuse":
+        return secondary(a)
 
     import torch
     import torch.distributed as dist
