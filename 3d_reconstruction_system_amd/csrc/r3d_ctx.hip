@@ -112,17 +112,18 @@ int r3d_ctx_create(int device, void* stream, int flags, r3d_ctx** ctx_out) {
 
 int r3d_ctx_destroy(r3d_ctx* ctx) {
   if (!ctx) return R3D_OK;
-  hipSetDevice(ctx->device);
-  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  // teardown is best effort: every call below may legitimately fail once the device is gone
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < r3d_ctx::kScratchSlots; ++i)
-    if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   for (int i = 0; i < 4; ++i)
-    if (ctx->pinned[i]) hipHostFree(ctx->pinned[i]);
+    if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
   for (int i = 0; i < 2; ++i)
-    if (ctx->ev_pipe[i]) hipEventDestroy(ctx->ev_pipe[i]);
-  if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
-  if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->ev_pipe[i]) (void)hipEventDestroy(ctx->ev_pipe[i]);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return R3D_OK;
 }
@@ -274,9 +275,9 @@ int r3d_camera_create(r3d_ctx* ctx, int height, int width, double fx, double fy,
 
 int r3d_camera_destroy(r3d_camera* cam) {
   if (!cam) return R3D_OK;
-  if (cam->ctx) hipSetDevice(cam->ctx->device);
-  if (cam->d_u) hipFree(cam->d_u);
-  if (cam->d_v) hipFree(cam->d_v);
+  if (cam->ctx) (void)hipSetDevice(cam->ctx->device);
+  if (cam->d_u) (void)hipFree(cam->d_u);
+  if (cam->d_v) (void)hipFree(cam->d_v);
   delete cam;
   return R3D_OK;
 }

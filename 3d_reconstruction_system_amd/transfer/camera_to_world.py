@@ -44,6 +44,31 @@ def point_camera(p1, r_inverse, t):
     return np.array(p_world.T)
 
 
+def read_pfm(path):
+    """Portable Float Map -> float32 array (what cv.imread returns for a .pfm): 'Pf'/'PF' header, width height,
+    scale (negative = little endian), rows stored bottom-up."""
+    with open(path, 'rb') as f:
+        kind = f.readline().strip()
+        if kind not in (b'Pf', b'PF'):
+            raise ValueError("%s is not a PFM file" % path)
+        w, h = [int(v) for v in f.readline().split()]
+        scale = float(f.readline().strip())
+        ch = 3 if kind == b'PF' else 1
+        data = np.frombuffer(f.read(w * h * ch * 4), dtype='<f4' if scale < 0 else '>f4').astype(np.float32)
+    img = data.reshape(h, w, ch)[::-1]
+    return np.ascontiguousarray(img[:, :, ::-1] if ch == 3 else img[:, :, 0])      # colour: BGR like OpenCV
+
+
+def sfm2npy(transfer_name):
+    """./pfm/<name>.pfm -> ./npy/<name>.npy (c2w:32-38; a COLMAP/MVS depth map converter, not on the fusion path)."""
+    pfm_path = './pfm/' + transfer_name + '.pfm'
+    npy_path = './npy/' + transfer_name + '.npy'
+    mat = read_pfm(pfm_path)
+    print(type(mat))
+    np.save(npy_path, mat)
+    return npy_path
+
+
 # ---- conversion functions (c2w:67-105) -------------------------------------------------------
 def gentxtcord(filename, depth):
     """Camera-frame `X,Y,Z` text of one raster (c2w:67-83).  Returns None like the reference."""

@@ -162,3 +162,17 @@ def test_coloured_ply_matches_reference_bytes(R, golden_dir, tmp_path):
     assert (tmp_path / "c32.ply").read_bytes() == want          # these values survive the f32 round trip at 4 decimals
     with pytest.raises(ValueError):
         R.cloud_io.write_ply_rgb(str(tmp_path / "bad.ply"), cam, rgb[:5])
+
+
+def test_sfm2npy_helper(tmp_path, monkeypatch):
+    """c2w:32-38 surface completeness: PFM (bottom-up float rows) -> npy."""
+    c2w = importlib.import_module(PKG + ".transfer.camera_to_world")
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("pfm")
+    os.makedirs("npy")
+    img = np.arange(12, dtype=np.float32).reshape(3, 4) / 7
+    with open("pfm/a.pfm", "wb") as f:
+        f.write(b"Pf\n4 3\n-1.0\n")
+        f.write(img[::-1].astype("<f4").tobytes())
+    assert c2w.sfm2npy("a") == "./npy/a.npy"
+    np.testing.assert_array_equal(np.load("npy/a.npy"), img)
