@@ -223,6 +223,36 @@ def main():
         json.dump(g6, f, indent=1)
     shutil.rmtree(c1)
 
+    # ---- G7: camera_to_world.main() on 2 frames of 192x640 (config C1 size): digests of every file it writes ----
+    big = os.path.join("/tmp", "r3d_golden_c1scene")
+    shutil.rmtree(big, ignore_errors=True)
+    for d in ("depth", "camera_pose", "point", "point_world", "ply"):
+        os.makedirs(os.path.join(big, d))
+    rng = np.random.default_rng(77)
+    lines = ["id,tx,ty,tz,qx,qy,qz,qw,name,tail\n"]
+    g7 = {"seed": 77, "shape": [192, 640], "frames": []}
+    for k in range(2):
+        depth = rng.integers(0, 256, size=(192, 640), dtype=np.uint8)
+        name = "c1_%d.png" % k
+        Image.fromarray(depth, mode="L").save(os.path.join(big, "depth", name))
+        q = rng.normal(size=4)
+        t = rng.normal(size=3) * 10
+        g7["frames"].append({"name": name, "q": [float(v) for v in q], "t": [float(v) for v in t]})
+        lines.append("%d,%r,%r,%r,%r,%r,%r,%r,%s,x\n" % ((k,) + tuple(float(v) for v in t) + tuple(float(v) for v in q) + (name,)))
+    with open(os.path.join(big, "camera_pose", "image_colmap_simi_2.txt"), "w") as f:
+        f.writelines(lines)
+    with chdir(big), contextlib.redirect_stdout(io.StringIO()):
+        c2w.main()
+    g7["gen"] = "per frame: default_rng(77) stream: integers(0,256,(192,640),uint8), normal(4), normal(3)*10"
+    g7["sha256_ply"] = sha256_file(os.path.join(big, "ply", "small_035_p8.ply"))
+    g7["sha256_point"] = {fr["name"]: sha256_file(os.path.join(big, "point", fr["name"][:-4] + ".txt")) for fr in g7["frames"]}
+    world = np.loadtxt(os.path.join(big, "point_world", "small_worldpoint_5_23_5.txt"), delimiter=",")
+    g7["world_last_frame_sum"] = [float(v) for v in world.sum(0)]
+    g7["world_last_frame_rows"] = {str(k): [float(v) for v in world[k]] for k in (0, 1, 61439, 122879)}
+    with open(os.path.join(HERE, "c1_scene_2x192x640.json"), "w") as f:
+        json.dump(g7, f, indent=1)
+    shutil.rmtree(big)
+
     # ---- manifest ----
     manifest = {}
     for root, _, files in os.walk(HERE):

@@ -138,3 +138,32 @@ def test_transfer_T_icp_estimate_recovers_transform(tmp_path):
     np.testing.assert_allclose(T, T_true, rtol=0, atol=5e-4)
     merged = R.cloud_io.read_ply(str(tmp_path / "ply" / "icp" / "024.ply"))
     assert merged.shape == (5500, 3)
+
+
+def test_camera_to_world_script_c1_scene_digests(tmp_path, golden_dir):
+    """245,760 points (2 frames of 640x192): the drop-in's PLY and camera txt files hash to what the reference wrote."""
+    import hashlib
+    import json
+    from PIL import Image
+    g = json.load(open(os.path.join(golden_dir, "c1_scene_2x192x640.json")))
+    for d in ("depth", "camera_pose", "point", "point_world", "ply"):
+        os.makedirs(tmp_path / d)
+    rng = np.random.default_rng(g["seed"])
+    lines = ["id,tx,ty,tz,qx,qy,qz,qw,name,tail\n"]
+    for k, fr in enumerate(g["frames"]):
+        depth = rng.integers(0, 256, size=tuple(g["shape"]), dtype=np.uint8)
+        Image.fromarray(depth, mode="L").save(tmp_path / "depth" / fr["name"])
+        q, t = rng.normal(size=4), rng.normal(size=3) * 10
+        assert [float(v) for v in q] == fr["q"] and [float(v) for v in t] == fr["t"]
+        lines.append("%d,%r,%r,%r,%r,%r,%r,%r,%s,x\n" % ((k,) + tuple(float(v) for v in t) + tuple(float(v) for v in q)
+                                                        + (fr["name"],)))
+    (tmp_path / "camera_pose" / "image_colmap_simi_2.txt").write_text("".join(lines))
+    run_script("transfer/camera_to_world.py", str(tmp_path))
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    for fr in g["frames"]:
+        assert sha(tmp_path / "point" / (fr["name"][:-4] + ".txt")) == g["sha256_point"][fr["name"]]
+    assert sha(tmp_path / "ply" / "small_035_p8.ply") == g["sha256_ply"]
+    world = O.read_xyz_txt(str(tmp_path / "point_world" / "small_worldpoint_5_23_5.txt"))
+    for k, row in g["world_last_frame_rows"].items():
+        np.testing.assert_allclose(world[int(k)], row, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(world.sum(0), g["world_last_frame_sum"], rtol=1e-11)

@@ -22,7 +22,7 @@ def kat_depth(h, w):
 
 def test_manifest_intact(golden_dir):
     man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["files"]
-    assert len(man) >= 19
+    assert len(man) >= 22
     for rel, digest in man.items():
         assert _sha(os.path.join(golden_dir, rel)) == digest, rel
 
