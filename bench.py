@@ -179,8 +179,14 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # R3D_BENCH_FORCE_COLLECTIVES=1 runs the N>1 code path (process group, assembly step) even with one rank:
+    # a rehearsal of the RCCL calls on a single-GPU box
+    use_dist = world > 1 or os.environ.get("R3D_BENCH_FORCE_COLLECTIVES", "0") not in ("", "0")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -200,7 +206,7 @@ def main():
     out_np = np.float32 if a.out_dtype == "float32" else np.float64
     out_t = torch.float32 if a.out_dtype == "float32" else torch.float64
     n_local = F * H * W
-    mode = a.assemble if world > 1 else "none"
+    mode = a.assemble if use_dist else "none"
     full = shard = depth_all = pose_all = None
     if mode == "none":
         shard = torch.empty((n_local, 3), dtype=out_t, device=dev)
@@ -232,7 +238,7 @@ def main():
     step = make_step(mode)
 
     def fence():
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.barrier(device_ids=[dev_index])
             else:
@@ -250,7 +256,7 @@ def main():
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -271,7 +277,7 @@ def main():
 
     # N > 1: the other assembly strategies, timed briefly after the main region (reported, not `value`)
     assemble_ms = {}
-    if world > 1:
+    if use_dist:
         for m in ("none", "outputs", "inputs"):
             if m == mode or (m != "none" and full is None):
                 continue
@@ -328,7 +334,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         fence()
         dist.destroy_process_group()
     ctx.close()
