@@ -257,3 +257,27 @@ def test_c4_sized_batch_64bit_indexing(R, ctx):
         np.testing.assert_array_equal(one, got)
     for b in (d_depth, d_pose, d_out):
         b.free()
+
+
+def test_pinned_and_preallocated_outputs(R, ctx):
+    rng = np.random.default_rng(12)
+    d = make_depth(rng, (37, 120, 160), np.uint8)              # 37 frames: several pipeline chunks, ragged last chunk
+    q = rng.normal(size=(37, 4))
+    t = rng.normal(size=(37, 3)) * 10
+    want = R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx)
+    check(want, O.fuse_frames(d, q, t), np.float32)
+    pin = ctx.pinned_empty(want.shape, np.float32)
+    got = R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx, out=pin)
+    assert got is pin
+    np.testing.assert_array_equal(pin, want)
+    pre = np.zeros(want.shape, np.float32)
+    R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx, out=pre)
+    np.testing.assert_array_equal(pre, want)
+    pin_in = ctx.pinned_empty(d.shape, np.uint8)               # pinned INPUT as well: no staging in either direction
+    pin_in[...] = d
+    pin[...] = 0
+    R.fuse_frames(pin_in, q, t, out_dtype=np.float32, ctx=ctx, out=pin)
+    np.testing.assert_array_equal(pin, want)
+    with pytest.raises(ValueError):
+        R.fuse_frames(d, q, t, ctx=ctx, out=np.zeros((5, 3), np.float32))
+    del pin, pin_in, got
