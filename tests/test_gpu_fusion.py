@@ -281,3 +281,22 @@ def test_pinned_and_preallocated_outputs(R, ctx):
     with pytest.raises(ValueError):
         R.fuse_frames(d, q, t, ctx=ctx, out=np.zeros((5, 3), np.float32))
     del pin, pin_in, got
+
+
+def test_nonfinite_and_negative_f32_depth_propagate_like_numpy(R, ctx):
+    """f32 rasters may carry NaN / inf / negative / zero: no masking in the reference, none here; IEEE semantics match."""
+    rng = np.random.default_rng(13)
+    d = (rng.random((2, 16, 24)) * 50).astype(np.float32)
+    d[0, 0, :6] = [np.nan, np.inf, -np.inf, 0.0, -3.5, 1e30]
+    d[1, 5, 7] = np.nan
+    q = rng.normal(size=(2, 4))
+    t = rng.normal(size=(2, 3))
+    got = R.fuse_frames(d, q, t, out_dtype=np.float64, ctx=ctx)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = O.fuse_frames(d, q, t)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    assert (np.abs(got[fin] - want[fin]) <= 1e-12 * (1 + np.abs(want[fin]))).all()
+    got32 = R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx)
+    assert np.array_equal(np.isnan(got32), np.isnan(want))
