@@ -247,6 +247,7 @@ int r3d_camera_create(r3d_ctx* ctx, int height, int width, double fx, double fy,
     return R3D_ERR_NOMEM;
   }
   cam->ctx = ctx;
+  cam->device = ctx->device;
   cam->height = height;
   cam->width = width;
   cam->fx = fx;
@@ -275,7 +276,7 @@ int r3d_camera_create(r3d_ctx* ctx, int height, int width, double fx, double fy,
 
 int r3d_camera_destroy(r3d_camera* cam) {
   if (!cam) return R3D_OK;
-  if (cam->ctx) (void)hipSetDevice(cam->ctx->device);
+  (void)hipSetDevice(cam->device);
   if (cam->d_u) (void)hipFree(cam->d_u);
   if (cam->d_v) (void)hipFree(cam->d_v);
   delete cam;

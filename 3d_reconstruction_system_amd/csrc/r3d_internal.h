@@ -40,6 +40,7 @@ struct r3d_ctx {
 
 struct r3d_camera {
   r3d_ctx* ctx = nullptr;
+  int device = 0;  // for destroy, which must not dereference ctx
   int height = 0, width = 0;
   double fx = 0, fy = 0, cx = 0, cy = 0;
   double* d_u = nullptr;  // [width]  (i-cx)/fx

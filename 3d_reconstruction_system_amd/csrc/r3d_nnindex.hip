@@ -23,6 +23,7 @@
 
 struct r3d_nn_index {
   r3d_ctx* ctx = nullptr;
+  int device = 0;  // kept so that destroy never has to touch a ctx that may already be gone
   int64_t n = 0;
   int64_t n_tiles = 0;
   int idx_bits = 1, axis_bits = 16;
@@ -30,6 +31,7 @@ struct r3d_nn_index {
   float4* d_tgt4 = nullptr;    // [n_tiles*1024] sorted, w = original index bits; padding has x = +inf
   float* d_tile_box = nullptr; // [n_tiles][6] lo xyz, hi xyz
   float* d_sub_box = nullptr;  // [n_tiles*4][6] boxes of the 256-target quarters of every tile
+  float* d_super_box = nullptr; // [ceil(n_tiles/16)][6] boxes of 16 consecutive tiles
   uint64_t* d_tile_code = nullptr;  // [n_tiles] Morton code (without index bits) of the tile's first target
   float* d_frame = nullptr;    // [8]: lo xyz, scale xyz, unused: quantisation frame shared by both clouds
 };
@@ -40,6 +42,7 @@ constexpr int kThreads = 256;
 constexpr int kTile = 1024;
 constexpr int kGroup = 32;
 constexpr int kSub = 256;  // targets per sub-tile (wave-level culling inside a swept tile)
+constexpr int kSuper = 16;  // tiles per super-box (workgroup-level culling of 16 tiles at once)
 constexpr float kShrink = 1.0f - 16.0f * 5.9604645e-8f;  // (1 - 16u): makes the box bound a strict lower bound
 
 struct __attribute__((packed, aligned(4))) P3 {
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
                                                            const float4* __restrict__ tgt4, int64_t n_tgt, int64_t n_tiles,
                                                            const float* __restrict__ tile_box,
                                                            const float* __restrict__ sub_box,
+                                                           const float* __restrict__ super_box,
                                                            const uint64_t* __restrict__ tile_code,
                                                            uint32_t* __restrict__ idx_out, float* __restrict__ d2_out,
                                                            uint32_t* __restrict__ tie_list, unsigned* __restrict__ tie_count,
@@ -220,10 +224,28 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
   const int64_t t0 = start_tile;
   unsigned swept = 0;
 
-  // outward walk: t0, t0+1, t0-1, t0+2, ...
-  for (int64_t step = 0; step < 2 * n_tiles; ++step) {
-    const int64_t tile = (step & 1) ? t0 + ((step + 1) >> 1) : t0 - (step >> 1);
-    if (tile < 0 || tile >= n_tiles) continue;  // uniform
+  // two-level outward walk: super-boxes of 16 tiles s0, s0+1, s0-1, ...; a super-box nobody can improve in is
+  // skipped with one test + one vote instead of 16; inside a kept one the tiles are visited starting at t0's slot
+  const int64_t n_super = (n_tiles + kSuper - 1) / kSuper;
+  const int64_t s0 = t0 / kSuper;
+  for (int64_t sstep = 0; sstep < 2 * n_super; ++sstep) {
+   const int64_t sup = (sstep & 1) ? s0 + ((sstep + 1) >> 1) : s0 - (sstep >> 1);
+   if (sup < 0 || sup >= n_super) continue;  // uniform
+   {
+    const float* sb = super_box + sup * 6;
+    bool want = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float ex = fmaxf(fmaxf(sb[0] - sx[s], sx[s] - sb[3]), 0.f);
+      const float ey = fmaxf(fmaxf(sb[1] - sy[s], sy[s] - sb[4]), 0.f);
+      const float ez = fmaxf(fmaxf(sb[2] - sz[s], sz[s] - sb[5]), 0.f);
+      want |= ok[s] && !(fmaf(ez, ez, fmaf(ey, ey, ex * ex)) * kShrink > best[s]);
+    }
+    if (!__syncthreads_or(want)) continue;
+   }
+   for (int k = 0; k < kSuper; ++k) {
+    const int64_t tile = sup * kSuper + ((t0 + k) & (kSuper - 1));
+    if (tile >= n_tiles) continue;  // uniform
     const float* box = tile_box + tile * 6;
     const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
     bool need = false;
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
       }
     }
     __syncthreads();
+   }
   }
 
   // resolve inside the winning group: exact distance, lowest original index among equals
@@ -382,14 +405,13 @@ extern "C" {
 
 int r3d_nn_index_destroy(r3d_nn_index* ix) {
   if (!ix) return R3D_OK;
-  if (ix->ctx) {
-    (void)hipSetDevice(ix->ctx->device);
-    (void)hipStreamSynchronize(ix->ctx->stream);
-  }
+  (void)hipSetDevice(ix->device);
+  (void)hipDeviceSynchronize();
   if (ix->d_tgt) (void)hipFree(ix->d_tgt);
   if (ix->d_tgt4) (void)hipFree(ix->d_tgt4);
   if (ix->d_tile_box) (void)hipFree(ix->d_tile_box);
   if (ix->d_sub_box) (void)hipFree(ix->d_sub_box);
+  if (ix->d_super_box) (void)hipFree(ix->d_super_box);
   if (ix->d_tile_code) (void)hipFree(ix->d_tile_code);
   if (ix->d_frame) (void)hipFree(ix->d_frame);
   delete ix;
@@ -410,6 +432,7 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
     return R3D_ERR_NOMEM;
   }
   ix->ctx = ctx;
+  ix->device = ctx->device;
   ix->n = n_tgt;
   ix->n_tiles = (n_tgt + kTile - 1) / kTile;
   ix->idx_bits = bits_for(n_tgt);
@@ -419,6 +442,7 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
   if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tgt4, (size_t)n_pad * sizeof(float4));
   if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tile_box, (size_t)ix->n_tiles * 6 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sub_box, (size_t)ix->n_tiles * (kTile / kSub) * 6 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_super_box, (size_t)((ix->n_tiles + kSuper - 1) / kSuper) * 6 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tile_code, (size_t)ix->n_tiles * sizeof(uint64_t));
   if (e == hipSuccess) e = hipMalloc((void**)&ix->d_frame, 16 * sizeof(float));
   if (e != hipSuccess) {
@@ -455,6 +479,8 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
                      n_tgt, ix->idx_bits, kTile, ix->d_tile_box, ix->d_tile_code);
   hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)(ix->n_tiles * (kTile / kSub))), dim3(kThreads), 0, st, ix->d_tgt4,
                      (const uint64_t*)keys, n_tgt, ix->idx_bits, kSub, ix->d_sub_box, (uint64_t*)nullptr);
+  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)((ix->n_tiles + kSuper - 1) / kSuper)), dim3(kThreads), 0, st, ix->d_tgt4,
+                     (const uint64_t*)keys, n_tgt, ix->idx_bits, kSuper * kTile, ix->d_super_box, (uint64_t*)nullptr);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // the scratch key buffers are reused by later calls
   if (e != hipSuccess) {
@@ -501,7 +527,7 @@ int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint
 #define R3D_LAUNCH_CULL(SS, FMT, PTR)                                                                                  \
   hipLaunchKernelGGL((nn_cull_kernel<SS, FMT>), dim3(blocks), dim3(kThreads), 0, st, (const void*)(PTR), n_src,        \
                      (const float*)ix->d_frame, ix->axis_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box,         \
-                     ix->d_sub_box, ix->d_tile_code, d_idx_out, d_d2_out, tie_list, tie_count, stats)
+                     ix->d_sub_box, ix->d_super_box, ix->d_tile_code, d_idx_out, d_d2_out, tie_list, tie_count, stats)
   if (presorted) {
     if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
     else if (S == 2) R3D_LAUNCH_CULL(2, false, d_src);

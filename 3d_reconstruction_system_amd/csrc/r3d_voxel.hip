@@ -26,6 +26,7 @@
 
 struct r3d_voxelset {
   r3d_ctx* ctx = nullptr;
+  int device = 0;  // kept so that destroy never has to touch a ctx that may already be gone
   double res = 0.1;
   double factor = 10.0;
   uint64_t* d_table = nullptr;
@@ -343,6 +344,7 @@ int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_v
     return R3D_ERR_NOMEM;
   }
   vs->ctx = ctx;
+  vs->device = ctx->device;
   vs->res = resolution;
   vs->factor = 1.0 / resolution;  // OcTreeBaseImpl::resolution_factor
   vs->log2cap = 10;
@@ -362,10 +364,8 @@ int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_v
 
 int r3d_voxelset_destroy(r3d_voxelset* vs) {
   if (!vs) return R3D_OK;
-  if (vs->ctx) {
-    (void)hipSetDevice(vs->ctx->device);
-    (void)hipStreamSynchronize(vs->ctx->stream);
-  }
+  (void)hipSetDevice(vs->device);
+  (void)hipDeviceSynchronize();
   if (vs->d_table) (void)hipFree(vs->d_table);
   if (vs->d_counters) (void)hipFree(vs->d_counters);
   delete vs;

@@ -97,9 +97,23 @@ class Context:
         self.handle = h.value
         self.device = int(device)
         self._cameras = {}
+        self._children = []   # weak references to objects holding library handles tied to this ctx
+
+    def adopt(self, obj):
+        """Register an object with a close() method: it is closed before the context goes away."""
+        import weakref
+        self._children.append(weakref.ref(obj))
 
     def close(self):
         if self.handle:
+            for ref in self._children:
+                obj = ref()
+                if obj is not None:
+                    try:
+                        obj.close()
+                    except Exception:
+                        pass
+            self._children = []
             for cam in list(self._cameras.values()):
                 cam.close()
             self._cameras.clear()

@@ -47,6 +47,7 @@ class NNIndex:
         h = C.c_void_p()
         L.check(ctx.lib.r3d_nn_index_create(ctx.handle, d_tgt_ptr, int(n_tgt), C.byref(h)))
         self.handle = h.value
+        ctx.adopt(self)
 
     def query(self, d_src_ptr, n_src, d_idx_ptr, d_d2_ptr, want_stats=False, presorted=False):
         swept = C.c_int64()

@@ -37,7 +37,7 @@ class VoxelSet:
         h = C.c_void_p()
         L.check(self.ctx.lib.r3d_voxelset_create(self.ctx.handle, self.resolution, int(capacity), C.byref(h)))
         self.handle = h.value
-        self.capacity = 1 << max(10, int(capacity - 1).bit_length()) if capacity > 1024 else 1024
+        self.ctx.adopt(self)
 
     def close(self):
         if self.handle:
