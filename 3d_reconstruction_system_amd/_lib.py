@@ -55,6 +55,7 @@ SIGNATURES = {
     "r3d_timer_stop": (_i, [_vp, _pf]),
     "r3d_camera_create": (_i, [_vp, _i, _i, _d, _d, _d, _d, _pvp]),
     "r3d_camera_destroy": (_i, [_vp]),
+    "r3d_selftest_magic_div": (_i, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "r3d_unproject": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
     "r3d_unproject_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
     "r3d_fuse_frames": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),

@@ -673,6 +673,25 @@ int fuse_host_common(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, i
 
 extern "C" {
 
+// Self-test hook: floor(x / d) through the same host-made magic number the kernels use (x < 2^31, d >= 1).
+int r3d_selftest_magic_div(uint32_t d, uint32_t x, uint32_t* q_out) {
+  if (d == 0 || x >= ((uint32_t)1 << 31) || !q_out) {
+    r3d_set_error("r3d_selftest_magic_div: d must be >= 1, x < 2^31");
+    return R3D_ERR_INVALID;
+  }
+  uint32_t m = 0, sh = 0;
+  make_magic(d, &m, &sh);
+  *q_out = (uint32_t)(((uint64_t)x * m) >> sh);
+  if (d >= 2) {  // the umulhi form used by variants 6 and 7
+    const uint32_t hi = (uint32_t)(((uint64_t)x * m) >> 32);
+    if ((hi >> (sh - 32)) != *q_out) {
+      r3d_set_error("magic forms disagree for d=%u x=%u", d, x);
+      return R3D_ERR_HIP;
+    }
+  }
+  return R3D_OK;
+}
+
 int r3d_unproject(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
                   double depth_scale, void* d_xyz_out, int out_dtype) {
   return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, nullptr, false, d_xyz_out, out_dtype);

@@ -96,6 +96,10 @@ int r3d_camera_create(r3d_ctx* ctx, int height, int width, double fx, double fy,
                       r3d_camera** cam_out);
 int r3d_camera_destroy(r3d_camera* cam);
 
+/* Self-test hook (no GPU needed): floor(x / d) computed with the host-made magic number the kernels use for
+ * pixel -> (row, column) and tile -> (frame, tile) splits.  d >= 1, x < 2^31. */
+int r3d_selftest_magic_div(uint32_t d, uint32_t x, uint32_t* q_out);
+
 /* ---- a1/a2: per-pixel back-projection.  Replaces gentxtcord() (pixel_to_camera.py:24-44,
  * camera_to_world.py:67-83): Z=depth[j,i]*depth_scale, X=(i-cx)/fx*Z, Y=(j-cy)/fy*Z, row-major,
  * every pixel emitted, no masking.  n_frames rasters of cam's HxW -> [n_frames*H*W][3]. */

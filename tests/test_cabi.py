@@ -74,3 +74,27 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(root, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
                 assert "oracle/" not in text and "fusion_ref" not in text and "icp_ref" not in text, fn
+
+
+def test_magic_division_is_exact():
+    """The kernels split pixel -> (row, col) and tile -> (frame, tile) with host-made magic numbers: exact for every
+    divisor >= 1 and every x < 2^31 (checked on edge values and 200k random pairs, both evaluation forms)."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.load()
+    rng = np.random.default_rng(0)
+    q = C.c_uint32()
+    ds = [1, 2, 3, 4, 5, 6, 7, 640, 1279, 1280, 1281, 1920, 4099, 65535, 65536, 65537, 2**30 - 1, 2**30, 2**30 + 1, 2**31 - 1]
+    xs = [0, 1, 2, 1279, 1280, 491519, 491520, 2**31 - 2, 2**31 - 1]
+    for d in ds:
+        for x in xs + [d - 1, d, d + 1, 2 * d - 1, 2 * d, 3 * d + 1, (2**31 - 1) // d * d, (2**31 - 1) // d * d - 1]:
+            if 0 <= x < 2**31:
+                assert lib.r3d_selftest_magic_div(d, x, C.byref(q)) == 0, L.last_error()
+                assert q.value == x // d, (d, x, q.value)
+    dd = rng.integers(1, 2**31, size=200000)
+    dd[:100000] = rng.integers(1, 5000, size=100000)          # realistic widths / tile counts
+    xx = rng.integers(0, 2**31, size=200000)
+    for d, x in zip(dd.tolist(), xx.tolist()):
+        lib.r3d_selftest_magic_div(d, x, C.byref(q))
+        if q.value != x // d:
+            raise AssertionError((d, x, q.value, x // d))
+    assert lib.r3d_selftest_magic_div(0, 1, C.byref(q)) == L.ERR_INVALID

@@ -300,3 +300,24 @@ def test_nonfinite_and_negative_f32_depth_propagate_like_numpy(R, ctx):
     assert (np.abs(got[fin] - want[fin]) <= 1e-12 * (1 + np.abs(want[fin]))).all()
     got32 = R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx)
     assert np.array_equal(np.isnan(got32), np.isnan(want))
+
+
+@pytest.mark.parametrize("hw", [(3, 1), (2, 3), (3, 5), (2, 1023), (3, 1025), (2, 4099), (5, 257), (1, 8192)])
+def test_odd_widths_on_every_variant(R, ctx, hw):
+    """Widths that are not multiples of 4 (and a 1-pixel-wide raster) take the any-width paths; every variant that accepts
+    them must agree bit for bit and match the oracle."""
+    h, w = hw
+    rng = np.random.default_rng(h * 10007 + w)
+    d = make_depth(rng, (3, h, w), np.uint16)
+    q = rng.normal(size=(3, 4))
+    t = rng.normal(size=(3, 3)) * 10
+    want = O.fuse_frames(d, q, t)
+    outs = []
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
+        ctx.set_tuning("fuse_variant", variant)
+        got = R.fuse_frames(d, q, t, out_dtype=np.float64, ctx=ctx)
+        check(got, want, np.float64)
+        outs.append(got)
+    ctx.set_tuning("fuse_variant", 0)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
