@@ -119,8 +119,9 @@ int r3d_ctx_destroy(r3d_ctx* ctx) {
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   for (int i = 0; i < 4; ++i)
     if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 6; ++i)
     if (ctx->ev_pipe[i]) (void)hipEventDestroy(ctx->ev_pipe[i]);
+  if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -77,9 +77,18 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
     if (!out_pinned && (rc = pinned_slot(ctx, 2 + b, (size_t)chunk * out_item_bytes, &pin_out[b]))) return rc;
   }
   if (!ctx->ev_pipe[0]) {
-    R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[0], hipEventDisableTiming));
-    R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[1], hipEventDisableTiming));
+    for (int k = 0; k < 6; ++k) R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[k], hipEventDisableTiming));
+    R3D_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
   }
+  // uploads ride their own stream so H2D of chunk c+1 overlaps the kernel + D2H of chunk c (PCIe is full duplex):
+  //   upload_stream: [wait free(b)] H2D -> up(b)        main stream: [wait up(b)] kernel, D2H -> done(b) (+ free(b) for d_in reuse)
+  // d_in is a whole-batch buffer, so uploads never overwrite data a kernel still reads; the first upload waits for
+  // whatever the main stream did before this call.
+  hipEvent_t* ev_done = ctx->ev_pipe;      // [0,1] results of chunk b landed in pinned_out[b] / user memory
+  hipEvent_t* ev_up = ctx->ev_pipe + 2;    // [2,3] chunk uploaded
+  hipEvent_t ev_entry = ctx->ev_pipe[4];
+  R3D_HIP(hipEventRecord(ev_entry, ctx->stream));
+  R3D_HIP(hipStreamWaitEvent(ctx->upload_stream, ev_entry, 0));
   auto issue = [&](int64_t c) -> int {
     const int b = (int)(c & 1);
     const int64_t lo = c * chunk, n = std::min(chunk, n_items - lo);
@@ -89,19 +98,21 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
       src = static_cast<const char*>(pin_in[b]);
     }
     R3D_HIP(hipMemcpyAsync(static_cast<char*>(d_in) + (size_t)lo * in_item_bytes, src, (size_t)n * in_item_bytes,
-                           hipMemcpyHostToDevice, ctx->stream));
+                           hipMemcpyHostToDevice, ctx->upload_stream));
+    R3D_HIP(hipEventRecord(ev_up[b], ctx->upload_stream));
+    R3D_HIP(hipStreamWaitEvent(ctx->stream, ev_up[b], 0));
     int r = launch(lo, n);
     if (r) return r;
     void* dst = out_pinned ? static_cast<void*>(static_cast<char*>(h_out) + (size_t)lo * out_item_bytes) : pin_out[b];
     R3D_HIP(hipMemcpyAsync(dst, static_cast<char*>(d_out) + (size_t)lo * out_item_bytes, (size_t)n * out_item_bytes,
                            hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(hipEventRecord(ctx->ev_pipe[b], ctx->stream));
+    R3D_HIP(hipEventRecord(ev_done[b], ctx->stream));
     return R3D_OK;
   };
   auto drain = [&](int64_t c) -> int {
     const int b = (int)(c & 1);
     const int64_t lo = c * chunk, n = std::min(chunk, n_items - lo);
-    R3D_HIP(hipEventSynchronize(ctx->ev_pipe[b]));
+    R3D_HIP(hipEventSynchronize(ev_done[b]));
     if (!out_pinned)
       parallel_memcpy(static_cast<char*>(h_out) + (size_t)lo * out_item_bytes, pin_out[b], (size_t)n * out_item_bytes,
                       n_threads);

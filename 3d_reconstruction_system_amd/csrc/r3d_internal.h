@@ -35,7 +35,8 @@ struct r3d_ctx {
   // pinned staging buffers of the host pipeline: [0,1] inbound, [2,3] outbound
   void* pinned[4] = {};
   size_t pinned_bytes[4] = {};
-  hipEvent_t ev_pipe[2] = {nullptr, nullptr};
+  hipEvent_t ev_pipe[6] = {};           // host pipeline: done[2], uploaded[2], entry, spare
+  hipStream_t upload_stream = nullptr;  // H2D side of the host pipeline (full-duplex PCIe)
 };
 
 struct r3d_camera {

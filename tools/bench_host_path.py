@@ -41,3 +41,24 @@ for dt in (np.float32, np.float64):
             print("%s pinned out rep %d: %.1f ms  %.2f Gpoints/s  (%.1f GB/s)" % (np.dtype(dt).name, rep, dt_s * 1e3,
                   F * H * W / dt_s / 1e9, pin.nbytes / dt_s / 1e9))
 ctx.close()
+
+# apply-T through the host pipeline: 12 B/point each way, full duplex
+ctx = r3d.Context(0)
+pts = (rng.normal(size=(F * H * W, 3)) * 50).astype(np.float32)
+outp = np.zeros_like(pts)
+T = np.eye(4); T[:3, 3] = (1, 2, 3)
+for rep in range(3):
+    t0 = time.perf_counter()
+    r3d.apply_T(pts, T, ctx=ctx) if rep == 0 else None
+    dt_s = time.perf_counter() - t0
+pin_i, pin_o = ctx.pinned_empty(pts.shape, np.float32), ctx.pinned_empty(pts.shape, np.float32)
+pin_i[...] = pts
+import ctypes as C
+L = importlib.import_module("3d_reconstruction_system_amd._lib")
+for label, a, b in (("pageable (pre-touched)", pts, outp), ("pinned", pin_i, pin_o)):
+    for rep in range(3):
+        t0 = time.perf_counter()
+        L.check(ctx.lib.r3d_apply_T_host(ctx.handle, a.ctypes.data, 0, a.shape[0], np.ascontiguousarray(T).ctypes.data, b.ctypes.data, 0))
+        dt_s = time.perf_counter() - t0
+    print("apply_T host %s: %.1f ms  %.2f Gpoints/s  (%.1f GB/s each way)" % (label, dt_s * 1e3, a.shape[0] / dt_s / 1e9, a.nbytes / dt_s / 1e9))
+ctx.close()
