@@ -189,7 +189,6 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
   __shared__ __attribute__((aligned(16))) float ty[kTile];
   __shared__ __attribute__((aligned(16))) float tz[kTile];
   __shared__ int start_tile;
-  __shared__ uint32_t vote[2];
 
   const uint32_t tid = threadIdx.x;
   const int64_t s_base = (int64_t)blockIdx.x * (kThreads * S);
@@ -212,8 +211,6 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
     tie[s] = false;
   }
   if (tid == 0) {
-    vote[0] = 0;
-    vote[1] = 0;
     // tile whose Morton range holds this workgroup's first source: last tile with first code <= code
     const uint64_t code = point_code(P3{sx[0], sy[0], sz[0]}, frame, axis_bits);
     int64_t lo = 0, hi = n_tiles;  // answer in [lo, hi)
@@ -226,7 +223,6 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
   __syncthreads();
   const int64_t t0 = start_tile;
   unsigned swept = 0;
-  int parity = 0;
 
   // two-level outward walk: super-boxes of 16 tiles s0, s0+1, s0-1, ...; a super-box nobody can improve in is
   // skipped with one test + one vote instead of 16; inside a kept one the tiles are visited starting at t0's slot
@@ -247,34 +243,12 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
     }
     if (!__syncthreads_or(want)) continue;
    }
-   // one vote for all 16 tiles of the super-box: every lane marks the tiles whose box it cannot rule out, the marks
-   // are OR-ed across the workgroup through an LDS word (two words alternate so no extra barrier is needed to clear)
-   uint32_t mine = 0;
    for (int k = 0; k < kSuper; ++k) {
     const int64_t tile = sup * kSuper + ((t0 + k) & (kSuper - 1));
     if (tile >= n_tiles) continue;  // uniform
     const float* box = tile_box + tile * 6;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float ex = fmaxf(fmaxf(box[0] - sx[s], sx[s] - box[3]), 0.f);
-      const float ey = fmaxf(fmaxf(box[1] - sy[s], sy[s] - box[4]), 0.f);
-      const float ez = fmaxf(fmaxf(box[2] - sz[s], sz[s] - box[5]), 0.f);
-      if (ok[s] && !(fmaf(ez, ez, fmaf(ey, ey, ex * ex)) * kShrink > best[s])) mine |= 1u << k;
-    }
-   }
-#pragma unroll
-   for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off, 64);
-   if ((tid & 63) == 0 && mine) atomicOr(&vote[parity], mine);
-   if (tid == 0) vote[parity ^ 1] = 0;
-   __syncthreads();
-   const uint32_t marked = vote[parity];
-   parity ^= 1;
-   for (int k = 0; k < kSuper; ++k) {
-    if (!((marked >> k) & 1u)) continue;  // uniform
-    const int64_t tile = sup * kSuper + ((t0 + k) & (kSuper - 1));
-    const float* box = tile_box + tile * 6;
     const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
-    bool need = false;  // re-tested against the best distance as it stands NOW: decides whether this wave computes
+    bool need = false;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const float ex = fmaxf(fmaxf(blo[0] - sx[s], sx[s] - bhi[0]), 0.f);
@@ -283,6 +257,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
       const float lb = fmaf(ez, ez, fmaf(ey, ey, ex * ex)) * kShrink;
       need |= ok[s] && !(lb > best[s]);  // NaN bounds never allow a skip
     }
+    if (!__syncthreads_or(need)) continue;  // nobody in the workgroup can improve inside this tile
     ++swept;
     const int64_t t_base = tile * kTile;
     for (uint32_t k = tid; k < kTile; k += kThreads) {
