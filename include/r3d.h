@@ -14,7 +14,9 @@
  *   - device-pointer entry points are ASYNCHRONOUS on the ctx's HIP stream; *_host
  *     entry points are synchronous (H2D, kernel, D2H, stream sync).
  *   - one ctx = one GPU + one stream.  Calls on one ctx are not thread-safe; different
- *     ctxs are independent.
+ *     ctxs are independent.  Objects created from a ctx (r3d_camera, r3d_voxelset, r3d_nn_index,
+ *     r3d_dev_alloc / r3d_host_alloc memory) must not be USED after r3d_ctx_destroy; destroying
+ *     them afterwards is allowed (their destroy functions do not touch the ctx).
  *   - point clouds are AoS xyz, row-major [n][3], float32 (R3D_F32) or float64
  *     (R3D_F64).  All arithmetic is done in fp64 registers exactly in the reference's
  *     evaluation order and rounded ONCE on store, so R3D_F32 output is the correctly
