@@ -10,8 +10,8 @@ ONE fused unproject + SE(3) launch over all 100 frames (49,152,000 points -> f32
 N > 1 additionally the collective that assembles the fused world cloud on every rank (north_star):
 by default an all-gather of the INPUTS (depth + poses, 1 B/point) followed by a local fuse of every
 rank's frames, which is bit-identical to and several times faster than all-gathering the xyz
-OUTPUTS (12 B/point) on xGMI; `--assemble outputs|none` selects the other strategies, and all of
-them are timed and printed under "assemble_ms_per_step".  Weak scaling: every rank owns 100 frames.
+OUTPUTS (12 B/point) on xGMI; `--assemble outputs|none` selects the other strategies; `--all-modes` additionally
+times the other two after the timed region and prints them under "assemble_ms_per_step".  Weak scaling: every rank owns 100 frames.
 `value` is whole-job Mpoints/s = UNIQUE fused points of all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
@@ -152,6 +152,10 @@ def main():
                     help="N>1: how the step assembles the fused world cloud on every rank: 'inputs' = all-gather "
                          "depth+poses (1 B/point over xGMI) then fuse all frames locally (default, fastest); "
                          "'outputs' = fuse own frames then all-gather xyz (12 B/point over xGMI); 'none' = shards stay put")
+    ap.add_argument("--all-modes", action="store_true",
+                    help="N>1: after the timed region also time the other assembly strategies (10 steps each) and add them "
+                         "to the line under assemble_ms_per_step; off by default so that nothing runs between the timed "
+                         "region and the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel"],
@@ -277,7 +281,7 @@ def main():
 
     # N > 1: the other assembly strategies, timed briefly after the main region (reported, not `value`)
     assemble_ms = {}
-    if use_dist:
+    if use_dist and (a.all_modes or os.environ.get("R3D_BENCH_ALL_MODES", "0") not in ("", "0")):
         for m in ("none", "outputs", "inputs"):
             if m == mode or (m != "none" and full is None):
                 continue
