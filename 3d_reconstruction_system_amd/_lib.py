@@ -48,6 +48,7 @@ SIGNATURES = {
     "r3d_dev_free": (_i, [_vp, _vp]),
     "r3d_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "r3d_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memset": (_i, [_vp, _vp, _i, _sz]),
     "r3d_host_alloc": (_i, [_vp, _sz, _pvp]),
     "r3d_host_free": (_i, [_vp, _vp]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "r3d_se3_apply_host": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_apply_T": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_apply_T_host": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
+    "r3d_apply_T_dev": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_icp_nn": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "r3d_icp_nn_host": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "r3d_nn_index_create": (_i, [_vp, _vp, _i64, _pvp]),
@@ -71,6 +73,12 @@ SIGNATURES = {
     "r3d_nn_index_query": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "r3d_nn_index_sort_cloud": (_i, [_vp, _vp, _i64, _vp]),
     "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),
+    "r3d_icp_accumulate_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp]),
+    "r3d_nn_index_query_sums": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _f, _f, _vp]),
+    "r3d_umeyama_from_sums": (_i, [_vp, _i, _vp, _vp]),
+    "r3d_icp_state_reset": (_i, [_vp, _vp]),
+    "r3d_icp_solve_dev": (_i, [_vp, _vp, _i, _vp]),
+    "r3d_icp_iterate": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
     "r3d_format_ply": (_i, [_vp, _i, _i64, _vp, _sz, _psz]),
     "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),
     "r3d_write_ply_rgb": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),

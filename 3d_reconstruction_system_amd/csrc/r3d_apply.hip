@@ -27,8 +27,15 @@ struct ApplyArgs {
   const void* in;
   void* out;
   double T[12];  // affine: rows 0..2 of the 4x4, row-major.  SE3: Rinv row-major (9) then t (3)
+  const double* d_T;  // non-NULL: the 12 numbers are read from HBM instead (r3d_apply_T_dev: the matrix was made on the GPU)
   uint64_t n;    // points
 };
+
+// the 12 coefficients: kernel arguments, or 12 scalar loads from a wave-uniform device address
+__device__ __forceinline__ void load_T(const ApplyArgs& a, double T[12]) {
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = a.d_T ? a.d_T[k] : a.T[k];
+}
 
 template <typename IT, typename OT, bool VEC, bool SE3>
 __global__ __launch_bounds__(kThreads) void apply_kernel(const ApplyArgs a) {
@@ -39,6 +46,8 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const ApplyArgs a) {
   OT* lout = reinterpret_cast<OT*>(lds_raw);
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
+  double T[12];
+  load_T(a, T);
 
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t p_base = tile * kTile;
@@ -70,14 +79,14 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const ApplyArgs a) {
         const double y = (double)lin[(first + k) * 3 + 1];
         const double z = (double)lin[(first + k) * 3 + 2];
         if (SE3) {  // Rinv . (p - t), the order of point_camera (camera_to_world.py:57-59) and of the fused kernel
-          const double dx = x - a.T[9], dy = y - a.T[10], dz = z - a.T[11];
+          const double dx = x - T[9], dy = y - T[10], dz = z - T[11];
 #pragma unroll
           for (int r = 0; r < 3; ++r)
-            w[3 * k + r] = fma(a.T[3 * r + 2], dz, fma(a.T[3 * r + 1], dy, a.T[3 * r + 0] * dx));
+            w[3 * k + r] = fma(T[3 * r + 2], dz, fma(T[3 * r + 1], dy, T[3 * r + 0] * dx));
         } else {  // row . [x y z 1]  (transfer_T_icp.py:10-12)
 #pragma unroll
           for (int r = 0; r < 3; ++r)
-            w[3 * k + r] = fma(a.T[4 * r + 2], z, fma(a.T[4 * r + 1], y, a.T[4 * r + 0] * x)) + a.T[4 * r + 3];
+            w[3 * k + r] = fma(T[4 * r + 2], z, fma(T[4 * r + 1], y, T[4 * r + 0] * x)) + T[4 * r + 3];
         }
       }
     }
@@ -130,6 +139,8 @@ __global__ __launch_bounds__(kThreads) void apply_lane_kernel(const ApplyArgs a)
   const IT* in = static_cast<const IT*>(a.in);
   OT* out = static_cast<OT*>(a.out);
   const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
+  double T[12];
+  load_T(a, T);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t base = tile * kTile + threadIdx.x;
     Packed3<IT> p[kPts];
@@ -145,13 +156,13 @@ __global__ __launch_bounds__(kThreads) void apply_lane_kernel(const ApplyArgs a)
         const double x = (double)p[r].x, y = (double)p[r].y, z = (double)p[r].z;
         double w[3];
         if (SE3) {
-          const double dx = x - a.T[9], dy = y - a.T[10], dz = z - a.T[11];
+          const double dx = x - T[9], dy = y - T[10], dz = z - T[11];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) w[c] = fma(a.T[3 * c + 2], dz, fma(a.T[3 * c + 1], dy, a.T[3 * c + 0] * dx));
+          for (int c = 0; c < 3; ++c) w[c] = fma(T[3 * c + 2], dz, fma(T[3 * c + 1], dy, T[3 * c + 0] * dx));
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            w[c] = fma(a.T[4 * c + 2], z, fma(a.T[4 * c + 1], y, a.T[4 * c + 0] * x)) + a.T[4 * c + 3];
+            w[c] = fma(T[4 * c + 2], z, fma(T[4 * c + 1], y, T[4 * c + 0] * x)) + T[4 * c + 3];
         }
         store3_nt<OT>(out + i * 3, w);
       }
@@ -171,20 +182,21 @@ void launch(const ApplyArgs& a, int variant, bool vec, int blocks, hipStream_t s
 
 template <bool SE3>
 int apply_common(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_M,
-                 void* d_xyz_out, int out_dtype) {
+                 void* d_xyz_out, int out_dtype, const double* d_M = nullptr) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(in_dtype == R3D_F32 || in_dtype == R3D_F64, "unknown input dtype %d", in_dtype);
   R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
   R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
-  R3D_REQUIRE(h_M != nullptr, "transform is NULL");
+  R3D_REQUIRE(h_M != nullptr || d_M != nullptr, "transform is NULL");
   if (n_points == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz_in && d_xyz_out, "NULL device pointer");
   R3D_REQUIRE(d_xyz_in == d_xyz_out ? in_dtype == out_dtype : true, "in-place apply needs equal dtypes");
   ApplyArgs a;
   a.in = d_xyz_in;
   a.out = d_xyz_out;
-  for (int k = 0; k < 12; ++k) a.T[k] = h_M[k];
+  for (int k = 0; k < 12; ++k) a.T[k] = h_M ? h_M[k] : 0.0;
+  a.d_T = d_M;
   a.n = (uint64_t)n_points;
   // tile bases are multiples of 1024 points = 12 KiB (f32) / 24 KiB (f64): 16-B alignment of
   // every tile follows from the alignment of the two base pointers
@@ -262,6 +274,12 @@ int r3d_apply_T(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_poin
 int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_T,
                      void* h_xyz_out, int out_dtype) {
   return apply_host_common<false>(ctx, h_xyz_in, in_dtype, n_points, h_T, h_xyz_out, out_dtype);
+}
+
+int r3d_apply_T_dev(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* d_T,
+                    void* d_xyz_out, int out_dtype) {
+  R3D_REQUIRE(d_T != nullptr, "d_T is NULL");
+  return apply_common<false>(ctx, d_xyz_in, in_dtype, n_points, nullptr, d_xyz_out, out_dtype, d_T);
 }
 
 int r3d_se3_apply(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_pose,

@@ -207,6 +207,15 @@ int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   return R3D_OK;
 }
 
+int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  if (bytes == 0) return R3D_OK;
+  R3D_REQUIRE(d_dst && d_src, "NULL pointer with bytes > 0");
+  R3D_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return R3D_OK;
+}
+
 int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;

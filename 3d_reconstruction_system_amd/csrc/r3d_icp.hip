@@ -22,6 +22,7 @@
 //   reproducible run to run.
 #include <cmath>
 
+#include "r3d_icp_sums.h"
 #include "r3d_internal.h"
 
 namespace {
@@ -155,51 +156,37 @@ __global__ __launch_bounds__(kThreads) void nn_merge_kernel(const uint32_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-constexpr int kSums = 18;
+using r3d_icp::block_reduce_store;
+using r3d_icp::kSums;
+using r3d_icp::pair_accumulate;
+using r3d_icp::pair_weight;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
+// flag != nullptr: only sources whose flag byte is non-zero take part (the cross-group ties of the culled
+// NN kernel, whose winners the exact fallback wrote after the main kernel's fused sums were taken).
+// only_if != nullptr: the whole launch is a no-op when *only_if == 0 (partials are zeroed).
 __global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __restrict__ src, int64_t n_src,
                                                               const float* __restrict__ tgt,
                                                               const uint32_t* __restrict__ idx,
-                                                              const float* __restrict__ d2, float max_d2,
+                                                              const float* __restrict__ d2, float max_d2, float dead_zone,
+                                                              const unsigned char* __restrict__ flag,
+                                                              const unsigned* __restrict__ only_if,
                                                               double* __restrict__ partials) {
   __shared__ double red[kThreads / 64][kSums];
   double acc[kSums];
 #pragma unroll
   for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_src; i += (int64_t)gridDim.x * kThreads) {
-    if (d2 != nullptr && !(d2[i] <= max_d2)) continue;
-    const uint32_t j = idx[i];
-    const double p[3] = {(double)src[i * 3 + 0], (double)src[i * 3 + 1], (double)src[i * 3 + 2]};
-    const double q[3] = {(double)tgt[(int64_t)j * 3 + 0], (double)tgt[(int64_t)j * 3 + 1], (double)tgt[(int64_t)j * 3 + 2]};
-    acc[0] += 1.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      acc[1 + a] += p[a];
-      acc[4 + a] += q[a];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) acc[7 + 3 * a + b] += p[a] * q[b];
-      acc[16] += p[a] * p[a];
-      acc[17] += q[a] * q[a];
+  const bool active = only_if == nullptr || *only_if != 0u;
+  if (active) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_src; i += (int64_t)gridDim.x * kThreads) {
+      if (flag != nullptr && flag[i] == 0) continue;
+      if (max_d2 >= 0.f && !(d2[i] <= max_d2)) continue;
+      const int64_t j = idx ? (int64_t)idx[i] : i;  // no index array: pair k with k (per-cloud moments)
+      const double p[3] = {(double)src[i * 3 + 0], (double)src[i * 3 + 1], (double)src[i * 3 + 2]};
+      const double q[3] = {(double)tgt[j * 3 + 0], (double)tgt[j * 3 + 1], (double)tgt[j * 3 + 2]};
+      pair_accumulate(acc, d2 ? pair_weight(d2[i], dead_zone) : 1.0, p, q);
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kSums; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) red[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kSums) {
-    double v = 0.0;
-    for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
-    partials[(int64_t)blockIdx.x * kSums + threadIdx.x] = v;
-  }
+  block_reduce_store(acc, red, partials + (int64_t)blockIdx.x * kSums);
 }
 
 // One workgroup per sum: 256 lanes stride over the per-workgroup partials in a fixed order, then a fixed LDS tree.
@@ -218,7 +205,57 @@ __global__ __launch_bounds__(kThreads) void accumulate_final_kernel(const double
   if (threadIdx.x == 0) sums[k] = red[0];
 }
 
+// ---- device-side similarity solve: the ICP loop never waits for the host ---------------------------------
+__global__ void icp_state_reset_kernel(double* __restrict__ st) {
+  for (int k = threadIdx.x; k < r3d_icp::kStateDoubles; k += blockDim.x) {
+    double v = 0.0;
+    if (k < 32 && (k % 16) % 5 == 0) v = 1.0;  // T_total = T_step = identity
+    st[k] = v;
+  }
+}
+
+// One thread: step = umeyama(sums); T_total <- step . T_total; history.  A degenerate fit leaves the identity step.
+__global__ void icp_solve_kernel(const double* __restrict__ sums, int with_scale, double* __restrict__ st) {
+  double s[kSums], T[16], rms = 0.0;
+  for (int k = 0; k < kSums; ++k) s[k] = sums[k];
+  const int bad = r3d_icp::umeyama_from_sums(s, with_scale, T, &rms);
+  double tot[16], nt[16];
+  for (int k = 0; k < 16; ++k) tot[k] = st[r3d_icp::kStateTTotal + k];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double v = 0.0;
+      for (int m = 0; m < 4; ++m) v += T[4 * r + m] * tot[4 * m + c];
+      nt[4 * r + c] = v;
+    }
+  for (int k = 0; k < 16; ++k) {
+    st[r3d_icp::kStateTStep + k] = T[k];
+    st[r3d_icp::kStateTTotal + k] = nt[k];
+  }
+  const int it = (int)st[r3d_icp::kStateIters];
+  if (r3d_icp::kStateHistory + it < r3d_icp::kStateDoubles) st[r3d_icp::kStateHistory + it] = rms;
+  st[r3d_icp::kStateIters] = (double)(it + 1);
+  if (bad) st[r3d_icp::kStateStatus] = 1.0;
+  st[r3d_icp::kStateRms] = rms;
+  st[r3d_icp::kStatePairs] = s[0];
+}
+
 }  // namespace
+
+// Second half of the fused NN + sums path (r3d_nnindex.hip): partial rows [0, main_blocks) were written by the NN
+// kernel; the sources it handed to the exact fallback (flag != 0) are summed here in a fixed order into rows
+// [main_blocks, main_blocks + tie_blocks), then everything is reduced in a fixed order -> bitwise repeatable.
+int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
+                        const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,
+                        const unsigned* d_tie_count, double* d_partials, int main_blocks, int tie_blocks,
+                        double* d_sums_out) {
+  hipLaunchKernelGGL(accumulate_kernel, dim3(tie_blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx, d_d2,
+                     max_d2 >= 0.f ? max_d2 : -1.f, dead_zone, d_flag, d_tie_count,
+                     d_partials + (size_t)main_blocks * kSums);
+  hipLaunchKernelGGL(accumulate_final_kernel, dim3(kSums), dim3(kThreads), 0, ctx->stream, d_partials,
+                     main_blocks + tie_blocks, d_sums_out);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
 
 extern "C" {
 
@@ -298,30 +335,103 @@ int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float
   return R3D_OK;
 }
 
-int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
-                       const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums) {
+// sums over the matched pairs into a DEVICE array of 18 doubles; asynchronous on the ctx stream
+int r3d_icp_accumulate_dev(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                           const uint32_t* d_idx, const float* d_d2, float max_d2, float dead_zone,
+                           double* d_sums_out) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(n_src >= 0 && n_tgt >= 0, "negative cloud size");
-  R3D_REQUIRE(h_sums != nullptr, "h_sums is NULL");
-  for (int k = 0; k < kSums; ++k) h_sums[k] = 0.0;
-  if (n_src == 0) return R3D_OK;
-  R3D_REQUIRE(d_src && d_tgt && d_idx, "NULL device pointer");
+  R3D_REQUIRE(d_sums_out != nullptr, "d_sums_out is NULL");
+  if (n_src == 0) {
+    R3D_HIP(hipMemsetAsync(d_sums_out, 0, kSums * sizeof(double), ctx->stream));
+    return R3D_OK;
+  }
+  R3D_REQUIRE(d_src && d_tgt, "NULL device pointer");
+  R3D_REQUIRE(d_idx != nullptr || n_tgt >= n_src, "identity pairing (d_idx == NULL) needs n_tgt >= n_src");
   const bool gated = max_d2 >= 0.f;
-  R3D_REQUIRE(!gated || d_d2 != nullptr, "max_d2 >= 0 needs the d2 array");
+  R3D_REQUIRE((!gated && !(dead_zone > 0.f)) || d_d2 != nullptr, "max_d2 >= 0 or dead_zone > 0 needs the d2 array");
   int blocks = (int)((n_src + kThreads - 1) / kThreads);
   if (blocks > ctx->num_cus * 4) blocks = ctx->num_cus * 4;
   void* d_part_v = nullptr;
   if ((rc = r3d_scratch(ctx, 4, ((size_t)blocks + 1) * kSums * sizeof(double), &d_part_v))) return rc;
   double* d_part = static_cast<double*>(d_part_v);
-  double* d_sums = d_part + (size_t)blocks * kSums;
   hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx,
-                     gated ? d_d2 : nullptr, max_d2, d_part);
-  hipLaunchKernelGGL(accumulate_final_kernel, dim3(kSums), dim3(kThreads), 0, ctx->stream, d_part, blocks, d_sums);
+                     (gated || dead_zone > 0.f) ? d_d2 : nullptr, gated ? max_d2 : -1.f, dead_zone,
+                     (const unsigned char*)nullptr, (const unsigned*)nullptr, d_part);
+  hipLaunchKernelGGL(accumulate_final_kernel, dim3(kSums), dim3(kThreads), 0, ctx->stream, d_part, blocks, d_sums_out);
   R3D_HIP(hipGetLastError());
+  (void)n_tgt;
+  return R3D_OK;
+}
+
+int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                       const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(h_sums != nullptr, "h_sums is NULL");
+  for (int k = 0; k < kSums; ++k) h_sums[k] = 0.0;
+  R3D_REQUIRE(n_src >= 0 && n_tgt >= 0, "negative cloud size");
+  if (n_src == 0) return R3D_OK;
+  void* d_sums = nullptr;
+  if ((rc = r3d_scratch(ctx, 3, kSums * sizeof(double), &d_sums))) return rc;
+  if ((rc = r3d_icp_accumulate_dev(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, 0.f, (double*)d_sums)))
+    return rc;
   R3D_HIP(hipMemcpyAsync(h_sums, d_sums, kSums * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   R3D_HIP(hipStreamSynchronize(ctx->stream));
-  (void)n_tgt;
+  return R3D_OK;
+}
+
+int r3d_umeyama_from_sums(const double* h_sums, int with_scale, double* h_T, double* h_rms_out) {
+  R3D_REQUIRE(h_sums && h_T, "NULL argument");
+  const int bad = r3d_icp::umeyama_from_sums(h_sums, with_scale, h_T, h_rms_out);
+  if (bad) {
+    r3d_set_error("similarity fit undefined: weight sum %g (need >= 3) or no spread in the source points", h_sums[0]);
+    return R3D_ERR_INVALID;
+  }
+  return R3D_OK;
+}
+
+int r3d_icp_state_reset(r3d_ctx* ctx, double* d_state) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(d_state != nullptr, "d_state is NULL");
+  hipLaunchKernelGGL(icp_state_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, d_state);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+int r3d_icp_solve_dev(r3d_ctx* ctx, const double* d_sums, int with_scale, double* d_state) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(d_sums && d_state, "NULL device pointer");
+  hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1), 0, ctx->stream, d_sums, with_scale, d_state);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                    uint32_t* d_idx, float* d_d2, int n_iters, int with_scale, float max_d2, double* d_state) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_iters >= 0, "n_iters must be >= 0");
+  R3D_REQUIRE(n_src >= 3, "need at least 3 source points");
+  R3D_REQUIRE(d_src && d_idx && d_d2 && d_state, "NULL device pointer");
+  R3D_REQUIRE(index != nullptr || d_tgt != nullptr, "need an index or a target cloud");
+  void* d_sums_v = nullptr;
+  if ((rc = r3d_scratch(ctx, 3, kSums * sizeof(double), &d_sums_v))) return rc;
+  double* d_sums = static_cast<double*>(d_sums_v);
+  for (int it = 0; it < n_iters; ++it) {
+    if (index) {
+      // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud): no sort, sums fused
+      if ((rc = r3d_nn_index_query_sums(index, d_src, n_src, d_idx, d_d2, 1, max_d2, 0.f, d_sums))) return rc;
+    } else {
+      if ((rc = r3d_icp_nn(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2))) return rc;
+      if ((rc = r3d_icp_accumulate_dev(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, 0.f, d_sums))) return rc;
+    }
+    if ((rc = r3d_icp_solve_dev(ctx, d_sums, with_scale, d_state))) return rc;
+    if ((rc = r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32))) return rc;
+  }
   return R3D_OK;
 }
 

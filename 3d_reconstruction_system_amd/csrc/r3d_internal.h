@@ -79,5 +79,11 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
 // Stable LSD radix sort of 64-bit keys by their low `bits` bits (r3d_sort.hip); d_tmp holds n keys.
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits);
 
+// r3d_icp.hip: finish the fused NN + 18-sums path of r3d_nnindex.hip (flagged fallback sources + fixed-order reduction)
+int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
+                        const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,
+                        const unsigned* d_tie_count, double* d_partials, int main_blocks, int tie_blocks,
+                        double* d_sums_out);
+
 static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
 static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

@@ -19,6 +19,7 @@
 //       fallback kernel that scans all targets in original order.
 #include <cmath>
 
+#include "r3d_icp_sums.h"
 #include "r3d_internal.h"
 
 struct r3d_nn_index {
@@ -184,7 +185,9 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
                                                            const uint64_t* __restrict__ tile_code,
                                                            uint32_t* __restrict__ idx_out, float* __restrict__ d2_out,
                                                            uint32_t* __restrict__ tie_list, unsigned* __restrict__ tie_count,
-                                                           unsigned long long* __restrict__ stats) {
+                                                           unsigned long long* __restrict__ stats,
+                                                           double* __restrict__ partials, unsigned char* __restrict__ tie_flag,
+                                                           float max_d2, float dead_zone) {
   __shared__ __attribute__((aligned(16))) float tx[kTile];
   __shared__ __attribute__((aligned(16))) float ty[kTile];
   __shared__ __attribute__((aligned(16))) float tz[kTile];
@@ -323,7 +326,15 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
    }
   }
 
-  // resolve inside the winning group: exact distance, lowest original index among equals
+  // resolve inside the winning group: exact distance, lowest original index among equals.  With `partials` the
+  // 18 fp64 pair sums of the Umeyama fit are taken right here (p = this source, q = its winner): the ICP loop
+  // needs no separate gather pass over (src, idx, tgt).  Sources handed to the exact fallback are flagged and
+  // summed by a small follow-up pass once their winners are known.
+  double acc[r3d_icp::kSums];
+  if (partials) {
+#pragma unroll
+    for (int k = 0; k < r3d_icp::kSums; ++k) acc[k] = 0.0;
+  }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int64_t i = s_base + (int64_t)s * kThreads + tid;
@@ -331,19 +342,34 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
     const uint32_t orig = SRC4 ? __float_as_uint(static_cast<const float4*>(src_any)[i].w) : (uint32_t)i;
     const int64_t g0 = (int64_t)best_group[s] * kGroup;
     uint32_t found = 0xffffffffu;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
     for (int k = 0; k < kGroup; ++k) {
       const float4 p = tgt4[g0 + k];
       const float dx = sx[s] - p.x, dy = sy[s] - p.y, dz = sz[s] - p.z;
       const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      if (d == best[s]) found = min(found, __float_as_uint(p.w));
+      if (d == best[s] && __float_as_uint(p.w) < found) {
+        found = __float_as_uint(p.w);
+        qx = p.x; qy = p.y; qz = p.z;
+      }
     }
-    if (found == 0xffffffffu || tie[s]) {
+    const bool to_fallback = found == 0xffffffffu || tie[s];
+    if (to_fallback) {
       // no finite distance at all (NaN input) or a cross-group tie: the exact fallback scans everything
       tie_list[atomicAdd(tie_count, 1u)] = orig;
     } else {
       idx_out[orig] = found;
       if (d2_out) d2_out[orig] = best[s];
+      if (partials && !(max_d2 >= 0.f && !(best[s] <= max_d2))) {
+        const double p3[3] = {(double)sx[s], (double)sy[s], (double)sz[s]};
+        const double q3[3] = {(double)qx, (double)qy, (double)qz};
+        r3d_icp::pair_accumulate(acc, r3d_icp::pair_weight(best[s], dead_zone), p3, q3);
+      }
     }
+    if (tie_flag) tie_flag[orig] = to_fallback ? 1 : 0;
+  }
+  if (partials) {
+    __shared__ double red[kThreads / 64][r3d_icp::kSums];
+    r3d_icp::block_reduce_store(acc, red, partials + (int64_t)blockIdx.x * r3d_icp::kSums);
   }
   if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)swept);
 }
@@ -491,18 +517,24 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
   return R3D_OK;
 }
 
-int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                       int presorted, int64_t* h_tiles_swept) {
+static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                               int presorted, int64_t* h_tiles_swept, bool want_sums, float max_d2, float dead_zone,
+                               double* d_sums_out) {
   R3D_REQUIRE(ix != nullptr, "nn index is NULL");
   r3d_ctx* ctx = ix->ctx;
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(n_src >= 0, "negative cloud size");
   if (h_tiles_swept) *h_tiles_swept = 0;
-  if (n_src == 0) return R3D_OK;
+  hipStream_t st = ctx->stream;
+  if (want_sums) R3D_REQUIRE(d_sums_out != nullptr, "d_sums_out is NULL");
+  if (n_src == 0) {
+    if (want_sums) R3D_HIP(hipMemsetAsync(d_sums_out, 0, r3d_icp::kSums * sizeof(double), st));
+    return R3D_OK;
+  }
   R3D_REQUIRE(n_src < ((int64_t)1 << 32), "source cloud too large");
   R3D_REQUIRE(d_src && d_idx_out, "NULL device pointer");
-  hipStream_t st = ctx->stream;
+  R3D_REQUIRE(!want_sums || d_d2_out != nullptr, "the fused pair sums need the d2 output array");
   void *src4 = nullptr, *misc = nullptr;
   if (!presorted) {
     // one-off query: sort a float4 copy of the sources into index order (results are scattered back by index)
@@ -515,19 +547,28 @@ int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint
     hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_src + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_src,
                        (const uint64_t*)keys, n_src, n_src, src_idx_bits, (float4*)src4);
   }
-  if ((rc = r3d_scratch(ctx, 5, (size_t)n_src * 4 + 64, &misc))) return rc;
+  if ((rc = r3d_scratch(ctx, 5, (size_t)n_src * 5 + 64, &misc))) return rc;
   unsigned long long* stats = static_cast<unsigned long long*>(misc);  // [0] tile sweeps
   unsigned* tie_count = reinterpret_cast<unsigned*>(stats + 2);
   uint32_t* tie_list = reinterpret_cast<uint32_t*>(stats + 4);
+  unsigned char* tie_flag = want_sums ? reinterpret_cast<unsigned char*>(tie_list + n_src) : nullptr;
   R3D_HIP(hipMemsetAsync(misc, 0, 32, st));
   int S = ctx->nn_variant;
   if (S != 1 && S != 2 && S != 4) S = 1;
   const int64_t per_block = (int64_t)kThreads * S;
   const unsigned blocks = (unsigned)((n_src + per_block - 1) / per_block);
+  const int tie_blocks = 64;  // fixed: the follow-up pass over flagged sources is part of the reduction order
+  double* partials = nullptr;
+  if (want_sums) {
+    void* pv = nullptr;
+    if ((rc = r3d_scratch(ctx, 4, ((size_t)blocks + tie_blocks) * r3d_icp::kSums * sizeof(double), &pv))) return rc;
+    partials = static_cast<double*>(pv);
+  }
 #define R3D_LAUNCH_CULL(SS, FMT, PTR)                                                                                  \
   hipLaunchKernelGGL((nn_cull_kernel<SS, FMT>), dim3(blocks), dim3(kThreads), 0, st, (const void*)(PTR), n_src,        \
                      (const float*)ix->d_frame, ix->axis_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box,         \
-                     ix->d_sub_box, ix->d_super_box, ix->d_tile_code, d_idx_out, d_d2_out, tie_list, tie_count, stats)
+                     ix->d_sub_box, ix->d_super_box, ix->d_tile_code, d_idx_out, d_d2_out, tie_list, tie_count, stats,   \
+                     partials, tie_flag, max_d2, dead_zone)
   if (presorted) {
     if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
     else if (S == 2) R3D_LAUNCH_CULL(2, false, d_src);
@@ -548,6 +589,17 @@ int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint
     *h_tiles_swept = (int64_t)v;
   }
   return R3D_OK;
+}
+
+int r3d_nn_index_query(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                       int presorted, int64_t* h_tiles_swept) {
+  return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, presorted, h_tiles_swept, false, -1.f, 0.f, nullptr);
+}
+
+int r3d_nn_index_query_sums(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                            int presorted, float max_d2, float dead_zone, double* d_sums_out) {
+  return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, presorted, nullptr, true, max_d2, dead_zone,
+                             d_sums_out);
 }
 
 // gathers xyz rows by the index part of sorted keys

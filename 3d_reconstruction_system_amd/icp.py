@@ -18,24 +18,43 @@ from .device import default_context
 
 
 def umeyama_from_sums(sums, with_scale=True):
-    """4x4 T = [sR t; 0 1] minimising sum |q - (s R p + t)|^2 from the 18 sums of
-    r3d_icp_accumulate: n, sum p (3), sum q (3), sum p_a q_b (9, a major), sum |p|^2, sum |q|^2."""
-    sums = np.asarray(sums, dtype=np.float64)
-    n = sums[0]
-    if not n >= 3:
-        raise ValueError("need at least 3 matched pairs (got %g)" % n)
-    mu_p, mu_q = sums[1:4] / n, sums[4:7] / n
-    cov_pq = sums[7:16].reshape(3, 3) / n - np.outer(mu_p, mu_q)   # E[(p-mu_p)(q-mu_q)^T]
-    var_p = sums[16] / n - mu_p @ mu_p
-    U, D, Vt = np.linalg.svd(cov_pq.T)                             # Sigma_qp = U D V^T
-    S = np.eye(3)
-    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
-        S[2, 2] = -1.0
-    R = U @ S @ Vt
-    s = float(np.trace(np.diag(D) @ S) / var_p) if with_scale else 1.0
+    """4x4 T = [sR t; 0 1] minimising sum w |q - (s R p + t)|^2 from the 18 sums of
+    r3d_icp_accumulate: n, sum p (3), sum q (3), sum p_a q_b (9, a major), sum |p|^2, sum |q|^2.
+    Solved by the library (r3d_umeyama_from_sums: fp64 one-sided Jacobi SVD) -- the same code the
+    device-side solve of r3d_icp_iterate runs."""
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    if sums.shape != (18,):
+        raise ValueError("expected 18 sums")
+    T = np.zeros(16, dtype=np.float64)
+    rc = L.load().r3d_umeyama_from_sums(sums.ctypes.data, 1 if with_scale else 0, T.ctypes.data, None)
+    if rc != L.OK:
+        raise ValueError("need at least 3 matched pairs with some spread (weight sum %g)" % sums[0])
+    return T.reshape(4, 4)
+
+
+def swap_pair_sums(sums):
+    """The 18 sums with the roles of p and q exchanged."""
+    s = np.asarray(sums, dtype=np.float64)
+    out = s.copy()
+    out[1:4], out[4:7] = s[4:7], s[1:4]
+    out[7:16] = s[7:16].reshape(3, 3).T.reshape(9)
+    out[16], out[17] = s[17], s[16]
+    return out
+
+
+def moments_init(mom_src, mom_tgt):
+    """Coarse similarity from per-cloud moments (sum p, sum |p|^2): centroid onto centroid, RMS radius onto RMS
+    radius, no rotation.  mom_*: the 18 sums of a cloud paired with itself."""
+    def stats(m):
+        n = m[0]
+        mu = m[1:4] / n
+        return mu, np.sqrt(max(m[16] / n - mu @ mu, 0.0))
+    mu_p, r_p = stats(np.asarray(mom_src, dtype=np.float64))
+    mu_q, r_q = stats(np.asarray(mom_tgt, dtype=np.float64))
+    s = r_q / r_p if r_p > 0 and r_q > 0 else 1.0
     T = np.eye(4)
-    T[:3, :3] = s * R
-    T[:3, 3] = mu_q - s * (R @ mu_p)
+    T[:3, :3] *= s
+    T[:3, 3] = mu_q - s * mu_p
     return T
 
 
@@ -70,6 +89,9 @@ class NNIndex:
             pass
 
 
+STATE_DOUBLES, STATE_HISTORY = 512, 48       # R3D_ICP_STATE_DOUBLES / R3D_ICP_STATE_HISTORY (include/r3d.h)
+
+
 class IcpDevice:
     """Source / target clouds resident on one GPU.  culled=True (default) answers NN queries through the
     Morton-tile index (same results, far fewer pair evaluations); culled=False runs the plain brute-force sweep."""
@@ -88,8 +110,11 @@ class IcpDevice:
         self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
         self.d_idx = c.alloc(max(self.n * 4, 16))
         self.d_d2 = c.alloc(max(self.n * 4, 16))
+        self.d_sums = c.alloc(18 * 8)
+        self.d_state = c.alloc(STATE_DOUBLES * 8)
         self.index = NNIndex(c, self.d_tgt.ptr, self.m) if culled else None
         self.d_perm = None
+        self._back = None            # lazily built: reverse-direction search (target -> source snapshot)
         if self.index is not None and self.n:
             # put the source cloud into the index's Morton order ONCE: rigid / similarity moves keep every
             # workgroup's 256 sources a compact blob, so no later query needs to sort.  d_perm maps back.
@@ -104,12 +129,108 @@ class IcpDevice:
                                  self.d_d2.ptr))
         return 0
 
-    def sums(self, max_d2=-1.0):
+    def _download_sums(self):
+        return self.d_sums.download(np.float64, 18)
+
+    def sums(self, max_d2=-1.0, dead_zone=0.0):
+        """The 18 pair sums over the current matches (separate gather pass, r3d_icp_accumulate_dev)."""
         c = self.ctx
-        out = np.zeros(18, dtype=np.float64)
-        L.check(c.lib.r3d_icp_accumulate(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
-                                         self.d_d2.ptr if max_d2 >= 0 else None, float(max_d2), out.ctypes.data))
-        return out
+        need_d2 = max_d2 >= 0 or dead_zone > 0
+        L.check(c.lib.r3d_icp_accumulate_dev(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
+                                             self.d_d2.ptr if need_d2 else None, float(max_d2), float(dead_zone),
+                                             self.d_sums.ptr))
+        return self._download_sums()
+
+    def nn_sums(self, max_d2=-1.0, dead_zone=0.0):
+        """Nearest neighbours AND the 18 sums in one pass (culled index: sums taken in the query kernel's epilogue)."""
+        c = self.ctx
+        if self.index is not None:
+            L.check(c.lib.r3d_nn_index_query_sums(self.index.handle, self.d_src.ptr, self.n, self.d_idx.ptr,
+                                                  self.d_d2.ptr, 1, float(max_d2), float(dead_zone), self.d_sums.ptr))
+            return self._download_sums()
+        self.nn()
+        return self.sums(max_d2, dead_zone)
+
+    def moments(self, which):
+        """The 18 sums of one cloud paired with itself: [0] n, [1:4] sum p, [7:16] sum p p^T, [16] sum |p|^2."""
+        c = self.ctx
+        buf, n = (self.d_src, self.n) if which == "src" else (self.d_tgt, self.m)
+        L.check(c.lib.r3d_icp_accumulate_dev(c.handle, buf.ptr, n, buf.ptr, n, None, None, -1.0, 0.0, self.d_sums.ptr))
+        return self._download_sums()
+
+    def target_spacing(self, max_queries=65536):
+        """Median nearest-neighbour distance between two interleaved halves of the target cloud: its sampling
+        resolution, independent of how the clouds are aligned."""
+        if self.m < 8:
+            return 0.0
+        c = self.ctx
+        tgt = self.d_tgt.download(np.float32, self.m * 3).reshape(-1, 3)
+        base, probe = tgt[1::2], tgt[0::2]
+        probe = probe[::max(1, probe.shape[0] // max_queries)]
+        d_base = c.alloc(base.nbytes).upload(base)
+        d_probe = c.alloc(probe.nbytes).upload(probe)
+        d_i, d_d = c.alloc(probe.shape[0] * 4), c.alloc(probe.shape[0] * 4)
+        ix = NNIndex(c, d_base.ptr, base.shape[0])
+        try:
+            ix.query(d_probe.ptr, probe.shape[0], d_i.ptr, d_d.ptr)
+            d2 = d_d.download(np.float32, probe.shape[0])
+        finally:
+            ix.close()
+            for b in (d_base, d_probe, d_i, d_d):
+                b.free()
+        d2 = d2[np.isfinite(d2)]
+        return float(np.sqrt(np.median(d2))) if d2.size else 0.0
+
+    # ---- reverse direction (symmetric coarse phase): every TARGET point's nearest point of a source snapshot ----
+    def back_begin(self):
+        """Freeze the current source cloud as a second index; keep a copy of the target in that index's order."""
+        c = self.ctx
+        self.back_end()
+        ix = NNIndex(c, self.d_src.ptr, self.n)
+        d_tgt_b = c.alloc(self.m * 12)
+        L.check(c.lib.r3d_memcpy_d2d(c.handle, d_tgt_b.ptr, self.d_tgt.ptr, self.m * 12))
+        ix.sort_cloud(d_tgt_b.ptr, self.m, None)
+        self._back = {"index": ix, "tgt": d_tgt_b, "moved": c.alloc(self.m * 12), "idx": c.alloc(self.m * 4),
+                      "d2": c.alloc(self.m * 4), "sums": c.alloc(18 * 8)}
+
+    def back_sums(self, T_since, dead_zone=0.0):
+        """18 sums over the pairs (p = CURRENT source point nearest to target point q, q): the target is taken
+        into the snapshot's frame by T_since^-1, searched there, and the sums are formed in the world frame."""
+        c, b = self.ctx, self._back
+        T_inv = np.ascontiguousarray(np.linalg.inv(T_since), dtype=np.float64)
+        s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
+        L.check(c.lib.r3d_apply_T(c.handle, b["tgt"].ptr, L.F32, self.m, T_inv.ctypes.data, b["moved"].ptr, L.F32))
+        b["index"].query(b["moved"].ptr, self.m, b["idx"].ptr, b["d2"].ptr, presorted=True)
+        # roles swapped: "src" = target rows (world frame), "tgt" = current source rows; d2 lives in the snapshot frame
+        L.check(c.lib.r3d_icp_accumulate_dev(c.handle, b["tgt"].ptr, self.m, self.d_src.ptr, self.n, b["idx"].ptr,
+                                             b["d2"].ptr, -1.0, float(dead_zone) / s_since if dead_zone > 0 else 0.0,
+                                             b["sums"].ptr))
+        return swap_pair_sums(b["sums"].download(np.float64, 18))
+
+    def back_end(self):
+        if self._back is not None:
+            self._back["index"].close()
+            for k in ("tgt", "moved", "idx", "d2", "sums"):
+                self._back[k].free()
+            self._back = None
+
+    # ---- whole iterations on the GPU, no host round trip ----
+    def state_reset(self):
+        c = self.ctx
+        L.check(c.lib.r3d_icp_state_reset(c.handle, self.d_state.ptr))
+
+    def iterate(self, n_iters, with_scale=True, max_d2=-1.0):
+        c = self.ctx
+        L.check(c.lib.r3d_icp_iterate(c.handle, self.index.handle if self.index is not None else None, self.d_src.ptr,
+                                      self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr, self.d_d2.ptr, int(n_iters),
+                                      1 if with_scale else 0, float(max_d2), self.d_state.ptr))
+
+    def state(self):
+        st = self.d_state.download(np.float64, STATE_DOUBLES)
+        it = int(st[32])
+        return {"T_total": st[0:16].reshape(4, 4).copy(), "T_step": st[16:32].reshape(4, 4).copy(), "iterations": it,
+                "degenerate": bool(st[33]), "rms": float(st[34]), "pairs": float(st[35]),
+                "rms_history": st[STATE_HISTORY:STATE_HISTORY + min(it, STATE_DOUBLES - STATE_HISTORY)].tolist()}
 
     def move_source(self, T):
         c = self.ctx
@@ -135,9 +256,10 @@ class IcpDevice:
         return self._unpermute(self.d_src.download(np.float32, self.n * 3).reshape(-1, 3))
 
     def free(self):
+        self.back_end()
         if self.index is not None:
             self.index.close()
-        for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2, self.d_perm):
+        for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2, self.d_perm, self.d_sums, self.d_state):
             if b is not None:
                 b.free()
 
@@ -164,29 +286,90 @@ def nearest_neighbours(src, tgt, ctx=None, culled=False):
     return idx, d2
 
 
-def icp_similarity(src, tgt, max_iter=30, tol=1e-7, with_scale=True, trim_d2=None, ctx=None, culled=True):
-    """Iterate NN + Umeyama until the RMS match distance stops improving by more than `tol`
-    (relative).  Returns (T 4x4 mapping src -> tgt, info dict).  trim_d2: ignore pairs whose
-    squared distance exceeds it (None = use all)."""
+def _step_size(T, extent):
+    """How far a 4x4 step is from the identity: linear part absolutely, translation relative to the cloud size."""
+    return max(float(np.abs(T[:3, :3] - np.eye(3)).max()), float(np.abs(T[:3, 3]).max()) / max(extent, 1e-30))
+
+
+def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=None, ctx=None, culled=True, init="auto",
+                   check_every=4, dead_zone=None, max_coarse=40, coarse_tol=2e-4):
+    """Similarity (s, R, t) that maps `src` onto `tgt`: the T_data.txt of transfer_T_icp.py:99-108.
+    Returns (T 4x4, info dict).  Three stages, all on device-resident clouds:
+
+      init   "identity": none.  "moments": centroid onto centroid and RMS radius onto RMS radius (closes a scale gap
+             such as monocular depth vs COLMAP units).  "auto" (default): moments, then the symmetric dead-zone stage.
+             A 4x4 array: that transform.
+      coarse (init="auto") SYMMETRIC ICP under the cost max(0, d - dead_zone)^2: source -> target and target ->
+             source matches together, each weighted w = max(0, 1 - dead_zone/d).  Matches closer than the target's
+             sampling resolution (dead_zone, default 2 x target_spacing()) carry no weight, so the extents of the two
+             clouds decide -- plain ICP stalls on a densely, evenly sampled volume, and one-directional ICP with a free
+             scale can always shrink the source into the target.  Host solve per step (a handful of steps).
+      fine   plain ICP, nearest neighbour -> 18 sums -> Umeyama -> move, until the RMS match distance stops improving
+             by more than `tol` (relative).  Runs in blocks of `check_every` iterations enqueued with no host round trip
+             (r3d_icp_iterate: fused NN + sums, device-side solve); the host only reads the rms history per block.
+    trim_d2: ignore pairs whose squared distance exceeds it in the fine stage (None = use all)."""
     dev = IcpDevice(src, tgt, ctx, culled)
+    info = {"init": init if isinstance(init, str) else "matrix", "coarse_iterations": 0, "coarse_history": []}
     T_total = np.eye(4)
-    history = []
-    prev = None
     try:
-        for it in range(max_iter):
-            dev.nn()
-            sums = dev.sums(-1.0 if trim_d2 is None else float(trim_d2))
-            n = sums[0]
-            # sum |p-q|^2 = sum|p|^2 + sum|q|^2 - 2 tr(sum p q^T)
-            rms = float(np.sqrt(max(sums[16] + sums[17] - 2.0 * (sums[7] + sums[11] + sums[15]), 0.0) / max(n, 1.0)))
-            history.append(rms)
-            T = umeyama_from_sums(sums, with_scale)
-            dev.move_source(T)
-            T_total = T @ T_total
-            if prev is not None and abs(prev - rms) <= tol * max(prev, 1e-30):
-                break
-            prev = rms
-        dev.ctx.sync()
+        if dev.n < 3:
+            raise ValueError("need at least 3 source points")
+        mode = init if isinstance(init, str) else "matrix"
+        if mode not in ("identity", "moments", "auto", "matrix"):
+            raise ValueError("init must be 'identity', 'moments', 'auto' or a 4x4 matrix")
+        mom_t = dev.moments("tgt") if mode in ("moments", "auto") else None
+        if mode == "matrix":
+            T_total = np.array(init, dtype=np.float64).reshape(4, 4)
+            dev.move_source(T_total)
+        elif mode in ("moments", "auto"):
+            mom_s = dev.moments("src")
+            T_total = moments_init(mom_s, mom_t)
+            if not with_scale:
+                T_total = np.eye(4)
+                T_total[:3, 3] = mom_t[1:4] / mom_t[0] - mom_s[1:4] / mom_s[0]
+            dev.move_source(T_total)
+        if mode == "auto" and dev.index is not None:
+            mu = mom_t[1:4] / mom_t[0]
+            extent = float(np.sqrt(max(mom_t[16] / mom_t[0] - mu @ mu, 0.0)))
+            d0 = float(dead_zone) if dead_zone is not None else 2.0 * dev.target_spacing()
+            info["dead_zone"] = d0
+            if d0 > 0 and extent > 0:
+                dev.back_begin()
+                T_since = np.eye(4)
+                for _ in range(max_coarse):
+                    sums = dev.nn_sums(-1.0, d0) + dev.back_sums(T_since, d0)
+                    info["coarse_history"].append(float(sums[0]))
+                    if not sums[0] >= 3.0:
+                        break                       # every match is inside the dead zone: extents agree
+                    try:
+                        T = umeyama_from_sums(sums, with_scale)
+                    except ValueError:
+                        break
+                    dev.move_source(T)
+                    T_total = T @ T_total
+                    T_since = T @ T_since
+                    info["coarse_iterations"] += 1
+                    if _step_size(T, extent) <= coarse_tol:
+                        break
+                dev.back_end()
+        # fine stage
+        dev.state_reset()
+        max_d2 = -1.0 if trim_d2 is None else float(trim_d2)
+        done, stop_at = 0, None
+        while done < max_iter and stop_at is None:
+            k = min(max(int(check_every), 1), max_iter - done)
+            dev.iterate(k, with_scale, max_d2)
+            done += k
+            st = dev.state()
+            h = st["rms_history"]
+            for i in range(max(1, done - k), len(h)):
+                if abs(h[i - 1] - h[i]) <= tol * max(h[i - 1], 1e-30):
+                    stop_at = i
+                    break
+        st = dev.state()
+        T_total = st["T_total"] @ T_total
+        info.update({"iterations": st["iterations"], "rms_history": st["rms_history"], "degenerate": st["degenerate"],
+                     "converged_at": stop_at})
     finally:
         dev.free()
-    return T_total, {"iterations": len(history), "rms_history": history}
+    return T_total, info

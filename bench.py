@@ -54,21 +54,64 @@ def cpu_baseline(sample_frames=1):
     O.fuse_frames(depth, q, t)
     dt_vec = time.perf_counter() - t0
     pts = sample_frames * H * W
-    return {"value": round(pts / dt / 1e6, 5), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+    return {"value": round(pts / dt / 1e6, 5), "unit": "Mpoints/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d frame(s) of 1280x384 u8 (%d points), per-point Python loops + txt round trip as "
                       "camera_to_world.py:67-105, no PLY; %.1f s" % (sample_frames, pts, dt),
             "vectorised_numpy_fp64_Mpoints_s": round(pts / dt_vec / 1e6, 3),
             "host_cpus": os.cpu_count()}
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command, if present."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pmc_traffic(frames, out_dtype, depth="u8"):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (separate --pmc passes over this same command).
+    Counters cannot be read from inside the process, so this is a RECORDED figure: it is emitted only when this run's
+    launch is the one that was profiled (same frames, depth and output types), otherwise null."""
     p = os.path.join(ROOT, "profiles", "pmc_fuse_latest.json")
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            rec = json.load(f)
     except Exception:
         return None
+    cfg = rec.get("config", {"frames": 100, "out_dtype": "float32", "depth": "u8"})   # r01 file: the C2 default launch
+    if (cfg.get("frames"), cfg.get("out_dtype"), cfg.get("depth")) != (frames, out_dtype, depth):
+        return None
+    return rec.get("hbm_bytes_per_launch")
+
+
+def kernel_duration_ms(torch, stream, launch, min_launches=200, min_ms=50.0, warm=50):
+    """Median duration of one launch of the dominant kernel, independent of --steps: after `warm` untimed launches,
+    at least `min_launches` launches (and at least `min_ms` of GPU time) timed with HIP events on the launch stream.  Returns (median_ms, mean_ms, n)."""
+    for _ in range(warm):
+        launch()
+    torch.cuda.synchronize()
+    per = 10                      # launches between two events: the event packets' own cost is spread over 10 launches
+    durations, total = [], 0.0
+    while len(durations) * per < min_launches or total < min_ms:
+        n = 20
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record(stream)
+        for i in range(n):
+            for _ in range(per):
+                launch()
+            evs[i + 1].record(stream)
+        evs[n].synchronize()
+        block = [evs[i].elapsed_time(evs[i + 1]) / per for i in range(n)]
+        durations += block
+        total += sum(block) * per
+        if len(durations) * per >= 4000:
+            break
+    durations.sort()
+    return durations[len(durations) // 2], sum(durations) / len(durations), len(durations) * per
 
 
 def secondary(a):
@@ -249,6 +292,12 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # kernel-only duration of the dominant kernel (this rank's fused launch), measured BEFORE the timed region and
+    # independently of --steps: it doubles as the clock ramp, so that a short --steps run sees a warm GPU
+    bytes_per_launch = n_local * (1 + 3 * (4 if a.out_dtype == "float32" else 8))
+    kernel_ms, kernel_mean_ms, kernel_n = kernel_duration_ms(torch, stream, fuse)
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+
     for _ in range(a.warmup):
         step()
     fence()
@@ -260,24 +309,11 @@ def main():
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / max(a.steps, 1)       # this rank's stream, first step's start to last step's end
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
-    # kernel-only duration of the dominant kernel: HIP events on the launch stream, K back-to-back launches
-    for _ in range(5):
-        fuse()
-    torch.cuda.synchronize(dev)
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record(stream)
-    for _ in range(a.steps):
-        fuse()
-    k1.record(stream)
-    torch.cuda.synchronize(dev)
-    kernel_ms = k0.elapsed_time(k1) / a.steps
-    bytes_per_launch = n_local * (1 + 3 * (4 if a.out_dtype == "float32" else 8))
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
     # N > 1: the other assembly strategies, timed briefly after the main region (reported, not `value`)
     assemble_ms = {}
@@ -301,6 +337,8 @@ def main():
             except Exception as e:  # pragma: no cover
                 assemble_ms[m] = "failed: %s" % type(e).__name__
 
+    # which kernel the library dispatched for this launch (r3d_fuse.hip picks by output type)
+    kernel_label = "fuse_lane_kernel<u8,f32,pose>" if a.out_dtype == "float32" else "fuse_tile_kernel<u8,f64,pose>"
     if rank == 0:
         total_pts = world * n_local * a.steps
         line = {
@@ -326,10 +364,14 @@ def main():
                        "assemble": mode,
                        "parallelism": "frames sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                         "kernel": "fuse_lane_kernel<u8,%s,pose>" % ("f32" if a.out_dtype == "float32" else "f64"),
-                         "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "timing": "HIP events on the launch stream over %d back-to-back launches" % a.steps},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(F, a.out_dtype),
+                         "kernel": kernel_label,
+                         "kernel_ms": round(kernel_ms, 5), "kernel_mean_ms": round(kernel_mean_ms, 5),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "timing": "median over %d launches in groups of 10 between HIP events on the launch stream, "
+                                   "after 50 untimed launches, before the timed region" % kernel_n,
+                         "kernel_ms_le_ms_per_step": bool(kernel_ms <= elapsed / a.steps * 1e3)},
+            "gpu_ms_per_step": round(gpu_ms_per_step, 5),
             "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),
         }
         if assemble_ms:

@@ -18,10 +18,12 @@
  *     r3d_dev_alloc / r3d_host_alloc memory) must not be USED after r3d_ctx_destroy; destroying
  *     them afterwards is allowed (their destroy functions do not touch the ctx).
  *   - point clouds are AoS xyz, row-major [n][3], float32 (R3D_F32) or float64
- *     (R3D_F64).  All arithmetic is done in fp64 registers exactly in the reference's
- *     evaluation order and rounded ONCE on store, so R3D_F32 output is the correctly
- *     rounded fp64 result (<= 6e-8 relative per component) and R3D_F64 output equals the
- *     reference's fp64 up to dot-product summation order (~1e-16).
+ *     (R3D_F64).  All arithmetic is done in fp64 registers in the reference's evaluation
+ *     order -- products and differences exactly as written there; the 3-term dot products of the
+ *     SE(3) / 4x4 apply are an fma chain fma(r2,dz, fma(r1,dy, r0*dx)) -- and rounded ONCE on
+ *     store, so R3D_F32 output is the correctly rounded fp64 result (<= 6e-8 relative per
+ *     component), R3D_F64 unprojection is bit-identical to the reference and R3D_F64 world
+ *     points equal the reference's fp64 up to that dot-product's rounding (~1e-16 relative).
  */
 #ifndef R3D_H
 #define R3D_H
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 100 /* 0.1.0 */
+#define R3D_VERSION 200 /* 0.2.0 */
 
 /* status codes */
 #define R3D_OK 0
@@ -81,6 +83,7 @@ int r3d_dev_alloc(r3d_ctx* ctx, size_t bytes, void** d_ptr_out);
 int r3d_dev_free(r3d_ctx* ctx, void* d_ptr);
 int r3d_memcpy_h2d(r3d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* async on ctx stream */
 int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on ctx stream */
+int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes); /* async on ctx stream */
 int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
 /* Pinned (page-locked) host memory.  The *_host entry points detect pinned buffers and DMA straight from/to them;
  * pageable buffers go through the library's own pinned staging ring with multi-threaded copies. */
@@ -136,11 +139,16 @@ int r3d_apply_T(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_poin
                 void* d_xyz_out, int out_dtype);
 int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n_points, const double* h_T,
                      void* h_xyz_out, int out_dtype);
+/* The same with the matrix in HBM (16 doubles, row-major; e.g. the step a device-side ICP solve just wrote). */
+int r3d_apply_T_dev(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* d_T,
+                    void* d_xyz_out, int out_dtype);
 
 /* ---- a8: ICP estimation kernels (NOT in the reference -- transfer_T_icp.py only consumes a
  * T_data.txt made by an external tool; build-defined per SURVEY.md 8(a8)).
  * r3d_icp_nn: for each source point the index of the nearest target point under squared L2
- * computed in fp32 as ((sx-tx)^2+(sy-ty)^2)+(sz-tz)^2 with fma contraction off, lowest index wins ties.
+ * computed in fp32 as d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx)) with dx = sx-tx, dy = sy-ty, dz = sz-tz (one rounding
+ * for dx*dx, one per fused multiply-add; no other contraction), lowest index wins exact ties.  This expression IS
+ * the specification: brute force, culled index, fallback and oracle all evaluate exactly it.
  * src/tgt are float32 xyz AoS.  d_idx_out [n_src] uint32, d_d2_out [n_src] float32 (may be NULL). */
 int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                uint32_t* d_idx_out, float* d_d2_out);
@@ -169,6 +177,40 @@ int r3d_nn_index_sort_cloud(r3d_nn_index* index, float* d_xyz, int64_t n_points,
  * Deterministic (fixed two-stage tree, no float atomics).  h_sums is a host pointer; synchronous. */
 int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                        const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums);
+
+/* Weighted, device-resident variant: the 18 sums go to d_sums_out (HBM, 18 doubles), asynchronously on the ctx stream.
+ * dead_zone > 0 weights every pair by w = max(0, 1 - dead_zone/d), d = sqrt(d2) -- the IRLS weight of the cost
+ * max(0, d - dead_zone)^2, which treats a densely sampled cloud as the solid it samples (a match closer than the
+ * sampling resolution carries no information about the transform); every sum above is then a weighted sum and
+ * sums[0] the weight total.  dead_zone <= 0: w = 1.  d_d2 is required when max_d2 >= 0 or dead_zone > 0.
+ * d_idx == NULL pairs row k with row k (with d_tgt == d_src: the moments sum p, sum p p^T, sum |p|^2 of one cloud). */
+int r3d_icp_accumulate_dev(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                           const uint32_t* d_idx, const float* d_d2, float max_d2, float dead_zone, double* d_sums_out);
+/* r3d_nn_index_query with the pair sums taken in the query kernel's own epilogue (each lane holds its source and its
+ * winner there): one pass instead of NN + gather.  Same idx / d2 as r3d_nn_index_query, same sums as
+ * r3d_icp_accumulate_dev up to fp64 summation order; bitwise repeatable run to run.  d_d2_out must not be NULL. */
+int r3d_nn_index_query_sums(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out,
+                            float* d_d2_out, int presorted, float max_d2, float dead_zone, double* d_sums_out);
+/* Closed-form similarity from the 18 sums (Umeyama 1991): h_T (16 doubles, row-major 4x4) = [sR t; 0 1] minimising
+ * sum w |q - (sRp + t)|^2; with_scale = 0 pins s = 1.  h_rms_out (optional) = sqrt(sum w|p-q|^2 / sum w) before the
+ * step.  Pure host arithmetic (3x3 one-sided Jacobi SVD, fp64), no GPU needed -- and the very code the device-side
+ * solve runs.  R3D_ERR_INVALID when the fit is undefined (weight sum < 3, no spread). */
+int r3d_umeyama_from_sums(const double* h_sums, int with_scale, double* h_T, double* h_rms_out);
+/* Device-resident ICP state: R3D_ICP_STATE_DOUBLES doubles in HBM.
+ *   [0..15] T_total (row-major 4x4, maps the ORIGINAL source onto the target), [16..31] the last step,
+ *   [32] steps solved, [33] status (1 = some step was degenerate and skipped), [34] rms seen by the last step,
+ *   [35] its weight sum, [48+k] rms seen by step k (while it fits). */
+#define R3D_ICP_STATE_DOUBLES 512
+#define R3D_ICP_STATE_HISTORY 48
+int r3d_icp_state_reset(r3d_ctx* ctx, double* d_state);
+/* One solve on the GPU (single thread, fp64): step = umeyama(d_sums); T_total <- step . T_total; history. Asynchronous. */
+int r3d_icp_solve_dev(r3d_ctx* ctx, const double* d_sums, int with_scale, double* d_state);
+/* n_iters whole ICP iterations enqueued back to back with NO host round trip: nearest neighbours (+ fused sums) ->
+ * device solve -> source cloud moved in place by the step (r3d_apply_T_dev).  index != NULL: culled exact NN, d_src must
+ * be in the index's order (r3d_nn_index_sort_cloud; similarity moves preserve it); index == NULL: brute force against
+ * d_tgt.  The host reads d_state whenever it wants to look at the rms history / convergence. */
+int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                    uint32_t* d_idx, float* d_d2, int n_iters, int with_scale, float max_d2, double* d_state);
 
 /* ---- f1: reference-layout ASCII serialisation on the host (multi-threaded C++).
  * r3d_format_ply: the byte layout of genply() (camera_to_world.py:112-134): header with 4-space

@@ -42,21 +42,63 @@ def nearest_neighbours(src, tgt, chunk=512):
     return idx, d2
 
 
-def pair_sums(src, tgt, idx, d2=None, max_d2=-1.0):
-    """The 18 fp64 sums: n, sum p, sum q, sum p_a q_b (a major), sum |p|^2, sum |q|^2."""
+def pair_weights(d2, dead_zone):
+    """w = max(0, 1 - dead_zone/d), d = sqrt(d2) in fp64: the IRLS weight of the cost max(0, d - dead_zone)^2.
+    dead_zone <= 0: all ones."""
+    d2 = np.asarray(d2, dtype=np.float32).astype(np.float64)
+    if not dead_zone > 0:
+        return np.ones_like(d2)
+    d = np.sqrt(d2)
+    dz = float(np.float32(dead_zone))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(d > dz, 1.0 - dz / d, 0.0)
+
+
+def pair_sums(src, tgt, idx, d2=None, max_d2=-1.0, dead_zone=0.0):
+    """The 18 fp64 sums: n, sum p, sum q, sum p_a q_b (a major), sum |p|^2, sum |q|^2; weighted by
+    pair_weights(d2, dead_zone) when dead_zone > 0 (n is then the weight total)."""
     p = np.asarray(src, dtype=np.float32).astype(np.float64)
     q = np.asarray(tgt, dtype=np.float32).astype(np.float64)[np.asarray(idx, dtype=np.int64)]
+    w = pair_weights(d2, dead_zone) if dead_zone > 0 else np.ones(p.shape[0])
     if max_d2 >= 0:
         keep = np.asarray(d2) <= np.float32(max_d2)
-        p, q = p[keep], q[keep]
+        p, q, w = p[keep], q[keep], w[keep]
     out = np.zeros(18)
-    out[0] = p.shape[0]
-    out[1:4] = p.sum(0)
-    out[4:7] = q.sum(0)
-    out[7:16] = (p[:, :, None] * q[:, None, :]).sum(0).reshape(9)
-    out[16] = (p * p).sum()
-    out[17] = (q * q).sum()
+    wp = p * w[:, None]
+    out[0] = w.sum()
+    out[1:4] = wp.sum(0)
+    out[4:7] = (q * w[:, None]).sum(0)
+    out[7:16] = (wp[:, :, None] * q[:, None, :]).sum(0).reshape(9)
+    out[16] = (wp * p).sum()
+    out[17] = (q * q * w[:, None]).sum()
     return out
+
+
+def swap_pair_sums(s):
+    out = np.array(s, dtype=np.float64)
+    out[1:4], out[4:7] = s[4:7], s[1:4]
+    out[7:16] = np.asarray(s[7:16]).reshape(3, 3).T.reshape(9)
+    out[16], out[17] = s[17], s[16]
+    return out
+
+
+def umeyama_from_sums(sums, with_scale=True):
+    """Umeyama's closed form from the 18 (weighted) sums, numpy SVD."""
+    sums = np.asarray(sums, dtype=np.float64)
+    n = sums[0]
+    mu_p, mu_q = sums[1:4] / n, sums[4:7] / n
+    cov_pq = sums[7:16].reshape(3, 3) / n - np.outer(mu_p, mu_q)
+    var_p = sums[16] / n - mu_p @ mu_p
+    U, D, Vt = np.linalg.svd(cov_pq.T)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1.0
+    R = U @ S @ Vt
+    s = float(np.trace(np.diag(D) @ S) / var_p) if with_scale else 1.0
+    T = np.eye(4)
+    T[:3, :3] = s * R
+    T[:3, 3] = mu_q - s * (R @ mu_p)
+    return T
 
 
 def umeyama(p, q, with_scale=True):
@@ -95,6 +137,73 @@ def icp_similarity(src, tgt, max_iter=30, tol=1e-7, with_scale=True):
             break
         prev = rms
     return T_total
+
+
+def apply_T32(xyz, T):
+    """float32 cloud moved by a 4x4 in fp64, rounded once (what r3d_apply_T does)."""
+    x = np.asarray(xyz, dtype=np.float32).astype(np.float64)
+    return (x @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+
+
+def target_spacing(tgt, max_queries=65536):
+    """Median NN distance between the interleaved halves of the target (its sampling resolution)."""
+    tgt = np.asarray(tgt, dtype=np.float32)
+    base, probe = tgt[1::2], tgt[0::2]
+    probe = probe[::max(1, probe.shape[0] // max_queries)]
+    _i, d2 = nearest_neighbours(probe, base)
+    return float(np.sqrt(np.median(d2)))
+
+
+def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_zone=None, max_coarse=40,
+                        coarse_tol=2e-4):
+    """The build's full estimator restated: moments init -> symmetric dead-zone ICP -> plain ICP
+    (3d_reconstruction_system_amd/icp.py: icp_similarity(init="auto")).  Brute-force NN: small clouds only."""
+    src = np.asarray(src, dtype=np.float32)
+    tgt = np.asarray(tgt, dtype=np.float32)
+    P, Q = src.astype(np.float64), tgt.astype(np.float64)
+    mu_p, mu_q = P.mean(0), Q.mean(0)
+    r_p, r_q = np.sqrt(((P - mu_p) ** 2).sum(1).mean()), np.sqrt(((Q - mu_q) ** 2).sum(1).mean())
+    T_total = np.eye(4)
+    s0 = r_q / r_p if with_scale else 1.0
+    T_total[:3, :3] *= s0
+    T_total[:3, 3] = mu_q - s0 * mu_p
+    cur = apply_T32(src, T_total)
+    d0 = float(dead_zone) if dead_zone is not None else 2.0 * target_spacing(tgt)
+    snap = cur.copy()
+    T_since = np.eye(4)
+    coarse = 0
+    for _ in range(max_coarse):
+        ia, da = nearest_neighbours(cur, tgt)
+        sums = pair_sums(cur, tgt, ia, da, -1.0, d0)
+        T_inv = np.linalg.inv(T_since)
+        s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
+        moved = apply_T32(tgt, T_inv)
+        ib, db = nearest_neighbours(moved, snap)
+        sums = sums + swap_pair_sums(pair_sums(tgt, cur, ib, db, -1.0, d0 / s_since))
+        if not sums[0] >= 3.0:
+            break
+        T = umeyama_from_sums(sums, with_scale)
+        cur = apply_T32(cur, T)
+        T_total = T @ T_total
+        T_since = T @ T_since
+        coarse += 1
+        step = max(np.abs(T[:3, :3] - np.eye(3)).max(), np.abs(T[:3, 3]).max() / r_q)
+        if step <= coarse_tol:
+            break
+    prev = None
+    fine = 0
+    for _ in range(max_iter):
+        idx, d2 = nearest_neighbours(cur, tgt)
+        sums = pair_sums(cur, tgt, idx)
+        rms = float(np.sqrt(max(sums[16] + sums[17] - 2 * (sums[7] + sums[11] + sums[15]), 0.0) / sums[0]))
+        T = umeyama_from_sums(sums, with_scale)
+        cur = apply_T32(cur, T)
+        T_total = T @ T_total
+        fine += 1
+        if prev is not None and abs(prev - rms) <= tol * max(prev, 1e-30):
+            break
+        prev = rms
+    return T_total, {"coarse_iterations": coarse, "iterations": fine, "dead_zone": d0}
 
 
 def synthetic_pair(n_tgt=4000, n_src=3000, seed=7, s=1.7, angle_deg=10.0, t_norm=0.5, noise=0.0, extent=20.0):

@@ -15,4 +15,4 @@ def test_header_compiles_as_c99_and_consumer_links(tmp_path):
     assert build.returncode == 0, build.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode in (0, 77), run.stdout + run.stderr      # 77 = no GPU visible: clean skip, no crash
-    assert "r3d version 100" in run.stdout
+    assert "r3d version 200" in run.stdout

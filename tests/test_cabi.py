@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libr3d_hip.so does not export %s" % s
     assert sorted(L.SIGNATURES) == syms, set(L.SIGNATURES) ^ set(syms)
-    assert lib.r3d_version() == 100
+    assert lib.r3d_version() == 200
 
 
 def test_library_carries_gfx950_code_object():
