@@ -61,6 +61,7 @@ SIGNATURES = {
     "r3d_unproject_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
     "r3d_fuse_frames": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),
     "r3d_fuse_frames_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),
+    "r3d_fuse_frames_rgb": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
     "r3d_se3_apply": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_se3_apply_host": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_apply_T": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "r3d_format_ply": (_i, [_vp, _i, _i64, _vp, _sz, _psz]),
     "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),
     "r3d_write_ply_rgb": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),
+    "r3d_write_ply_rgba": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),
     "r3d_write_xyz_txt": (_i, [C.c_char_p, _vp, _i, _i64, _vp, _i, _i]),
     "r3d_format_xyz_txt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _sz, _psz]),
     "r3d_png_gray_info": (_i, [C.c_char_p, _pi, _pi, _pi]),

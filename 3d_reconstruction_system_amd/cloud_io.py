@@ -144,13 +144,23 @@ def write_ply(path, xyz):
 
 
 def write_ply_rgb(path, xyz, rgb):
-    """Coloured PLY in the reference layout (p2c:55-91): rgb is [N,3] uint8 (R,G,B), alpha column is the literal 0."""
-    xyz = _cloud(xyz)
+    """Coloured PLY in the reference layout (p2c:55-91).  rgb: [N,3] uint8 (R,G,B), or the [N] uint32 rgba words of
+    fuse_frames_rgb (bytes R,G,B,0); the alpha column is the literal 0 either way."""
+    xyz = np.ascontiguousarray(xyz)
+    rgb = np.asarray(rgb)
+    lib = L.load()
+    if rgb.dtype == np.uint32 and rgb.ndim == 1:
+        rgb = np.ascontiguousarray(rgb)
+        if rgb.shape[0] != xyz.shape[0]:
+            raise ValueError("%d colours, cloud has %d points" % (rgb.shape[0], xyz.shape[0]))
+        L.check(lib.r3d_write_ply_rgba(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), rgb.ctypes.data,
+                                       xyz.shape[0]))
+        return
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
     if rgb.shape[0] != xyz.shape[0]:
         raise ValueError("colour image has %d pixels, cloud has %d points" % (rgb.shape[0], xyz.shape[0]))
-    L.check(L.load().r3d_write_ply_rgb(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), rgb.ctypes.data,
-                                       xyz.shape[0]))
+    L.check(lib.r3d_write_ply_rgb(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), rgb.ctypes.data,
+                                  xyz.shape[0]))
 
 
 def read_xyz_txt(path):

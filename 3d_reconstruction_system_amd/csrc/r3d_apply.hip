@@ -2,17 +2,18 @@
 //
 // Replaces local_world(flag=True) / point_camera of transfer_T_icp.py:71-97, 10-12:
 //     p' = (T . [x, y, z, 1]^T)[0:3]        (scale lives in T's 3x3 block)
-// and serves the standalone SE(3) apply of camera_to_world.py:57-59 on an existing cloud
-// (T = [Rinv | -Rinv t]).
+// and serves the standalone SE(3) apply of camera_to_world.py:57-59 on an existing cloud (Rinv . (p - t)).
 //
 // Roofline: HBM, 24 B/point (12 read + 12 written) for f32 clouds.
-// Default (apply_variant 0): lane-per-point rounds.  In each round the 64 lanes of a wave hold 64
-// CONSECUTIVE points: one 12-byte load and one 12-byte nontemporal store per lane at a 12-byte lane
-// stride = 768 contiguous bytes per wave instruction, no LDS, no barrier.  The fused kernel's A/B
-// (profiles/variants_r01.md) showed this shape beating LDS-transposed 16-byte stores by 1.4x.
-// apply_variant 1 keeps that LDS design for comparison: a 256-thread workgroup owns a tile of 1024
-// points = 12 KiB, read and written as tile-linear 16-B pieces staged through LDS.
-// In-place operation is safe in both: a point is read before it is written, by the same lane.
+// Shape (A/B: profiles/r02_ab_kernels.log): a workgroup owns one tile of 1024 consecutive points; all of a lane's
+// loads are issued up front with the NONTEMPORAL hint (a once-read stream: +6 % over cached loads on this 1:1
+// read/write kernel), and every wave store instruction writes one contiguous run, 12 B per lane at a 12-B lane stride
+// (`global_store_dwordx3 ... nt`):
+//   * f32 out (apply_lane_kernel): lane-per-point rounds, one x3 store per point.  6.4 TB/s = 0.80 of peak.
+//   * f64 out (apply_pair_kernel): two lanes per point -- the even lane computes output rows 0,1 and stores
+//     (x_lo x_hi y_lo), the odd lane rows 1,2 and stores (y_hi z_lo z_hi) -- the same trick as fuse_pair_kernel.
+// In-place operation is safe: every load of a wave is complete (s_waitcnt) before its first store, and the two lanes
+// that share a point are neighbours in one wave.
 #include <type_traits>
 
 #include "r3d_internal.h"
@@ -37,147 +38,144 @@ __device__ __forceinline__ void load_T(const ApplyArgs& a, double T[12]) {
   for (int k = 0; k < 12; ++k) T[k] = a.d_T ? a.d_T[k] : a.T[k];
 }
 
-template <typename IT, typename OT, bool VEC, bool SE3>
-__global__ __launch_bounds__(kThreads) void apply_kernel(const ApplyArgs a) {
-  // one buffer, sized for the wider of the two element types
-  constexpr size_t kElt = sizeof(IT) > sizeof(OT) ? sizeof(IT) : sizeof(OT);
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kTile * 3 * kElt];
-  IT* lin = reinterpret_cast<IT*>(lds_raw);
-  OT* lout = reinterpret_cast<OT*>(lds_raw);
-  const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
-  double T[12];
-  load_T(a, T);
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t p_base = tile * kTile;
-    const uint32_t n_pts = (uint32_t)min((uint64_t)kTile, a.n - p_base);
-    const uint32_t n_elts = n_pts * 3;
-    const IT* src = static_cast<const IT*>(a.in) + p_base * 3;
-    OT* dst = static_cast<OT*>(a.out) + p_base * 3;
-
-    // ---- tile -> LDS ----
-    if (VEC) {
-      constexpr uint32_t kPerPiece = 16 / sizeof(IT);
-      const uint32_t n_pieces = n_elts / kPerPiece;
-      using V = typename std::conditional<sizeof(IT) == 4, float4, double2>::type;
-      for (uint32_t q = tid; q < n_pieces; q += kThreads)
-        reinterpret_cast<V*>(lin)[q] = reinterpret_cast<const V*>(src)[q];
-      for (uint32_t e = n_pieces * kPerPiece + tid; e < n_elts; e += kThreads) lin[e] = src[e];
-    } else {
-      for (uint32_t e = tid; e < n_elts; e += kThreads) lin[e] = src[e];
-    }
-    __syncthreads();
-
-    // ---- transform this lane's 4 points (fp64, reference order: row . [x y z 1]) ----
-    double w[kPts * 3];
-    const uint32_t first = tid * kPts;
-#pragma unroll
-    for (int k = 0; k < kPts; ++k) {
-      if (first + k < n_pts) {
-        const double x = (double)lin[(first + k) * 3 + 0];
-        const double y = (double)lin[(first + k) * 3 + 1];
-        const double z = (double)lin[(first + k) * 3 + 2];
-        if (SE3) {  // Rinv . (p - t), the order of point_camera (camera_to_world.py:57-59) and of the fused kernel
-          const double dx = x - T[9], dy = y - T[10], dz = z - T[11];
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-            w[3 * k + r] = fma(T[3 * r + 2], dz, fma(T[3 * r + 1], dy, T[3 * r + 0] * dx));
-        } else {  // row . [x y z 1]  (transfer_T_icp.py:10-12)
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-            w[3 * k + r] = fma(T[4 * r + 2], z, fma(T[4 * r + 1], y, T[4 * r + 0] * x)) + T[4 * r + 3];
-        }
-      }
-    }
-    __syncthreads();  // everyone has read its inputs before the buffer is reused for outputs
-#pragma unroll
-    for (int k = 0; k < kPts; ++k) {
-      if (first + k < n_pts) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) lout[(first + k) * 3 + r] = (OT)w[3 * k + r];
-      }
-    }
-    __syncthreads();
-
-    // ---- LDS -> tile ----
-    if (VEC) {
-      constexpr uint32_t kPerPiece = 16 / sizeof(OT);
-      const uint32_t n_pieces = n_elts / kPerPiece;
-      using V = typename std::conditional<sizeof(OT) == 4, float4, double2>::type;
-      for (uint32_t q = tid; q < n_pieces; q += kThreads)
-        reinterpret_cast<V*>(dst)[q] = reinterpret_cast<const V*>(lout)[q];
-      for (uint32_t e = n_pieces * kPerPiece + tid; e < n_elts; e += kThreads) dst[e] = lout[e];
-    } else {
-      for (uint32_t e = tid; e < n_elts; e += kThreads) dst[e] = lout[e];
-    }
-    __syncthreads();
-  }
-}
-
+// One point's three coordinates as doubles, loaded with nontemporal loads.  The compiler does not see inline-asm
+// loads: the caller issues all of them, then wait_loads(), then reads the registers.
 template <typename T>
-struct __attribute__((packed, aligned(4))) Packed3 {
-  T x, y, z;
+struct RawPoint;
+template <>
+struct RawPoint<float> {
+  f32x3 v;
+  __device__ __forceinline__ void issue(const float* src) {
+    asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(v) : "v"(src) : "memory");
+  }
+  __device__ __forceinline__ void get(double p[3]) const {
+    p[0] = (double)v.x;
+    p[1] = (double)v.y;
+    p[2] = (double)v.z;
+  }
 };
-
-template <typename OT>
-__device__ __forceinline__ void store3_nt(OT* dst, const double w[3]);
 template <>
-__device__ __forceinline__ void store3_nt<float>(float* dst, const double w[3]) {
-  typedef float v3 __attribute__((ext_vector_type(3)));
-  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(v3{(float)w[0], (float)w[1], (float)w[2]}) : "memory");
-}
-template <>
-__device__ __forceinline__ void store3_nt<double>(double* dst, const double w[3]) {
-  __builtin_nontemporal_store(w[0], dst);
-  __builtin_nontemporal_store(w[1], dst + 1);
-  __builtin_nontemporal_store(w[2], dst + 2);
+struct RawPoint<double> {
+  f64x2 xy;
+  double z;
+  __device__ __forceinline__ void issue(const double* src) {
+    asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx2 %1, %2, off offset:16 nt"
+                 : "=&v"(xy), "=&v"(z)
+                 : "v"(src)
+                 : "memory");
+  }
+  __device__ __forceinline__ void get(double p[3]) const {
+    p[0] = xy.x;
+    p[1] = xy.y;
+    p[2] = z;
+  }
+};
+__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// output row `r` of the transform for the point p (fp64, the reference's order)
+template <bool SE3>
+__device__ __forceinline__ double out_row(const double T[12], int r, const double p[3], const double d[3]) {
+  if (SE3)  // Rinv . (p - t), the order of point_camera (camera_to_world.py:57-59) and of the fused kernel
+    return fma(T[3 * r + 2], d[2], fma(T[3 * r + 1], d[1], T[3 * r + 0] * d[0]));
+  // row . [x y z 1]  (transfer_T_icp.py:10-12)
+  return fma(T[4 * r + 2], p[2], fma(T[4 * r + 1], p[1], T[4 * r + 0] * p[0])) + T[4 * r + 3];
 }
 
-template <typename IT, typename OT, bool SE3>
+template <typename IT, bool SE3>
 __global__ __launch_bounds__(kThreads) void apply_lane_kernel(const ApplyArgs a) {
   const IT* in = static_cast<const IT*>(a.in);
-  OT* out = static_cast<OT*>(a.out);
+  float* out = static_cast<float*>(a.out);
   const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
   double T[12];
   load_T(a, T);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t base = tile * kTile + threadIdx.x;
-    Packed3<IT> p[kPts];
+    RawPoint<IT> raw[kPts];
 #pragma unroll
     for (int r = 0; r < kPts; ++r) {
       const uint64_t i = base + (uint64_t)r * kThreads;
-      if (i < a.n) p[r] = reinterpret_cast<const Packed3<IT>*>(in)[i];
+      if (i < a.n) raw[r].issue(in + i * 3);
     }
+    wait_loads();
 #pragma unroll
     for (int r = 0; r < kPts; ++r) {
       const uint64_t i = base + (uint64_t)r * kThreads;
       if (i < a.n) {
-        const double x = (double)p[r].x, y = (double)p[r].y, z = (double)p[r].z;
-        double w[3];
+        double p[3], d[3];
+        raw[r].get(p);
         if (SE3) {
-          const double dx = x - T[9], dy = y - T[10], dz = z - T[11];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) w[c] = fma(T[3 * c + 2], dz, fma(T[3 * c + 1], dy, T[3 * c + 0] * dx));
-        } else {
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-            w[c] = fma(T[4 * c + 2], z, fma(T[4 * c + 1], y, T[4 * c + 0] * x)) + T[4 * c + 3];
+          d[0] = p[0] - T[9];
+          d[1] = p[1] - T[10];
+          d[2] = p[2] - T[11];
         }
-        store3_nt<OT>(out + i * 3, w);
+        const f32x3 w = {(float)out_row<SE3>(T, 0, p, d), (float)out_row<SE3>(T, 1, p, d), (float)out_row<SE3>(T, 2, p, d)};
+        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + i * 3), "v"(w) : "memory");
       }
     }
   }
 }
 
-template <typename IT, typename OT, bool SE3>
-void launch(const ApplyArgs& a, int variant, bool vec, int blocks, hipStream_t s) {
-  if (variant == 0)
-    hipLaunchKernelGGL((apply_lane_kernel<IT, OT, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
-  else if (vec)
-    hipLaunchKernelGGL((apply_kernel<IT, OT, true, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
+// f64 out: item q of a tile (q = r*256 + tid, r = 0..7) is half (q & 1) of point (q >> 1)
+template <typename IT, bool SE3>
+__global__ __launch_bounds__(kThreads) void apply_pair_kernel(const ApplyArgs a) {
+  constexpr int kItems = 2 * kPts;
+  const IT* in = static_cast<const IT*>(a.in);
+  uint32_t* out = static_cast<uint32_t*>(a.out);
+  const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
+  const bool odd = threadIdx.x & 1u;
+  double T[12];
+  load_T(a, T);
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t p0 = tile * kTile;
+    RawPoint<IT> raw[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const uint64_t i = p0 + ((r * kThreads + threadIdx.x) >> 1);
+      if (i < a.n) raw[r].issue(in + i * 3);
+    }
+    wait_loads();
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const uint32_t q = r * kThreads + threadIdx.x;
+      const uint64_t i = p0 + (q >> 1);
+      if (i < a.n) {
+        double p[3], d[3];
+        raw[r].get(p);
+        if (SE3) {
+          d[0] = p[0] - T[9];
+          d[1] = p[1] - T[10];
+          d[2] = p[2] - T[11];
+        }
+        // both lanes need row 1; the even lane adds row 0, the odd lane row 2 (same instructions, selected operands)
+        const double w1 = out_row<SE3>(T, 1, p, d);
+        double Tsel[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tsel[k] = T[k];
+        const int lo = SE3 ? 3 : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < lo) Tsel[k] = odd ? T[2 * lo + k] : T[k];
+        const double w02 = out_row<SE3>(Tsel, 0, p, d);
+        const double a_ = odd ? w1 : w02, b_ = odd ? w02 : w1;
+        const uint32_t alo = (uint32_t)__double2loint(a_), ahi = (uint32_t)__double2hiint(a_);
+        const uint32_t blo = (uint32_t)__double2loint(b_), bhi = (uint32_t)__double2hiint(b_);
+        const u32x3 val = odd ? u32x3{ahi, blo, bhi} : u32x3{alo, ahi, blo};
+        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + p0 * 6 + (uint64_t)q * 3), "v"(val) : "memory");
+      }
+    }
+  }
+}
+
+template <typename IT, bool SE3>
+void launch(const ApplyArgs& a, int out_dtype, int blocks, hipStream_t s) {
+  if (out_dtype == R3D_F32)
+    hipLaunchKernelGGL((apply_lane_kernel<IT, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
   else
-    hipLaunchKernelGGL((apply_kernel<IT, OT, false, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((apply_pair_kernel<IT, SE3>), dim3(blocks), dim3(kThreads), 0, s, a);
 }
 
 template <bool SE3>
@@ -198,23 +196,16 @@ int apply_common(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_poi
   for (int k = 0; k < 12; ++k) a.T[k] = h_M ? h_M[k] : 0.0;
   a.d_T = d_M;
   a.n = (uint64_t)n_points;
-  // tile bases are multiples of 1024 points = 12 KiB (f32) / 24 KiB (f64): 16-B alignment of
-  // every tile follows from the alignment of the two base pointers
-  const bool vec = ((uintptr_t)d_xyz_in % 16 == 0) && ((uintptr_t)d_xyz_out % 16 == 0);
   const uint64_t n_tiles = (a.n + kTile - 1) / kTile;
-  // one tile per workgroup measured best for this 1:1 read/write stream (5.96 vs 5.67 TB/s at 8 workgroups per CU)
+  // one tile per workgroup measured best for this 1:1 read/write stream
   uint64_t blocks64 = ctx->apply_blocks > 0 ? (uint64_t)ctx->apply_blocks : n_tiles;
   if (blocks64 > n_tiles) blocks64 = n_tiles;
   if (blocks64 > 0x7fffffffull) blocks64 = 0x7fffffffull;
   const int blocks = (int)blocks64;
-  if (in_dtype == R3D_F32 && out_dtype == R3D_F32)
-    launch<float, float, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
-  else if (in_dtype == R3D_F32)
-    launch<float, double, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
-  else if (out_dtype == R3D_F32)
-    launch<double, float, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
+  if (in_dtype == R3D_F32)
+    launch<float, SE3>(a, out_dtype, blocks, ctx->stream);
   else
-    launch<double, double, SE3>(a, ctx->apply_variant, vec, blocks, ctx->stream);
+    launch<double, SE3>(a, out_dtype, blocks, ctx->stream);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

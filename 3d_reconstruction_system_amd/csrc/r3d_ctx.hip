@@ -143,13 +143,10 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out) {
 }
 
 static int* tuning_slot(r3d_ctx* ctx, const char* key) {
-  if (!strcmp(key, "fuse_variant")) return &ctx->fuse_variant;
   if (!strcmp(key, "fuse_blocks")) return &ctx->fuse_blocks;
-  if (!strcmp(key, "nontemporal")) return &ctx->nontemporal;
   if (!strcmp(key, "nn_variant")) return &ctx->nn_variant;
   if (!strcmp(key, "nn_blocks")) return &ctx->nn_blocks;
   if (!strcmp(key, "apply_blocks")) return &ctx->apply_blocks;
-  if (!strcmp(key, "apply_variant")) return &ctx->apply_variant;
   if (!strcmp(key, "voxel_dedupe")) return &ctx->voxel_dedupe;
   return nullptr;
 }

@@ -204,7 +204,7 @@ void txt_rows(const T* xyz, const void* z_raw, int z_dtype, int64_t lo, int64_t 
 }
 
 template <typename T>
-void format_rows_rgb(const T* xyz, const unsigned char* rgb, int64_t lo, int64_t hi, std::string* out) {
+void format_rows_rgb(const T* xyz, const unsigned char* rgb, int stride, int64_t lo, int64_t hi, std::string* out) {
   out->resize((size_t)(hi - lo) * 80 + 1300);
   char* base = &(*out)[0];
   char* p = base;
@@ -220,7 +220,7 @@ void format_rows_rgb(const T* xyz, const unsigned char* rgb, int64_t lo, int64_t
       *p++ = ' ';
     }
     for (int a = 0; a < 3; ++a) {
-      p = put_uint(p, rgb[i * 3 + a]);
+      p = put_uint(p, rgb[i * stride + a]);
       *p++ = ' ';
     }
     *p++ = '0';
@@ -295,7 +295,19 @@ int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, 
   return R3D_OK;
 }
 
+static int write_ply_colour(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int stride,
+                            int64_t n_points);
+
 int r3d_write_ply_rgb(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int64_t n_points) {
+  return write_ply_colour(path, h_xyz, dtype, h_rgb, 3, n_points);
+}
+
+int r3d_write_ply_rgba(const char* path, const void* h_xyz, int dtype, const uint32_t* h_rgba, int64_t n_points) {
+  return write_ply_colour(path, h_xyz, dtype, reinterpret_cast<const unsigned char*>(h_rgba), 4, n_points);
+}
+
+static int write_ply_colour(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int stride,
+                            int64_t n_points) {
   if (!path || n_points < 0 || (n_points > 0 && (!h_xyz || !h_rgb)) || (dtype != R3D_F32 && dtype != R3D_F64)) {
     r3d_set_error("r3d_write_ply_rgb: bad argument");
     return R3D_ERR_INVALID;
@@ -326,9 +338,9 @@ int r3d_write_ply_rgb(const char* path, const void* h_xyz, int dtype, const unsi
         const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
         auto work = [=, &chunks]() {
           if (dtype == R3D_F32)
-            format_rows_rgb(static_cast<const float*>(h_xyz), h_rgb, lo, hi, &chunks[(size_t)c]);
+            format_rows_rgb(static_cast<const float*>(h_xyz), h_rgb, stride, lo, hi, &chunks[(size_t)c]);
           else
-            format_rows_rgb(static_cast<const double*>(h_xyz), h_rgb, lo, hi, &chunks[(size_t)c]);
+            format_rows_rgb(static_cast<const double*>(h_xyz), h_rgb, stride, lo, hi, &chunks[(size_t)c]);
         };
         if (n_chunks == 1)
           work();

@@ -18,14 +18,11 @@ struct r3d_ctx {
   bool owns_stream = false;
   int num_cus = 256;
   // tuning knobs (r3d_ctx_set_tuning)
-  int fuse_variant = 0;  // 0 auto
   int fuse_blocks = 0;   // 0 auto
-  int nontemporal = 0;
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
-  int apply_variant = 0;
-  int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set  // 0 lane-per-point (default), 1 LDS-tiled
+  int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set
   // HIP-event stopwatch
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // grow-only scratch buffers for the *_host entry points and reductions

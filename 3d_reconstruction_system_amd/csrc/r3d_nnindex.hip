@@ -582,6 +582,10 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   hipLaunchKernelGGL(nn_tie_fallback_kernel, dim3(ctx->num_cus * 4), dim3(64), 0, st, d_src, ix->d_tgt, ix->n, tie_list,
                      tie_count, d_idx_out, d_d2_out);
   R3D_HIP(hipGetLastError());
+  if (want_sums &&
+      (rc = r3d_icp_sums_finish(ctx, d_src, n_src, ix->d_tgt, d_idx_out, d_d2_out, max_d2, dead_zone, tie_flag, tie_count,
+                                partials, (int)blocks, tie_blocks, d_sums_out)))
+    return rc;
   if (h_tiles_swept) {
     unsigned long long v = 0;
     R3D_HIP(hipMemcpyAsync(&v, stats, sizeof(v), hipMemcpyDeviceToHost, st));

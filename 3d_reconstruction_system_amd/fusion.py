@@ -75,6 +75,45 @@ def fuse_frames(depths, quats_xyzw, ts, intrinsics=REF_INTRINSICS, out_dtype=np.
     return out
 
 
+def fuse_frames_rgb(depths, rgb, quats_xyzw=None, ts=None, intrinsics=REF_INTRINSICS, out_dtype=np.float32, depth_scale=1.0,
+                    ctx=None):
+    """RGBD fusion (BASELINE config 5; colour attach of genply_noRGB, p2c:55-91): depths [F,H,W] + rgb [F,H,W,3] uint8
+    -> (xyz [F*H*W,3], rgba [F*H*W] uint32 with bytes R,G,B,0).  quats/ts None: camera-frame points."""
+    d = _as_batch(depths)
+    f, h, w = d.shape
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    if rgb.shape != (f, h, w, 3) and not (f == 1 and rgb.shape == (h, w, 3)):
+        raise ValueError("rgb must be [F,H,W,3] uint8 matching the depth batch (got %s)" % (rgb.shape,))
+    table = None
+    if quats_xyzw is not None:
+        table = pose_table(quats_xyzw, ts)
+        if table.shape[0] != f:
+            raise ValueError("%d frames but %d poses" % (f, table.shape[0]))
+    n = f * h * w
+    out = np.empty((n, 3), dtype=out_dtype)
+    rgba = np.empty(n, dtype=np.uint32)
+    code = xyz_code(out.dtype)
+    if n == 0:
+        return out, rgba
+    ctx = ctx or default_context()
+    cam = ctx.camera(h, w, *intrinsics)
+    d_depth, d_rgb = ctx.alloc(d.nbytes).upload(d), ctx.alloc(rgb.nbytes).upload(rgb)
+    d_pose = ctx.alloc(table.nbytes).upload(table) if table is not None else None
+    d_xyz, d_rgba = ctx.alloc(out.nbytes), ctx.alloc(rgba.nbytes)
+    try:
+        fuse_frames_rgb_device(ctx, cam, d_depth.ptr, d.dtype, f, d_pose.ptr if d_pose else None, d_rgb.ptr, d_xyz.ptr,
+                               out.dtype, d_rgba.ptr, depth_scale)
+        L.check(ctx.lib.r3d_memcpy_d2h(ctx.handle, out.ctypes.data, d_xyz.ptr, out.nbytes))
+        L.check(ctx.lib.r3d_memcpy_d2h(ctx.handle, rgba.ctypes.data, d_rgba.ptr, rgba.nbytes))
+        ctx.sync()
+    finally:
+        for b in (d_depth, d_rgb, d_pose, d_xyz, d_rgba):
+            if b is not None:
+                b.free()
+    del code
+    return out, rgba
+
+
 def se3_apply(xyz, rinv, t, out_dtype=None, ctx=None):
     """Rinv . (p - t) for every point of an [N,3] cloud -- point_camera() (c2w:57-59) in bulk."""
     xyz = np.ascontiguousarray(xyz)
@@ -116,6 +155,12 @@ def unproject_device(ctx, cam, d_depth, depth_dtype, n_frames, d_out, out_dtype,
 def fuse_frames_device(ctx, cam, d_depth, depth_dtype, n_frames, d_pose, d_out, out_dtype, depth_scale=1.0):
     L.check(ctx.lib.r3d_fuse_frames(ctx.handle, cam.handle, d_depth, depth_code(depth_dtype), int(n_frames),
                                     float(depth_scale), d_pose, d_out, xyz_code(out_dtype)))
+
+
+def fuse_frames_rgb_device(ctx, cam, d_depth, depth_dtype, n_frames, d_pose, d_rgb, d_out, out_dtype, d_rgba,
+                           depth_scale=1.0):
+    L.check(ctx.lib.r3d_fuse_frames_rgb(ctx.handle, cam.handle, d_depth, depth_code(depth_dtype), int(n_frames),
+                                        float(depth_scale), d_pose, d_rgb, d_out, xyz_code(out_dtype), d_rgba))
 
 
 def apply_T_device(ctx, d_in, in_dtype, n_points, T, d_out, out_dtype):

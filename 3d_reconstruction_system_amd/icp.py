@@ -367,6 +367,8 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                     stop_at = i
                     break
         st = dev.state()
+        if st["degenerate"]:
+            raise ValueError("ICP step undefined: fewer than 3 matched pairs (or no spread) after gating")
         T_total = st["T_total"] @ T_total
         info.update({"iterations": st["iterations"], "rms_history": st["rms_history"], "degenerate": st["degenerate"],
                      "converged_at": stop_at})

@@ -88,16 +88,16 @@ def pmc_traffic(frames, out_dtype, depth="u8"):
     return rec.get("hbm_bytes_per_launch")
 
 
-def kernel_duration_ms(torch, stream, launch, min_launches=200, min_ms=50.0, warm=50):
+def kernel_duration_ms(torch, stream, launch, min_launches=1000, min_ms=100.0, warm=50):
     """Median duration of one launch of the dominant kernel, independent of --steps: after `warm` untimed launches,
     at least `min_launches` launches (and at least `min_ms` of GPU time) timed with HIP events on the launch stream.  Returns (median_ms, mean_ms, n)."""
     for _ in range(warm):
         launch()
     torch.cuda.synchronize()
-    per = 10                      # launches between two events: the event packets' own cost is spread over 10 launches
+    per = 100                     # launches between two events, back to back exactly as in the timed region
     durations, total = [], 0.0
     while len(durations) * per < min_launches or total < min_ms:
-        n = 20
+        n = 5
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         evs[0].record(stream)
         for i in range(n):
@@ -108,7 +108,7 @@ def kernel_duration_ms(torch, stream, launch, min_launches=200, min_ms=50.0, war
         block = [evs[i].elapsed_time(evs[i + 1]) / per for i in range(n)]
         durations += block
         total += sum(block) * per
-        if len(durations) * per >= 4000:
+        if len(durations) * per >= 8000:
             break
     durations.sort()
     return durations[len(durations) // 2], sum(durations) / len(durations), len(durations) * per
@@ -368,7 +368,7 @@ def main():
                          "kernel": kernel_label,
                          "kernel_ms": round(kernel_ms, 5), "kernel_mean_ms": round(kernel_mean_ms, 5),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "timing": "median over %d launches in groups of 10 between HIP events on the launch stream, "
+                         "timing": "median over %d launches in groups of 100 between HIP events on the launch stream, "
                                    "after 50 untimed launches, before the timed region" % kernel_n,
                          "kernel_ms_le_ms_per_step": bool(kernel_ms <= elapsed / a.steps * 1e3)},
             "gpu_ms_per_step": round(gpu_ms_per_step, 5),

@@ -70,11 +70,10 @@ int r3d_ctx_create(int device, void* stream, int flags, r3d_ctx** ctx_out);
 int r3d_ctx_destroy(r3d_ctx* ctx);
 int r3d_ctx_sync(r3d_ctx* ctx);
 int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
-/* tuning knobs (integers; 0 = auto everywhere): "fuse_variant" {1 scalar any-width, 2 vec4 direct stores, 3 LDS-tile
- * 16-B stores, 4 LDS-wave, 5 lane-per-pixel (default for f32 xyz), 6 lane-per-pixel with batched loads, 7 lane-per-pixel
- * with scalar bases}, "nontemporal" (store mode of variant 5: 0 x3, 1 3 x nt scalar, 2 3 x scalar, 3 nt x3), "fuse_blocks",
- * "apply_variant" {0 lane-per-point, 1 LDS-tile}, "apply_blocks", "nn_variant" (sources per lane 1/2/4), "nn_blocks".
- * Every variant of a kernel produces bit-identical results.  Unknown key -> R3D_ERR_INVALID. */
+/* tuning knobs (integers; 0 = auto everywhere): launch geometry only -- "fuse_blocks", "apply_blocks", "nn_blocks"
+ * (workgroup counts), "nn_variant" (sources per lane of the NN sweeps: 1/2/4), "voxel_dedupe" (0 auto, 1 off, 2 on).
+ * No knob changes any result bit.  Unknown key -> R3D_ERR_INVALID.  (Kernel A/B variants live in tools/ab_kernels.hip,
+ * not in the library.) */
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);
 int r3d_ctx_get_tuning(r3d_ctx* ctx, const char* key, int* value_out);
 
@@ -123,6 +122,15 @@ int r3d_fuse_frames(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, in
                     double depth_scale, const double* d_pose, void* d_xyz_out, int out_dtype);
 int r3d_fuse_frames_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,
                          double depth_scale, const double* h_pose, void* h_xyz_out, int out_dtype);
+
+/* f4 colour attach (genply_noRGB, pixel_to_camera.py:55-91; BASELINE config 5 "RGBD"): the same fused launch also
+ * carries the frames' colour.  d_rgb: [n_frames][H][W][3] uint8, R,G,B per pixel (the image the depth raster belongs
+ * to).  d_rgba_out: [n_frames*H*W] uint32 = r | g<<8 | b<<16, i.e. bytes R,G,B,0 -- the "R G B 0" of the reference's
+ * PLY rows -- point k takes the colour of pixel k.  d_pose == NULL: camera-frame points (pixel_to_camera.py).
+ * +7 B/point of HBM traffic (3 read, 4 written). */
+int r3d_fuse_frames_rgb(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
+                        double depth_scale, const double* d_pose, const unsigned char* d_rgb, void* d_xyz_out,
+                        int out_dtype, uint32_t* d_rgba_out);
 
 /* ---- a4 on an existing cloud: p_world = Rinv . (p_cam - t), the evaluation order of point_camera()
  * (camera_to_world.py:57-59) and of the fused kernel, so fuse_frames(depth) == se3_apply(unproject(depth))
@@ -223,6 +231,8 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
 /* f4: the coloured layout of genply_noRGB() (pixel_to_camera.py:55-91): uchar red/green/blue/alpha header lines and
  * "%.4f %.4f %.4f R G B 0\n" rows; h_rgb is [n][3] uint8 in R,G,B order, point k takes colour k. */
 int r3d_write_ply_rgb(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int64_t n_points);
+/* The same file from the rgba words r3d_fuse_frames_rgb produces ([n] uint32, bytes R,G,B,0 in memory). */
+int r3d_write_ply_rgba(const char* path, const void* h_xyz, int dtype, const uint32_t* h_rgba, int64_t n_points);
 /* "X,Y,Z\n" lines with Python repr() float formatting -- the camera / world txt of
  * camera_to_world.py:80-81, 103-104 and transfer_T_icp.py:87,93.  If h_z_raw != NULL the third column
  * is printed as that raw integer raster value (the reference's camera txt prints str(np.uint8));

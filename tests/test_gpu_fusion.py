@@ -61,7 +61,6 @@ def test_fuse_matches_oracle(R, ctx, shape, ddtype, odtype):
     d = make_depth(rng, shape, ddtype)
     q = rng.normal(size=(shape[0], 4))
     t = rng.normal(size=(shape[0], 3)) * 10
-    ctx.set_tuning("fuse_variant", 0)
     got = R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx)
     check(got, O.fuse_frames(d, q, t), odtype)
     got_u = R.unproject(d, out_dtype=odtype, ctx=ctx)
@@ -73,26 +72,23 @@ def test_fuse_matches_oracle(R, ctx, shape, ddtype, odtype):
 
 @pytest.mark.parametrize("shape", [(3, 24, 32), (2, 37, 52), (2, 100, 1280)])
 @pytest.mark.parametrize("odtype", [np.float32, np.float64])
-def test_variants_bitwise_equal(R, ctx, shape, odtype):
+def test_launch_geometry_never_changes_a_bit(R, ctx, shape, odtype):
+    """The only tuning knob of the fused kernels is the workgroup count: grid-stride over tiles, same bits."""
     rng = np.random.default_rng(5)
     d = make_depth(rng, shape, np.uint8)
     q = rng.normal(size=(shape[0], 4))
     t = rng.normal(size=(shape[0], 3)) * 10
     outs = []
-    for variant in (1, 2, 3, 4, 5, 6, 7):
-        for nt in ((0, 1, 2, 3) if variant == 5 else (0, 1)):
-            ctx.set_tuning("fuse_variant", variant)
-            ctx.set_tuning("nontemporal", nt)
-            outs.append(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
-    for blocks in (1, 7, 300):
-        ctx.set_tuning("fuse_variant", 3)
+    for blocks in (0, 1, 7, 300, 100000):
         ctx.set_tuning("fuse_blocks", blocks)
         outs.append(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
-    ctx.set_tuning("fuse_variant", 0)
-    ctx.set_tuning("nontemporal", 0)
     ctx.set_tuning("fuse_blocks", 0)
+    assert ctx.get_tuning("fuse_blocks") == 0
     for o in outs[1:]:
         np.testing.assert_array_equal(o, outs[0])
+    # the f32 cloud is the f64 cloud rounded once: the two kernels (lane-per-pixel / lane-pair) share their arithmetic
+    if odtype == np.float64:
+        np.testing.assert_array_equal(R.fuse_frames(d, q, t, out_dtype=np.float32, ctx=ctx), outs[0].astype(np.float32))
 
 
 def test_intrinsics_and_scale(R, ctx):
@@ -152,16 +148,18 @@ def test_apply_T_and_se3(R, ctx, n, idt, odt):
     rinv = np.asarray(R.scipy_transfer(rng.normal(size=4)))
     t = rng.normal(size=3) * 10
     outs = []
-    for variant in (0, 1):  # lane-per-point (default) and LDS-tiled: same arithmetic, bit-identical results
-        ctx.set_tuning("apply_variant", variant)
+    for blocks in (0, 3):  # one tile per workgroup (default) and a grid-stride walk: bit-identical results
+        ctx.set_tuning("apply_blocks", blocks)
         got = R.apply_T(p, T, out_dtype=odt, ctx=ctx)
         check(got, O.apply_T(p, T), odt)
         got2 = R.se3_apply(p, rinv, t, out_dtype=odt, ctx=ctx)
         check(got2, O.se3_apply(p, rinv, t), odt)
         outs.append((got, got2))
-    ctx.set_tuning("apply_variant", 0)
+    ctx.set_tuning("apply_blocks", 0)
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    if odt == np.float64:   # lane-per-point f32 kernel == lane-pair f64 kernel rounded once
+        np.testing.assert_array_equal(R.apply_T(p, T, out_dtype=np.float32, ctx=ctx), outs[0][0].astype(np.float32))
 
 
 def test_fuse_equals_unproject_then_se3_bitwise(R, ctx):
@@ -303,21 +301,90 @@ def test_nonfinite_and_negative_f32_depth_propagate_like_numpy(R, ctx):
 
 
 @pytest.mark.parametrize("hw", [(3, 1), (2, 3), (3, 5), (2, 1023), (3, 1025), (2, 4099), (5, 257), (1, 8192)])
-def test_odd_widths_on_every_variant(R, ctx, hw):
-    """Widths that are not multiples of 4 (and a 1-pixel-wide raster) take the any-width paths; every variant that accepts
-    them must agree bit for bit and match the oracle."""
+@pytest.mark.parametrize("odtype", [np.float32, np.float64])
+def test_odd_widths(R, ctx, hw, odtype):
+    """Rasters whose size is not a multiple of anything convenient (and a 1-pixel-wide one): ragged last tiles."""
     h, w = hw
     rng = np.random.default_rng(h * 10007 + w)
     d = make_depth(rng, (3, h, w), np.uint16)
     q = rng.normal(size=(3, 4))
     t = rng.normal(size=(3, 3)) * 10
-    want = O.fuse_frames(d, q, t)
-    outs = []
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
-        ctx.set_tuning("fuse_variant", variant)
-        got = R.fuse_frames(d, q, t, out_dtype=np.float64, ctx=ctx)
-        check(got, want, np.float64)
-        outs.append(got)
-    ctx.set_tuning("fuse_variant", 0)
-    for o in outs[1:]:
-        np.testing.assert_array_equal(o, outs[0])
+    check(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx), O.fuse_frames(d, q, t), odtype)
+
+
+# ---- colour carried through the fused launch (f4; BASELINE config 5 "RGBD") ---------------------------------------
+def _rgba_words(rgb):
+    r = rgb.reshape(-1, 3).astype(np.uint32)
+    return r[:, 0] | (r[:, 1] << 8) | (r[:, 2] << 16)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 6), (3, 24, 32), (2, 37, 52), (2, 64, 128), (1, 192, 640), (3, 33, 1000)])
+@pytest.mark.parametrize("ddtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("odtype", [np.float32, np.float64])
+def test_fuse_rgb_matches_plain_fuse_and_carries_colour(R, ctx, shape, ddtype, odtype):
+    """xyz of the colour-carrying launch == the plain launch bit for bit; point k gets pixel k's colour, alpha 0.
+    Shapes cover whole 1024-pixel tiles (16-byte staged colour loads), ragged tiles and unaligned frames (byte loads)."""
+    rng = np.random.default_rng(sum(shape) + 3)
+    d = make_depth(rng, shape, ddtype)
+    rgb = rng.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+    q = rng.normal(size=(shape[0], 4))
+    t = rng.normal(size=(shape[0], 3)) * 10
+    xyz, rgba = R.fuse_frames_rgb(d, rgb, q, t, out_dtype=odtype, ctx=ctx)
+    np.testing.assert_array_equal(xyz, R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
+    np.testing.assert_array_equal(rgba, _rgba_words(rgb))
+    cam_xyz, rgba2 = R.fuse_frames_rgb(d, rgb, out_dtype=odtype, ctx=ctx)          # no pose: pixel_to_camera.py
+    np.testing.assert_array_equal(cam_xyz, R.unproject(d, out_dtype=odtype, ctx=ctx))
+    np.testing.assert_array_equal(rgba2, rgba)
+
+
+def test_fuse_rgb_reproduces_reference_coloured_ply(R, ctx, golden_dir, tmp_path):
+    """genply_noRGB's file (pixel_to_camera.py:55-91), fixture made with the reference itself (tests/golden/make_golden.py):
+    the first 6 points of the seeded 480x640 raster with the colours of p2c_rgb_2x3.png -> xyz + colour through the GPU
+    -> byte-identical PLY."""
+    import json
+    import os
+    from PIL import Image
+    g = json.load(open(os.path.join(golden_dir, "p2c_480x640.json")))
+    depth = np.random.default_rng(g["seed"]).integers(1, 256, tuple(g["shape"]), dtype=np.uint8)
+    six = np.array(Image.open(os.path.join(golden_dir, "p2c_rgb_2x3.png")).convert("RGB")).reshape(-1, 3)
+    img = np.zeros(depth.shape + (3,), np.uint8)
+    img.reshape(-1, 3)[:6] = six
+    want = open(os.path.join(golden_dir, "p2c_first6_rgb.ply"), "rb").read()
+    for odt in (np.float64, np.float32):
+        xyz, rgba = R.fuse_frames_rgb(depth, img, out_dtype=odt, ctx=ctx)
+        out = tmp_path / ("c%d.ply" % np.dtype(odt).itemsize)
+        R.cloud_io.write_ply_rgb(str(out), xyz[:6], rgba[:6])
+        assert out.read_bytes() == want
+
+
+def test_config5_geometry_1080p_f32_rgbd(R, ctx):
+    """BASELINE config 5 geometry (1920x1080 f32 depth + RGB), 50 frames = 103.7 M points, HBM-resident: properties
+    that need no oracle pass over 100 M points -- per-frame launches == one batched launch, colour == input, and a
+    strided sample against the oracle."""
+    F, H, W = 50, 1080, 1920
+    rng = np.random.default_rng(5)
+    depth = (rng.random((F, H, W), dtype=np.float32) * 99.5 + 0.5)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    q = rng.normal(size=(F, 4))
+    t = rng.normal(size=(F, 3)) * 10
+    intr = (960.0, 960.0, 959.5, 539.5)
+    cam = ctx.camera(H, W, *intr)
+    n = F * H * W
+    table = R.pose_table(q, t)
+    d_depth, d_rgb, d_pose = ctx.alloc(depth.nbytes).upload(depth), ctx.alloc(rgb.nbytes).upload(rgb), ctx.alloc(table.nbytes).upload(table)
+    d_xyz, d_rgba, d_xyz2, d_rgba2 = ctx.alloc(n * 12), ctx.alloc(n * 4), ctx.alloc(n * 12), ctx.alloc(n * 4)
+    R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, np.float32, d_rgba.ptr)
+    per = H * W
+    for f in range(F):      # frame by frame into the second pair of buffers
+        R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr + f * per * 4, np.float32, 1, d_pose.ptr + f * 96, d_rgb.ptr + f * per * 3,
+                                 d_xyz2.ptr + f * per * 12, np.float32, d_rgba2.ptr + f * per * 4)
+    xyz = d_xyz.download(np.float32, n * 3).reshape(-1, 3)
+    np.testing.assert_array_equal(xyz, d_xyz2.download(np.float32, n * 3).reshape(-1, 3))
+    rgba = d_rgba.download(np.uint32, n)
+    np.testing.assert_array_equal(rgba, d_rgba2.download(np.uint32, n))
+    np.testing.assert_array_equal(rgba, _rgba_words(rgb))
+    for f in (0, 17, 49):   # oracle on three whole frames
+        want = O.fuse_frames(depth[f:f + 1], q[f:f + 1], t[f:f + 1], *intr)
+        check(xyz[f * per:(f + 1) * per], want, np.float32)
+    for b in (d_depth, d_rgb, d_pose, d_xyz, d_rgba, d_xyz2, d_rgba2):
+        b.free()

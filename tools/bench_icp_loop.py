@@ -33,13 +33,40 @@ def synthetic_pair(n, s, angle_deg, t_norm, noise, seed):
 
 
 ctx = r3d.Context(0)
-src, tgt, T_true = synthetic_pair(500000, s=1.005, angle_deg=0.2, t_norm=0.02, noise=0.002, seed=7)
-for culled in (True, False):
-    icp.icp_similarity(src[:1000], tgt[:1000], max_iter=2, ctx=ctx, culled=culled)          # warm-up
+# SURVEY.md 8(d) C3 recipe: target = 500k points uniform in a 20 m cube + N(0, 0.01); source = the inverse similarity
+# (s=1.7, 10 degrees, |t|=0.5) of a permutation of the noise-free target.  No initial guess is given.
+src, tgt, T_true = synthetic_pair(500000, s=1.7, angle_deg=10.0, t_norm=0.5, noise=0.0, seed=7)
+tgt = (tgt.astype(np.float64) + np.random.default_rng(8).normal(size=tgt.shape) * 0.01).astype(np.float32)
+icp.icp_similarity(src[:2000], tgt[:2000], max_iter=2, ctx=ctx)                                # warm-up
+for check_every in (4, 1):
     t0 = time.perf_counter()
-    T, info = icp.icp_similarity(src, tgt, max_iter=20, tol=0.0, ctx=ctx, culled=culled)
+    T, info = icp.icp_similarity(src, tgt, ctx=ctx, check_every=check_every)
     dt = time.perf_counter() - t0
-    print("%-12s %d iterations in %.1f ms (%.2f ms/iteration incl. upload, index build, host SVD); |T - T_true|max = %.2e, rms %.3e"
-          % ("culled NN" if culled else "brute force", info["iterations"], dt * 1e3, dt * 1e3 / info["iterations"],
-             np.abs(T - T_true).max(), info["rms_history"][-1]))
+    print("auto init, check_every=%d: %d coarse + %d fine iterations in %.1f ms wall incl. upload, both index builds, spacing "
+          "probe; |T - T_true|max = %.2e, final rms %.3e, dead zone %.3f"
+          % (check_every, info["coarse_iterations"], info["iterations"], dt * 1e3, np.abs(T - T_true).max(),
+             info["rms_history"][-1], info["dead_zone"]))
+# the fine loop alone, from a near-aligned start, fused+device-solve vs stepped from the host, culled vs brute force
+near = (src.astype(np.float64) @ (T_true[:3, :3] * 1.003).T + T_true[:3, 3] + 0.01).astype(np.float32)
+for culled in (True, False):
+    for fused in (True, False):
+        dev = icp.IcpDevice(near, tgt, ctx, culled)
+        dev.state_reset()
+        ctx.sync()
+        n_it = 8 if culled else 3
+        t0 = time.perf_counter()
+        if fused:
+            dev.iterate(n_it)
+            st = dev.state()
+        else:
+            for _ in range(n_it):
+                dev.nn()
+                dev.move_source(icp.umeyama_from_sums(dev.sums()))
+            ctx.sync()
+        dt = time.perf_counter() - t0
+        print("%-11s %-44s %.3f ms/iteration (%d iterations)"
+              % ("culled NN" if culled else "brute force",
+                 "one enqueue, fused sums, device solve" if fused else "host-stepped: nn, sums + D2H, host SVD, apply",
+                 dt * 1e3 / n_it, n_it))
+        dev.free()
 ctx.close()

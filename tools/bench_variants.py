@@ -22,94 +22,8 @@ def time_ms(ctx, fn, iters):
     return ctx.timer_stop() / iters
 
 
-def bench_fuse(ctx, F, H, W, rounds, iters, odt=np.float32):
-    rng = np.random.default_rng(1234)
-    n = F * H * W
-    osz = np.dtype(odt).itemsize
-    depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
-    table = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
-    d_depth = ctx.alloc(n).upload(depth)
-    d_pose = ctx.alloc(table.nbytes).upload(table)
-    d_out = ctx.alloc(n * 3 * osz)
-    cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
-    configs = []
-    for variant in (3, 5, 6, 7):
-        for nt in (3,):
-            for blocks in (2048, 4096):
-
-                configs.append((variant, nt, blocks))
-    results = {c: [] for c in configs}
-
-    def run():
-        r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, odt)
-
-    for _ in range(rounds):
-        for c in configs:
-            ctx.set_tuning("fuse_variant", c[0])
-            ctx.set_tuning("nontemporal", c[1])
-            ctx.set_tuning("fuse_blocks", c[2])
-            results[c].append(time_ms(ctx, run, iters))
-    bpp = 1 + 3 * osz
-    print("fuse %dx%dx%d = %.1f Mpts, %d B/pt = %.1f MB per launch (%s out)" % (F, H, W, n / 1e6, bpp, n * bpp / 1e6, np.dtype(odt).name))
-    print("variant nt blocks   med_ms   min_ms   GB/s(med)  Gpts/s")
-    for c in configs:
-        med, mn = np.median(results[c]), np.min(results[c])
-        print("%7d %2d %6d %8.4f %8.4f %10.1f %7.1f" % (c[0], c[1], c[2], med, mn, n * bpp / med / 1e6, n / med / 1e6))
-    for k in ("fuse_variant", "nontemporal", "fuse_blocks"):
-        ctx.set_tuning(k, 0)
-
-
-def bench_fuse_dtypes(ctx, rounds, iters):
-    """Default kernel on every depth/output type and on the 1080p f32 shape of BASELINE config 5."""
-    rng = np.random.default_rng(5)
-    print("fuse, default variant: depth dtype x out dtype")
-    for (F, H, W) in ((100, 384, 1280), (24, 1080, 1920)):
-        n = F * H * W
-        table = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
-        d_pose = ctx.alloc(table.nbytes).upload(table)
-        cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
-        for ddt in (np.uint8, np.uint16, np.float32):
-            if ddt == np.float32:
-                depth = (rng.random((F, H, W)) * 99.5 + 0.5).astype(np.float32)
-            else:
-                depth = rng.integers(1, np.iinfo(ddt).max, size=(F, H, W), dtype=ddt)
-            d_depth = ctx.alloc(depth.nbytes).upload(depth)
-            for odt in (np.float32, np.float64):
-                d_out = ctx.alloc(n * 3 * np.dtype(odt).itemsize)
-                run = lambda: r3d.fuse_frames_device(ctx, cam, d_depth.ptr, ddt, F, d_pose.ptr, d_out.ptr, odt)
-                ts = [time_ms(ctx, run, iters) for _ in range(rounds)]
-                bpp = np.dtype(ddt).itemsize + 3 * np.dtype(odt).itemsize
-                med = np.median(ts)
-                print("%dx%dx%d %-7s -> %-7s %2d B/pt  med %.4f ms  %.1f GB/s  %.1f Gpts/s"
-                      % (F, H, W, np.dtype(ddt).name, np.dtype(odt).name, bpp, med, n * bpp / med / 1e6, n / med / 1e6))
-                d_out.free()
-            d_depth.free()
-        d_pose.free()
-
-
-def bench_apply(ctx, n, rounds, iters):
-    rng = np.random.default_rng(1)
-    p = (rng.normal(size=(n, 3)) * 50).astype(np.float32)
-    d_in = ctx.alloc(p.nbytes).upload(p)
-    d_out = ctx.alloc(p.nbytes)
-    T = np.eye(4)
-    T[:3, 3] = (1, 2, 3)
-    res = {}
-    for variant in (0, 1):
-        for blocks in (1024, 2048, 4096, 16384, 1000000):
-            res[(variant, blocks)] = []
-    for _ in range(rounds):
-        for (variant, blocks) in res:
-            ctx.set_tuning("apply_variant", variant)
-            ctx.set_tuning("apply_blocks", blocks)
-            res[(variant, blocks)].append(time_ms(ctx, lambda: r3d.apply_T_device(ctx, d_in.ptr, np.float32, n, T, d_out.ptr,
-                                                                       np.float32), iters))
-    ctx.set_tuning("apply_blocks", 0)
-    ctx.set_tuning("apply_variant", 0)
-    print("apply_T %.1f Mpts, 24 B/pt" % (n / 1e6))
-    for (variant, blocks), v in res.items():
-        med = np.median(v)
-        print("variant %d blocks %7d  med %.4f ms  %.1f GB/s" % (variant, blocks, med, n * 24 / med / 1e6))
+# The fused / apply kernel variants left the library in round 2: their A/B harness is tools/ab_kernels.hip
+# (make -C tools ab_kernels; history in profiles/variants_r01.md and profiles/r02_ab_kernels.log).
 
 
 def bench_nn(ctx, n, m, rounds):
@@ -210,14 +124,6 @@ if __name__ == "__main__":
     ap.add_argument("--nn", type=int, default=100000)
     a = ap.parse_args()
     ctx = r3d.Context(0)
-    if a.what in ("fuse", "all"):
-        bench_fuse(ctx, a.frames, 384, 1280, a.rounds, a.iters)
-    if a.what in ("fuse64", "all"):
-        bench_fuse(ctx, a.frames, 384, 1280, a.rounds, a.iters, np.float64)
-    if a.what in ("dtypes", "all"):
-        bench_fuse_dtypes(ctx, a.rounds, a.iters)
-    if a.what in ("apply", "all"):
-        bench_apply(ctx, 50_000_000, a.rounds, a.iters)
     if a.what in ("voxel", "all"):
         bench_voxel(ctx, a.frames, 384, 1280, a.rounds)
     if a.what in ("nn", "all"):
