@@ -80,6 +80,14 @@ SIGNATURES = {
     "r3d_icp_state_reset": (_i, [_vp, _vp]),
     "r3d_icp_solve_dev": (_i, [_vp, _vp, _i, _vp]),
     "r3d_icp_iterate": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
+    "r3d_comm_unique_id": (_i, [_vp]),
+    "r3d_comm_create": (_i, [_vp, _vp, _i, _i, _pvp]),
+    "r3d_comm_destroy": (_i, [_vp]),
+    "r3d_comm_info": (_i, [_vp, _pi, _pi, C.POINTER(C.c_char_p)]),
+    "r3d_comm_allgather": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "r3d_allgather_xyz": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
+    "r3d_allgather_inputs": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
+    "r3d_comm_allreduce_sum_f64": (_i, [_vp, _vp, _i64]),
     "r3d_format_ply": (_i, [_vp, _i, _i64, _vp, _sz, _psz]),
     "r3d_write_ply": (_i, [C.c_char_p, _vp, _i, _i64]),
     "r3d_write_ply_rgb": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),

@@ -135,6 +135,12 @@ class Context:
     def sync(self):
         L.check(self.lib.r3d_ctx_sync(self.handle))
 
+    def stream_handle(self):
+        """The raw hipStream_t this context launches on (0 = the device's default stream)."""
+        s = C.c_void_p()
+        L.check(self.lib.r3d_ctx_stream(self.handle, C.byref(s)))
+        return s.value or 0
+
     def set_tuning(self, key, value):
         L.check(self.lib.r3d_ctx_set_tuning(self.handle, key.encode(), int(value)))
 

@@ -27,27 +27,73 @@ def shard_counts(n_frames, world):
     return [shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0] for r in range(world)]
 
 
-def all_gather_cloud(shard, points_per_rank, group=None):
+class TorchTransport:
+    """The exchange step over torch.distributed ("nccl" = RCCL on the GPU box, "gloo" in CPU tests)."""
+
+    name = "torch.distributed"
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allgather_rows(self, shard, rows_per_rank, out=None):
+        """Shards [rows_r, ...] of possibly unequal length -> [sum rows, ...] in rank order.  Equal shards go straight
+        into the result (all_gather_into_tensor, no copy); unequal ones are padded to the longest and compacted."""
+        import torch
+        assert len(rows_per_rank) == self.world and shard.shape[0] == rows_per_rank[self.rank]
+        tail = tuple(shard.shape[1:])
+        longest, total = max(rows_per_rank), sum(rows_per_rank)
+        if out is None:
+            out = torch.empty((total,) + tail, dtype=shard.dtype, device=shard.device)
+        if total == 0:
+            return out
+        if all(c == longest for c in rows_per_rank):
+            self.dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
+            return out
+        padded = torch.zeros((longest,) + tail, dtype=shard.dtype, device=shard.device)
+        padded[:shard.shape[0]] = shard
+        gathered = torch.empty((self.world * longest,) + tail, dtype=shard.dtype, device=shard.device)
+        self.dist.all_gather_into_tensor(gathered, padded, group=self.group)
+        done = 0
+        for r, c in enumerate(rows_per_rank):
+            if c:
+                out[done:done + c] = gathered[r * longest:r * longest + c]
+            done += c
+        return out
+
+
+class R3dTransport:
+    """The exchange step through the C ABI (comm.Comm: RCCL bound by libr3d_hip.so, unequal shards by grouped
+    send/recv, no padding, no torch.distributed).  Tensors only lend their HBM addresses; the transfers run on the
+    comm's ctx stream, so create that ctx on the torch stream the tensors live on (Context(dev, stream=...))."""
+
+    name = "r3d_comm"
+
+    def __init__(self, comm, algo=0):
+        self.comm, self.algo = comm, int(algo)
+        self.rank, self.world = comm.rank, comm.world
+
+    def allgather_rows(self, shard, rows_per_rank, out=None):
+        import torch
+        assert len(rows_per_rank) == self.world and shard.shape[0] == rows_per_rank[self.rank]
+        if shard.device.type != "cuda":
+            raise RuntimeError("r3d_comm moves HBM buffers; got a tensor on %s" % shard.device)
+        tail = tuple(shard.shape[1:])
+        row_bytes = shard.element_size()
+        for d in tail:
+            row_bytes *= d
+        if out is None:
+            out = torch.empty((sum(rows_per_rank),) + tail, dtype=shard.dtype, device=shard.device)
+        shard = shard.contiguous()
+        self.comm.allgather(shard.data_ptr(), [c * row_bytes for c in rows_per_rank], out.data_ptr(), self.algo)
+        return out
+
+
+def all_gather_cloud(shard, points_per_rank, group=None, transport=None):
     """All-gather xyz shards of possibly unequal length into the full cloud, rank order.
-    shard: torch tensor [n_local, 3]; points_per_rank: list of n_local for every rank.
-    Equal shards use all_gather_into_tensor straight into the result (no copy); unequal ones
-    are padded to the longest shard and compacted."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    assert len(points_per_rank) == world and shard.shape[0] == points_per_rank[dist.get_rank(group)]
-    longest = max(points_per_rank)
-    total = sum(points_per_rank)
-    if all(c == longest for c in points_per_rank):
-        full = torch.empty((total, 3), dtype=shard.dtype, device=shard.device)
-        dist.all_gather_into_tensor(full, shard.contiguous(), group=group)
-        return full
-    padded = torch.zeros((longest, 3), dtype=shard.dtype, device=shard.device)
-    padded[:shard.shape[0]] = shard
-    gathered = torch.empty((world * longest, 3), dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(gathered, padded, group=group)
-    parts = [gathered[r * longest:r * longest + c] for r, c in enumerate(points_per_rank) if c]
-    return torch.cat(parts, dim=0) if parts else gathered[:0]
+    shard: torch tensor [n_local, 3]; points_per_rank: list of n_local for every rank."""
+    return (transport or TorchTransport(group)).allgather_rows(shard, list(points_per_rank))
 
 
 class ShardedFusion:
@@ -55,9 +101,11 @@ class ShardedFusion:
 
     fuse_fn(depth_tensor [F,H,W], pose_tensor [F,12] float64, out_tensor [F*H*W,3]) -> None
     defaults to the HIP kernel on the tensors' device (requires CUDA/ROCm tensors); CPU tests of
-    the sharding / gather logic inject a checker function instead."""
+    the sharding / gather logic inject a checker function instead.
+    transport: TorchTransport (default) or R3dTransport."""
 
-    def __init__(self, height, width, intrinsics, out_dtype="float32", device=None, fuse_fn=None, group=None):
+    def __init__(self, height, width, intrinsics, out_dtype="float32", device=None, fuse_fn=None, group=None,
+                 transport=None):
         import torch
         self.torch = torch
         self.h, self.w = int(height), int(width)
@@ -65,24 +113,48 @@ class ShardedFusion:
         self.out_dtype = getattr(torch, out_dtype) if isinstance(out_dtype, str) else out_dtype
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.group = group
-        self._ctx = None
-        self._cam = None
+        self._transport = transport
+        self._ctxs = {}
         self.fuse_fn = fuse_fn or self._hip_fuse
+
+    @property
+    def transport(self):
+        if self._transport is None:
+            self._transport = TorchTransport(self.group)
+        return self._transport
+
+    def _ctx_for(self, device):
+        """(Context, Camera) bound to the torch stream that is current NOW on `device`: a context launches on the
+        stream it was created with, so it is cached per (device, stream) -- a caller that switches streams
+        (torch.cuda.stream(s)) gets a context on that stream, ordered with its producers and consumers."""
+        torch = self.torch
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        key = (idx, stream)
+        hit = self._ctxs.get(key)
+        if hit is None:
+            from .device import Context
+            if isinstance(self._transport, R3dTransport) and self._transport.comm.ctx.device == idx:
+                c = self._transport.comm.ctx          # the comm's ctx: compute and exchange share one stream
+                stream_of = c.stream_handle()
+                if stream_of != stream:
+                    c = Context(idx, stream=stream)
+            else:
+                c = Context(idx, stream=stream)
+            hit = (c, c.camera(self.h, self.w, *self.intrinsics))
+            self._ctxs[key] = hit
+        return hit
 
     def _hip_fuse(self, depth, pose, out):
         torch = self.torch
         if depth.device.type != "cuda":
             raise RuntimeError("the HIP fusion path needs tensors on an MI355X (got %s); there is no CPU "
                                "fallback" % depth.device)
-        from .device import Context
         from .fusion import fuse_frames_device
-        if self._ctx is None:
-            idx = depth.device.index if depth.device.index is not None else torch.cuda.current_device()
-            self._ctx = Context(idx, stream=torch.cuda.current_stream(depth.device).cuda_stream)
-            self._cam = self._ctx.camera(self.h, self.w, *self.intrinsics)
+        ctx, cam = self._ctx_for(depth.device)
         np_depth = {torch.uint8: np.uint8, torch.uint16: np.uint16, torch.float32: np.float32}[depth.dtype]
         np_out = {torch.float32: np.float32, torch.float64: np.float64}[out.dtype]
-        fuse_frames_device(self._ctx, self._cam, depth.data_ptr(), np_depth, depth.shape[0], pose.data_ptr(),
+        fuse_frames_device(ctx, cam, depth.data_ptr(), np_depth, depth.shape[0], pose.data_ptr(),
                            out.data_ptr(), np_out)
 
     def fuse_local(self, depth, pose, out=None):
@@ -96,49 +168,35 @@ class ShardedFusion:
         return out
 
     def fuse_and_gather(self, depth, pose, frames_per_rank, out=None):
-        """'outputs' assembly: fuse this rank's frames, all-gather the xyz shards."""
-        shard = self.fuse_local(depth, pose, out)
-        pts = [c * self.h * self.w for c in frames_per_rank]
-        return all_gather_cloud(shard, pts, self.group)
+        """'outputs' assembly: fuse this rank's frames, all-gather the xyz shards (12 B/point over xGMI).
+        out: optional preallocated [total points, 3] tensor; this rank then fuses straight into its slot."""
+        per = self.h * self.w
+        pts = [c * per for c in frames_per_rank]
+        t = self.transport
+        if out is not None:
+            lo = sum(pts[:t.rank])
+            shard = self.fuse_local(depth, pose, out[lo:lo + pts[t.rank]])
+        else:
+            shard = self.fuse_local(depth, pose)
+        return t.allgather_rows(shard, pts, out)
 
     def gather_inputs(self, depth, pose, frames_per_rank):
-        """All-gather the depth rasters and pose rows of every rank (padded to the longest shard).
-        Returns (depth_all [world*Fmax,H,W], pose_all [world*Fmax,12], Fmax)."""
-        import torch.distributed as dist
-        torch = self.torch
-        world = dist.get_world_size(self.group)
-        fmax = max(frames_per_rank)
-        if depth.shape[0] != fmax:
-            pad_d = torch.zeros((fmax, self.h, self.w), dtype=depth.dtype, device=depth.device)
-            pad_d[:depth.shape[0]] = depth
-            pad_p = torch.zeros((fmax, 12), dtype=pose.dtype, device=pose.device)
-            pad_p[:pose.shape[0]] = pose
-            depth, pose = pad_d, pad_p
-        depth_all = torch.empty((world * fmax, self.h, self.w), dtype=depth.dtype, device=depth.device)
-        pose_all = torch.empty((world * fmax, 12), dtype=pose.dtype, device=pose.device)
-        dist.all_gather_into_tensor(depth_all, depth.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(pose_all, pose.contiguous(), group=self.group)
-        return depth_all, pose_all, fmax
+        """All-gather the depth rasters and pose rows of every rank, compact, in rank order:
+        (depth_all [total F,H,W], pose_all [total F,12])."""
+        t = self.transport
+        return (t.allgather_rows(depth.contiguous(), list(frames_per_rank)),
+                t.allgather_rows(pose.contiguous(), list(frames_per_rank)))
 
     def gather_inputs_and_fuse(self, depth, pose, frames_per_rank, out=None):
-        """'inputs' assembly: all-gather rasters + poses, fuse every frame here.  Same bits as
-        fuse_and_gather (same kernel, same per-frame arithmetic), 1/12 of the fabric traffic."""
+        """'inputs' assembly: all-gather rasters + poses (1 B/point + 96 B/frame), fuse every frame here in ONE
+        launch.  Same bits as fuse_and_gather (same kernel, same per-frame arithmetic), 1/12 of the fabric traffic."""
         torch = self.torch
-        depth_all, pose_all, fmax = self.gather_inputs(depth, pose, frames_per_rank)
+        depth_all, pose_all = self.gather_inputs(depth, pose, frames_per_rank)
         total = sum(frames_per_rank)
-        per = self.h * self.w
         if out is None:
-            out = torch.empty((total * per, 3), dtype=self.out_dtype, device=depth.device)
-        if all(c == fmax for c in frames_per_rank):
-            if total:
-                self.fuse_fn(depth_all, pose_all, out)          # one launch over world*F frames
-            return out
-        done = 0
-        for r, c in enumerate(frames_per_rank):                  # ragged: skip each rank's padding
-            if c:
-                self.fuse_fn(depth_all[r * fmax:r * fmax + c], pose_all[r * fmax:r * fmax + c],
-                             out[done * per:(done + c) * per])
-            done += c
+            out = torch.empty((total * self.h * self.w, 3), dtype=self.out_dtype, device=depth.device)
+        if total:
+            self.fuse_fn(depth_all, pose_all, out)
         return out
 
 
@@ -165,5 +223,17 @@ def all_gather_voxel_codes(codes, group=None):
     gathered = torch.empty(world * longest, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)
     parts = [gathered[r * longest:r * longest + c] for r, c in enumerate(counts) if c]
-    merged = torch.cat(parts).cpu().numpy().view(np.uint64)
-    return np.unique(merged)
+    merged = torch.cat(parts)
+    if merged.device.type == "cuda":
+        # sort in HBM with the library's radix sort (48-bit Morton codes), drop repeats, then one D2H of the union
+        from . import _lib as L
+        from .device import Context
+        ctx = Context(merged.device.index, stream=torch.cuda.current_stream(merged.device).cuda_stream)
+        try:
+            L.check(ctx.lib.r3d_sort_u64(ctx.handle, merged.data_ptr(), merged.numel(), 48))
+            merged = torch.unique_consecutive(merged)
+            torch.cuda.current_stream(merged.device).synchronize()
+        finally:
+            ctx.close()
+        return merged.cpu().numpy().view(np.uint64)
+    return np.unique(merged.numpy().view(np.uint64))

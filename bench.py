@@ -8,11 +8,13 @@ Workload (BASELINE.json configs[1], "C2"): KITTI-sized 1280x384 uint8 depth, 100
 synthetic (seed 1234), device-resident; one STEP = one pass of the hot path over the batch =
 ONE fused unproject + SE(3) launch over all 100 frames (49,152,000 points -> f32 xyz), and for
 N > 1 additionally the collective that assembles the fused world cloud on every rank (north_star):
-by default an all-gather of the INPUTS (depth + poses, 1 B/point) followed by a local fuse of every
-rank's frames, which is bit-identical to and several times faster than all-gathering the xyz
-OUTPUTS (12 B/point) on xGMI; `--assemble outputs|none` selects the other strategies; `--all-modes` additionally
-times the other two after the timed region and prints them under "assemble_ms_per_step".  Weak scaling: every rank owns 100 frames.
-`value` is whole-job Mpoints/s = UNIQUE fused points of all ranks / max-over-ranks time.
+by default (`--assemble auto`) the fastest measured strategy -- normally an all-gather of the INPUTS (depth + poses,
+1 B/point) followed by a local fuse of every rank's frames, which is bit-identical to and several times faster than
+all-gathering the xyz OUTPUTS (12 B/point) on xGMI.  Weak scaling: every rank owns 100 frames.
+`value` is whole-job Mpoints/s = UNIQUE fused points of all ranks / max-over-ranks time.  For N > 1 EVERY assembly
+strategy (none / outputs / inputs, ncclAllGather and direct send/recv) is timed before the headline region and printed
+under "assemble" with its achieved xGMI GB/s per link; the exchange runs through the library's own RCCL communicator
+(r3d_comm_*, C ABI) when it comes up, torch.distributed otherwise ("transport").
 
 Extra objects on the JSON line:
   roofline     -- the fused kernel against the HBM roof: algorithmic bytes (13 B/point) per launch
@@ -36,6 +38,7 @@ sys.path.insert(0, ROOT)
 H, W, FRAMES_PER_GPU = 384, 1280, 100
 BYTES_PER_POINT = 13          # 1 B u8 depth read + 12 B f32 xyz written
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+XGMI_LINK_GBS = 153.0         # one xGMI link, per direction (7 links per GPU, full mesh of 8)
 
 
 def cpu_baseline(sample_frames=1):
@@ -191,14 +194,14 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (100 = config C2)")
-    ap.add_argument("--assemble", default="inputs", choices=["inputs", "outputs", "none"],
-                    help="N>1: how the step assembles the fused world cloud on every rank: 'inputs' = all-gather "
-                         "depth+poses (1 B/point over xGMI) then fuse all frames locally (default, fastest); "
-                         "'outputs' = fuse own frames then all-gather xyz (12 B/point over xGMI); 'none' = shards stay put")
-    ap.add_argument("--all-modes", action="store_true",
-                    help="N>1: after the timed region also time the other assembly strategies (10 steps each) and add them "
-                         "to the line under assemble_ms_per_step; off by default so that nothing runs between the timed "
-                         "region and the JSON line")
+    ap.add_argument("--assemble", default="auto",
+                    choices=["auto", "inputs", "inputs_direct", "outputs", "outputs_direct", "none"],
+                    help="N>1: how the headline step assembles the fused world cloud on every rank.  Every strategy is "
+                         "timed before the headline region and printed under 'assemble'; 'auto' (default) then runs the "
+                         "fastest one that leaves the whole cloud on every rank.  'outputs' = fuse own frames, all-gather "
+                         "xyz (12 B/point over xGMI, north_star's wording); 'inputs' = all-gather depth+poses (1 B/point) "
+                         "then fuse all frames locally (same bits); '*_direct' = grouped send/recv per peer instead of "
+                         "ncclAllGather; 'none' = shards stay resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel"],
@@ -245,6 +248,24 @@ def main():
     ctx = r3d.Context(dev_index, stream=stream.cuda_stream)
     cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
 
+    # the exchange step: the library's own RCCL communicator (C ABI, r3d_comm_*) when it comes up on every rank,
+    # torch.distributed otherwise (always for gloo rehearsals)
+    transport, transport_note = None, ""
+    if use_dist:
+        want = os.environ.get("R3D_BENCH_TRANSPORT", "r3d" if backend == "nccl" else "torch")
+        if want == "r3d":
+            try:
+                CM = importlib.import_module("3d_reconstruction_system_amd.comm")
+                box = [CM.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                transport = D.R3dTransport(CM.Comm(ctx, box[0], rank, world))
+                transport_note = "r3d_comm over RCCL (%s)" % transport.comm.rccl_origin()
+            except Exception as e:     # e.g. no librccl to dlopen: every rank takes the same way out
+                transport, transport_note = None, "r3d_comm unavailable (%s: %s); " % (type(e).__name__, str(e)[:120])
+        if transport is None:
+            transport = D.TorchTransport()
+            transport_note += "torch.distributed (%s)" % backend
+
     # synthetic job: rank r owns frames [r*F, (r+1)*F) of a world*F-frame sequence
     F = a.frames
     rng = np.random.default_rng(1234 + rank)
@@ -252,37 +273,49 @@ def main():
     table = torch.from_numpy(r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)).to(dev)
     out_np = np.float32 if a.out_dtype == "float32" else np.float64
     out_t = torch.float32 if a.out_dtype == "float32" else torch.float64
+    xyz_bytes = 12 if a.out_dtype == "float32" else 24
     n_local = F * H * W
-    mode = a.assemble if use_dist else "none"
-    full = shard = depth_all = pose_all = None
-    if mode == "none":
-        shard = torch.empty((n_local, 3), dtype=out_t, device=dev)
-    else:
+    full = depth_all = pose_all = None
+    if use_dist:
         full = torch.empty((world * n_local, 3), dtype=out_t, device=dev)
-        shard = full[rank * n_local:(rank + 1) * n_local]       # 'outputs': fuse straight into this rank's slot
+        shard = full[rank * n_local:(rank + 1) * n_local]       # fuse straight into this rank's slot of the world cloud
         depth_all = torch.empty((world * F, H, W), dtype=torch.uint8, device=dev)
         pose_all = torch.empty((world * F, 12), dtype=torch.float64, device=dev)
+    else:
+        shard = torch.empty((n_local, 3), dtype=out_t, device=dev)
+    frames_pr, points_pr = [F] * world, [n_local] * world
 
     def fuse():                                                  # this rank's frames only
         r3d.fuse_frames_device(ctx, cam, depth.data_ptr(), np.uint8, F, table.data_ptr(), shard.data_ptr(), out_np)
 
+    def fuse_all():                                              # every rank's frames, from the gathered inputs
+        r3d.fuse_frames_device(ctx, cam, depth_all.data_ptr(), np.uint8, world * F, pose_all.data_ptr(), full.data_ptr(),
+                               out_np)
+
+    def with_algo(algo):
+        if isinstance(transport, D.R3dTransport):
+            transport.algo = algo
+
     def make_step(m):
+        """none: shards stay resident.  outputs: fuse own frames, all-gather xyz (north_star, 12 B/point over xGMI).
+        inputs: all-gather rasters + poses (1 B/point), fuse every frame locally.  *_direct: the same exchange as one
+        grouped send/recv per peer instead of ncclAllGather (r3d_comm only)."""
+        algo = 2 if m.endswith("_direct") else 0
         if m == "none":
             return fuse
-        if m == "outputs":
+        if m.startswith("outputs"):
             def step_outputs():
                 fuse()
-                dist.all_gather_into_tensor(full, shard)
+                with_algo(algo)
+                transport.allgather_rows(shard, points_pr, out=full)
             return step_outputs
 
         def step_inputs():
-            dist.all_gather_into_tensor(depth_all, depth)
-            dist.all_gather_into_tensor(pose_all, table)
-            r3d.fuse_frames_device(ctx, cam, depth_all.data_ptr(), np.uint8, world * F, pose_all.data_ptr(),
-                                   full.data_ptr(), out_np)
+            with_algo(algo)
+            transport.allgather_rows(depth, frames_pr, out=depth_all)
+            transport.allgather_rows(table, frames_pr, out=pose_all)
+            fuse_all()
         return step_inputs
-
-    step = make_step(mode)
 
     def fence():
         if use_dist:
@@ -292,11 +325,56 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(seconds):
+        if not use_dist:
+            return seconds
+        tm = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item())
+
     # kernel-only duration of the dominant kernel (this rank's fused launch), measured BEFORE the timed region and
     # independently of --steps: it doubles as the clock ramp, so that a short --steps run sees a warm GPU
     bytes_per_launch = n_local * (1 + 3 * (4 if a.out_dtype == "float32" else 8))
     kernel_ms, kernel_mean_ms, kernel_n = kernel_duration_ms(torch, stream, fuse)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+
+    # N > 1: every assembly strategy, timed briefly BEFORE the headline region (all of them go on the line); the
+    # headline step is --assemble, by default the fastest strategy that leaves the whole cloud on every rank
+    assemble = {}
+    mode = "none"
+    if use_dist:
+        modes = ["none", "outputs", "inputs"]
+        if isinstance(transport, D.R3dTransport):
+            modes += ["outputs_direct", "inputs_direct"]
+        for m in modes:
+            try:   # a side measurement must never cost the headline line
+                st = make_step(m)
+                for _ in range(3):
+                    st()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    st()
+                fence()
+                sec = max_over_ranks((time.perf_counter() - t1) / 10)
+                fabric_in = 0 if m == "none" else (world - 1) * (n_local * xyz_bytes if m.startswith("outputs")
+                                                                 else F * (H * W + 96))
+                entry = {"ms_per_step": round(sec * 1e3, 4), "Mpoints_s": round(world * n_local / sec / 1e6, 1),
+                         "fabric_bytes_in_per_gpu": fabric_in}
+                if fabric_in and world > 1:
+                    gbs = fabric_in / sec / 1e9          # whole step time, compute included: a lower bound on the links
+                    entry["xgmi_GBps_in_per_gpu"] = round(gbs, 1)
+                    entry["xgmi_GBps_per_link"] = round(gbs / (world - 1), 1)
+                    entry["frac_of_link_peak"] = round(gbs / (world - 1) / XGMI_LINK_GBS, 4)
+                assemble[m] = entry
+            except Exception as e:  # pragma: no cover
+                assemble[m] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:100])}
+        ok = {m: v["ms_per_step"] for m, v in assemble.items() if "ms_per_step" in v and m != "none"}
+        if a.assemble == "auto":
+            mode = min(ok, key=ok.get) if ok else "none"
+        else:
+            mode = a.assemble if (a.assemble in ok or a.assemble == "none") else "none"
+    step = make_step(mode)
 
     for _ in range(a.warmup):
         step()
@@ -310,32 +388,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     gpu_ms_per_step = ev0.elapsed_time(ev1) / max(a.steps, 1)       # this rank's stream, first step's start to last step's end
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # N > 1: the other assembly strategies, timed briefly after the main region (reported, not `value`)
-    assemble_ms = {}
-    if use_dist and (a.all_modes or os.environ.get("R3D_BENCH_ALL_MODES", "0") not in ("", "0")):
-        for m in ("none", "outputs", "inputs"):
-            if m == mode or (m != "none" and full is None):
-                continue
-            try:   # a side measurement must never cost the headline line
-                st = make_step(m)
-                for _ in range(3):
-                    st()
-                fence()
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    st()
-                fence()
-                tm = torch.tensor([(time.perf_counter() - t1) / 10], dtype=torch.float64,
-                                  device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                assemble_ms[m] = round(float(tm.item()) * 1e3, 4)
-            except Exception as e:  # pragma: no cover
-                assemble_ms[m] = "failed: %s" % type(e).__name__
+    elapsed = max_over_ranks(elapsed)
 
     # which kernel the library dispatched for this launch (r3d_fuse.hip picks by output type)
     kernel_label = "fuse_lane_kernel<u8,f32,pose>" if a.out_dtype == "float32" else "fuse_tile_kernel<u8,f64,pose>"
@@ -360,9 +413,12 @@ def main():
                        "step": {"none": "1 fused launch over this rank's frames (shards stay resident)",
                                 "outputs": "1 fused launch + all-gather of xyz shards (12 B/point over xGMI)",
                                 "inputs": "all-gather of depth+poses (1 B/point over xGMI) + 1 fused launch over "
-                                          "all ranks' frames on every rank"}[mode],
+                                          "all ranks' frames on every rank (replicated compute: each GPU writes the "
+                                          "whole cloud into its own HBM)"}[mode.replace("_direct", "")]
+                               + (" [grouped send/recv per peer]" if mode.endswith("_direct") else ""),
                        "assemble": mode,
-                       "parallelism": "frames sharded, %d rank(s)" % world},
+                       "assemble_choice": a.assemble,
+                       "parallelism": "frames sharded, %d rank(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(F, a.out_dtype),
                          "kernel": kernel_label,
@@ -370,13 +426,19 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "timing": "median over %d launches in groups of 100 between HIP events on the launch stream, "
                                    "after 50 untimed launches, before the timed region" % kernel_n,
-                         "kernel_ms_le_ms_per_step": bool(kernel_ms <= elapsed / a.steps * 1e3)},
+                         # a K-launch burst after a fence starts on an empty Infinity Cache write buffer (~256 MB =
+                         # ~40 us head start), so a short timed region can undercut the sustained median by ~1 %
+                         "kernel_ms_over_ms_per_step": round(kernel_ms / (elapsed / a.steps * 1e3), 4)},
             "gpu_ms_per_step": round(gpu_ms_per_step, 5),
             "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),
         }
-        if assemble_ms:
-            assemble_ms[mode] = line["ms_per_step"]
-            line["assemble_ms_per_step"] = assemble_ms
+        if use_dist:
+            line["transport"] = transport_note
+            line["assemble"] = assemble
+            line["scaling_note"] = ("weak: every rank owns %d frames.  A strategy that leaves the WHOLE cloud on EVERY rank "
+                                    "makes each GPU write world x %.0f MB into its own HBM, so its whole-job rate cannot "
+                                    "exceed one GPU's kernel rate; 'none' (shards stay resident for the voxel / ICP "
+                                    "stages) is the rate that scales" % (F, n_local * xyz_bytes / 1e6))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line), flush=True)

@@ -220,6 +220,38 @@ int r3d_icp_solve_dev(r3d_ctx* ctx, const double* d_sums, int with_scale, double
 int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                     uint32_t* d_idx, float* d_d2, int n_iters, int with_scale, float max_d2, double* d_state);
 
+/* ---- (e) multi-GPU: one process per GPU, frames sharded in contiguous blocks (the frame loop of camera_to_world.py:149-172
+ * carries no state between frames), ONE exchange step: an all-gather over RCCL / xGMI.  The reference has no
+ * counterpart (single process, no collective); these entry points let a ctypes or plain-C host shard without torch.
+ * librccl is dlopen'ed on first use (an RCCL already in the process is reused); without it they return
+ * R3D_ERR_UNSUPPORTED.  All transfers are asynchronous on the ctx's stream. */
+typedef struct r3d_comm r3d_comm;
+#define R3D_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to every rank by any means (file, pipe, MPI, torch). */
+int r3d_comm_unique_id(void* id_out);
+/* collective over all ranks (ncclCommInitRank on the ctx's GPU); one GPU per rank. */
+int r3d_comm_create(r3d_ctx* ctx, const void* id, int rank, int world, r3d_comm** comm_out);
+int r3d_comm_destroy(r3d_comm* comm);
+/* any out pointer may be NULL; *rccl_origin_out says which librccl was bound */
+int r3d_comm_info(const r3d_comm* comm, int* rank_out, int* world_out, const char** rccl_origin_out);
+/* All-gather of byte shards of possibly UNEQUAL length: rank r's h_counts[r] bytes land at offset sum(h_counts[0..r))
+ * of d_recv on every rank (rank order = pose-file order).  d_send may already be this rank's slot of d_recv (in place).
+ * algo: R3D_GATHER_AUTO (ncclAllGather when the shards are equal, else direct), R3D_GATHER_NCCL (equal shards only),
+ * R3D_GATHER_DIRECT (one grouped ncclSend/ncclRecv per peer: each shard crosses its own xGMI link once). */
+#define R3D_GATHER_AUTO 0
+#define R3D_GATHER_NCCL 1
+#define R3D_GATHER_DIRECT 2
+int r3d_comm_allgather(r3d_comm* comm, const void* d_send, const int64_t* h_counts, void* d_recv, int algo);
+/* "outputs" assembly: all-gather of the world-frame xyz shards (12 or 24 B/point over the fabric). */
+int r3d_allgather_xyz(r3d_comm* comm, const void* d_shard, const int64_t* h_points_per_rank, int dtype, void* d_full,
+                      int algo);
+/* "inputs" assembly: all-gather of the depth rasters (+ pose rows when d_pose_all != NULL), 1-4 B/point over the fabric;
+ * every rank then runs r3d_fuse_frames over all frames locally (same kernel, same bits as the xyz all-gather). */
+int r3d_allgather_inputs(r3d_comm* comm, const void* d_depth, int depth_dtype, const int64_t* h_frames_per_rank, int height,
+                         int width, const double* d_pose, void* d_depth_all, double* d_pose_all, int algo);
+/* in-place sum over ranks (e.g. the 18 ICP sums of a sharded source cloud) */
+int r3d_comm_allreduce_sum_f64(r3d_comm* comm, double* d_buf, int64_t n);
+
 /* ---- f1: reference-layout ASCII serialisation on the host (multi-threaded C++).
  * r3d_format_ply: the byte layout of genply() (camera_to_world.py:112-134): header with 4-space
  * indents, "%.4f %.4f %.4f \n" rows, "\n    " trailer.  Two-call protocol: with h_buf == NULL

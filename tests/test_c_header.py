@@ -16,3 +16,17 @@ def test_header_compiles_as_c99_and_consumer_links(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode in (0, 77), run.stdout + run.stderr      # 77 = no GPU visible: clean skip, no crash
     assert "r3d version 200" in run.stdout
+
+
+def test_multi_rank_c_consumer_links_and_skips_cleanly_without_gpus(tmp_path):
+    """tests/c/comm_2rank.c: one process per GPU, r3d_comm_* + r3d_allgather_xyz, no torch.  Here (no GPU) it must
+    build, link and report the clean skip; with >= 2 GPUs visible it runs the sharded fusion for real."""
+    exe = str(tmp_path / "comm_2rank")
+    libdir = os.path.join(ROOT, PKG)
+    build = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c", "comm_2rank.c"), "-o", exe, "-L", libdir, "-lr3d_hip", "-lm",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe, "2", "5"], capture_output=True, text=True, timeout=300)
+    assert run.returncode in (0, 77), run.stdout + run.stderr
+    assert ("skipped" in run.stdout) == (run.returncode == 77)
