@@ -164,13 +164,36 @@ def write_ply_rgb(path, xyz, rgb):
 
 
 def read_xyz_txt(path):
-    """[N,3] float64 from `X,Y,Z\\n` lines (first three comma-separated fields, as c2w:97-98)."""
+    """[N,3] float64 from `X,Y,Z\n` lines: the first three comma-separated fields of every non-empty line, like the
+    reference's data_p[0:3] (c2w:97-98, icp:76-80) -- extra fields (e.g. x,y,z,r,g,b) are ignored, a missing final
+    newline is fine, a malformed line raises ValueError naming it."""
     with open(path, 'r') as f:
         text = f.read()
-    if not text:
+    lines = text.split('\n')
+    if lines and lines[-1] == '':
+        lines.pop()
+    if not lines:
         return np.empty((0, 3))
-    flat = np.array(text.replace('\n', ',').split(',')[:-1], dtype=np.float64)
-    return flat.reshape(-1, 3)
+    if text.count(',') == 2 * len(lines) and '' not in lines:
+        # the common case, exactly three fields on every line: one vectorised parse
+        try:
+            return np.array(','.join(lines).split(','), dtype=np.float64).reshape(-1, 3)
+        except ValueError:
+            pass                                   # fall through to the line-by-line parse for a precise message
+    out = np.empty((len(lines), 3))
+    n = 0
+    for no, line in enumerate(lines, 1):
+        if not line.strip():
+            continue
+        fields = line.split(',')
+        try:
+            if len(fields) < 3:
+                raise ValueError
+            out[n] = [float(v) for v in fields[:3]]
+        except ValueError:
+            raise ValueError("%s line %d: expected 'x,y,z[,...]', got %r" % (path, no, line[:80])) from None
+        n += 1
+    return out[:n]
 
 
 def read_ply(path):

@@ -6,7 +6,9 @@
 
 One process per GPU (RCCL refuses two ranks on one device).
 """
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -28,6 +30,9 @@ class Comm:
         L.check(ctx.lib.r3d_comm_create(ctx.handle, buf, self.rank, self.world, C.byref(h)))
         self.handle = h.value
         ctx.adopt(self)
+        # RCCL must let go of the GPU before the interpreter starts tearing the HIP runtime down
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
 
     @staticmethod
     def unique_id():

@@ -23,6 +23,10 @@ int r3d_fail_hip(hipError_t e, const char* what, const char* file, int line) {
 int r3d_ctx_enter(r3d_ctx* ctx) {
   R3D_REQUIRE(ctx != nullptr, "ctx is NULL");
   R3D_HIP(hipSetDevice(ctx->device));
+  // HIP's "last error" is per thread and sticky: another component of the process (torch probing a pointer, a
+  // failed query) may have left one behind.  Every entry point starts here, so the hipGetLastError() after our own
+  // launches reports our launches only.
+  (void)hipGetLastError();
   return R3D_OK;
 }
 
@@ -32,6 +36,7 @@ int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
   if (ctx->scratch_bytes[slot] < bytes) {
     if (ctx->scratch[slot]) {
       R3D_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->upload_stream) R3D_HIP(hipStreamSynchronize(ctx->upload_stream));
       R3D_HIP(hipFree(ctx->scratch[slot]));
       ctx->scratch[slot] = nullptr;
       ctx->scratch_bytes[slot] = 0;
@@ -115,6 +120,7 @@ int r3d_ctx_destroy(r3d_ctx* ctx) {
   // teardown is best effort: every call below may legitimately fail once the device is gone
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   for (int i = 0; i < r3d_ctx::kScratchSlots; ++i)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   for (int i = 0; i < 4; ++i)

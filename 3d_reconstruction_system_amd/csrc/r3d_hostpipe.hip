@@ -46,6 +46,7 @@ int pinned_slot(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
   if (ctx->pinned_bytes[slot] < bytes) {
     if (ctx->pinned[slot]) {
       R3D_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->upload_stream) R3D_HIP(hipStreamSynchronize(ctx->upload_stream));
       R3D_HIP(hipHostFree(ctx->pinned[slot]));
       ctx->pinned[slot] = nullptr;
       ctx->pinned_bytes[slot] = 0;
@@ -118,12 +119,19 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
                       n_threads);
     return R3D_OK;
   };
+  // On ANY failure copies may still be in flight into the caller's buffers or the staging ring: quiesce both streams
+  // before handing control (and ownership of those buffers) back.
+  auto bail = [&](int code) -> int {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->upload_stream);
+    return code;
+  };
   for (int64_t c = 0; c < n_chunks; ++c) {
-    if (c >= 2 && (rc = drain(c - 2))) return rc;  // frees staging pair b before it is reused
-    if ((rc = issue(c))) return rc;
+    if (c >= 2 && (rc = drain(c - 2))) return bail(rc);  // frees staging pair b before it is reused
+    if ((rc = issue(c))) return bail(rc);
   }
   for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c)
-    if ((rc = drain(c))) return rc;
+    if ((rc = drain(c))) return bail(rc);
   return R3D_OK;
 }
 

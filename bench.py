@@ -142,24 +142,75 @@ def secondary(a):
         gbs = n * 24 / ms / 1e6
         line = {"metric": "Mpoints/s apply-T (4x4 on a 49.2 Mpoint f32 cloud)", "value": round(n / ms / 1e3, 1), "unit": "Mpoints/s",
                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "apply_lane_kernel<f32,f32>",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "apply_lane_kernel<f32,affine>",
                              "kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": n * 24}}
     elif a.workload == "icp":
         icp = importlib.import_module("3d_reconstruction_system_amd.icp")
         m = 500000
-        tgt = (rng.random((m, 3)) * 20).astype(np.float32)
-        src = (tgt[rng.permutation(m)] * 1.01 + 0.02).astype(np.float32)
-        dev_b = icp.IcpDevice(src, tgt, ctx, culled=False)
+        # SURVEY.md 8(d) C3 recipe: target uniform in a 20 m cube + N(0, 0.01); source = inverse similarity
+        # (s=1.7, 10 degrees, |t|=0.5) of a permutation of the noise-free target; no initial guess
+        tgt0 = rng.random((m, 3)) * 20
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        ang = np.deg2rad(10.0)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        tv = rng.normal(size=3)
+        tv *= 0.5 / np.linalg.norm(tv)
+        T_true = np.eye(4)
+        T_true[:3, :3], T_true[:3, 3] = 1.7 * Rm, tv
+        src = ((tgt0[rng.permutation(m)] - tv) @ np.linalg.inv(1.7 * Rm).T).astype(np.float32)
+        tgt = (tgt0 + rng.normal(size=tgt0.shape) * 0.01).astype(np.float32)
+        icp.icp_similarity(src[:3000], tgt[:3000], max_iter=2, ctx=ctx)                      # warm-up
+        t0 = time.perf_counter()
+        T, info = icp.icp_similarity(src, tgt, ctx=ctx)
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        near = (src.astype(np.float64) @ (T_true[:3, :3] * 1.002).T + T_true[:3, 3]).astype(np.float32)
+        dev_b = icp.IcpDevice(near, tgt, ctx, culled=False)
         ms_b = timed(dev_b.nn, 3)
         dev_b.free()
-        dev_c = icp.IcpDevice(src, tgt, ctx, culled=True)
+        dev_c = icp.IcpDevice(near, tgt, ctx, culled=True)
         ms_c = timed(dev_c.nn, 20)
+        dev_c.state_reset()
+        ms_it = timed(lambda: dev_c.iterate(1), 20)
         dev_c.free()
         tf = m * m * 8 / ms_b / 1e9
-        line = {"metric": "ICP nearest neighbour, 500k x 500k points (C3)", "value": round(m / ms_c / 1e3, 1),
-                "unit": "Mqueries/s (culled exact NN)", "culled_ms": round(ms_c, 4), "bruteforce_ms": round(ms_b, 3),
+        line = {"metric": "ICP similarity estimation, two 500k-point clouds (C3: s=1.7, 10 deg, |t|=0.5, no initial guess)",
+                "value": round(wall_ms, 2), "unit": "ms wall (upload, index builds, coarse + fine stages)", "higher_is_better": False,
+                "T_error_max_abs": float(np.abs(T - T_true).max()), "coarse_iterations": info["coarse_iterations"],
+                "fine_iterations": info["iterations"], "final_rms": info["rms_history"][-1],
+                "fine_iteration_ms": round(ms_it, 4), "culled_nn_ms": round(ms_c, 4), "bruteforce_nn_ms": round(ms_b, 3),
                 "roofline": {"bound": "valu", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                              "traffic": None, "kernel": "nn_kernel<4> (brute force, 8 flop/pair)", "kernel_ms": round(ms_b, 3)}}
+    elif a.workload == "c5":
+        # BASELINE config 5 geometry per GPU: AirSim 1920x1080 f32 depth + RGB, fused cloud carrying colour + voxel insert
+        V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
+        F, h5, w5 = max(1, min(a.frames, 100)) if a.frames != FRAMES_PER_GPU else 50, 1080, 1920
+        n = F * h5 * w5
+        depth = (rng.random((F, h5, w5), dtype=np.float32) * 99.5 + 0.5)
+        rgb = rng.integers(0, 256, size=(F, h5, w5, 3), dtype=np.uint8)
+        tab = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
+        d_depth, d_rgb, d_pose = ctx.alloc(depth.nbytes).upload(depth), ctx.alloc(rgb.nbytes).upload(rgb), ctx.alloc(tab.nbytes).upload(tab)
+        del depth, rgb
+        d_xyz, d_rgba = ctx.alloc(n * 12), ctx.alloc(n * 4)
+        cam = ctx.camera(h5, w5, 960.0, 960.0, 959.5, 539.5)
+        ms = timed(lambda: r3d.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr,
+                                                      np.float32, d_rgba.ptr), max(a.steps // 20, 20))
+        vs = V.VoxelSet(0.1, 2 * n, ctx)
+
+        def both():
+            vs.clear()
+            vs.insert_device(d_xyz.ptr, n)
+        ms_v = timed(both, 5) - timed(vs.clear, 5)
+        bpp = 16 + 7
+        gbs = n * bpp / ms / 1e6
+        line = {"metric": "Mpoints/s fused RGBD (1920x1080 f32 depth + RGB -> f32 xyz + rgba), %d frames" % F,
+                "value": round(n / ms / 1e3, 1), "unit": "Mpoints/s", "voxel_insert_ms": round(ms_v, 3),
+                "fuse_plus_voxel_Mpoints_s": round(n / (ms + ms_v) / 1e3, 1),
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "fuse_rgb_kernel<f32,pose>",
+                             "kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": n * bpp,
+                             "bytes_per_point": "16 (f32 depth in, f32 xyz out) + 7 (rgb in, rgba out)"}}
     else:
         V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
         F = FRAMES_PER_GPU
@@ -182,7 +233,8 @@ def secondary(a):
                 "roofline": {"bound": "scattered 64-bit atomics", "achieved": round(st["voxels"] / ms / 1e6, 2), "peak": 19.1,
                              "unit": "Ginserts/s", "frac": round(st["voxels"] / ms / 1e6 / 19.1, 4), "traffic": None,
                              "kernel": "voxel_insert_kernel"}}
-    line.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic", "dtype": "f64" if a.workload == "apply" else "f32",
+    line.setdefault("higher_is_better", True)
+    line.update({"n_gpus": 1, "data": "synthetic", "dtype": "f64" if a.workload in ("apply", "c5") else "f32",
                  "config": {"workload": a.workload}})
     print(json.dumps(line), flush=True)
     ctx.close()
@@ -204,9 +256,10 @@ def main():
                          "ncclAllGather; 'none' = shards stay resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
-    ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel"],
+    ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel", "c5"],
                     help="fuse (default, the headline C2 line); the others print one JSON line for a secondary kernel on "
-                         "one GPU: apply = 4x4 apply on the C2 cloud, icp = C3 (two 500k clouds), voxel = occupancy insert")
+                         "one GPU: apply = 4x4 apply on the C2 cloud, icp = C3 (two 500k clouds, SURVEY recipe), voxel = occupancy insert, "
+                         "c5 = config 5 geometry (1080p f32 RGBD, colour carried, + voxel insert)")
     a = ap.parse_args()
     if a.workload != "fuse":
         return secondary(a)

@@ -176,3 +176,25 @@ def test_sfm2npy_helper(tmp_path, monkeypatch):
         f.write(img[::-1].astype("<f4").tobytes())
     assert c2w.sfm2npy("a") == "./npy/a.npy"
     np.testing.assert_array_equal(np.load("npy/a.npy"), img)
+
+
+def test_read_xyz_txt_takes_first_three_fields_and_names_bad_lines(R, tmp_path):
+    """The reference reads data_p[0:3] of every line (c2w:97-98): extra fields are ignored, a missing final newline is
+    fine, a malformed line is an error that names the line."""
+    p = tmp_path / "a.txt"
+    p.write_text("1.5,2,3\n4,5,6.25\n")
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)), [[1.5, 2, 3], [4, 5, 6.25]])
+    p.write_text("1.5,2,3\n4,5,6.25")                                  # no trailing newline
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)), [[1.5, 2, 3], [4, 5, 6.25]])
+    p.write_text("1,2,3,255,0,7\n4,5,6,1,2,3\n")                         # x,y,z,r,g,b rows: NOT two points per line
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)), [[1, 2, 3], [4, 5, 6]])
+    p.write_text("1,2,3\n\n4,5,6\n")                                     # blank line skipped
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)), [[1, 2, 3], [4, 5, 6]])
+    p.write_text("")
+    assert R.cloud_io.read_xyz_txt(str(p)).shape == (0, 3)
+    p.write_text("1,2,3\n4,5\n")
+    with pytest.raises(ValueError, match="line 2"):
+        R.cloud_io.read_xyz_txt(str(p))
+    p.write_text("1,2,3\n4,x,6\n")
+    with pytest.raises(ValueError, match="line 2"):
+        R.cloud_io.read_xyz_txt(str(p))

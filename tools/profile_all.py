@@ -26,6 +26,7 @@ def timed(ctx, fn, iters):
 
 
 def main():
+    short = "--short" in sys.argv          # PMC passes: few launches per kernel, no brute-force NN
     ctx = r3d.Context(0)
     rng = np.random.default_rng(1234)
     out = {}
@@ -46,6 +47,15 @@ def main():
     ms = timed(ctx, lambda: r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz64.ptr, np.float64), 50)
     out["fuse_u8_f64"] = {"ms": ms, "GBps": n * 25 / ms / 1e6, "Gpts": n / ms / 1e6, "bound": "hbm", "bytes_per_point": 25}
     d_xyz64.free()
+    # colour carried through the fused launch (+7 B/point)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    d_rgb, d_rgba = ctx.alloc(rgb.nbytes).upload(rgb), ctx.alloc(n * 4)
+    ms = timed(ctx, lambda: r3d.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr,
+                                                       np.float32, d_rgba.ptr), 20 if short else 100)
+    out["fuse_rgb_u8_f32"] = {"ms": ms, "GBps": n * 20 / ms / 1e6, "Gpts": n / ms / 1e6, "bound": "hbm", "bytes_per_point": 20}
+    d_rgb.free()
+    d_rgba.free()
+    r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
     # apply-T on the fused cloud, in place semantics excluded: separate output
     d_xyz2 = ctx.alloc(n * 12)
     T = np.eye(4)
@@ -75,14 +85,20 @@ def main():
     tgt = (rng.random((m, 3)) * 20).astype(np.float32)
     src = (tgt[rng.permutation(m)] * 1.01 + 0.02).astype(np.float32)
     dev = icp.IcpDevice(src, tgt, ctx, culled=False)
-    ms = timed(ctx, dev.nn, 3)
-    out["icp_nn_bruteforce_500k"] = {"ms": ms, "Tpairs": m * m / ms / 1e9, "TFLOPs_at_8_flop_per_pair": m * m * 8 / ms / 1e9,
-                                     "bound": "fp32 VALU"}
+    if not short:
+        ms = timed(ctx, dev.nn, 3)
+        out["icp_nn_bruteforce_500k"] = {"ms": ms, "Tpairs": m * m / ms / 1e9, "TFLOPs_at_8_flop_per_pair": m * m * 8 / ms / 1e9,
+                                         "bound": "fp32 VALU"}
     devc = icp.IcpDevice(src, tgt, ctx, culled=True)
     ms = timed(ctx, devc.nn, 10)
     swept = devc.nn(want_stats=True)
     out["icp_nn_culled_500k"] = {"ms": ms, "tile_sweeps_per_workgroup": swept / -(-m // 256), "tiles": -(-m // 1024),
                                  "note": "same indices and distances as the brute-force sweep"}
+    ms = timed(ctx, lambda: devc.nn_sums(), 10)
+    out["icp_nn_culled_fused_sums_500k"] = {"ms_incl_144B_D2H": ms}
+    devc.state_reset()
+    ms = timed(ctx, lambda: devc.iterate(1), 20)
+    out["icp_whole_iteration_500k"] = {"ms": ms, "what": "culled NN + fused 18 sums + device Umeyama solve + apply, one enqueue, no host sync"}
     devc.free()
     import time
     t0 = time.perf_counter()
