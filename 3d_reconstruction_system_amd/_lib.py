@@ -129,6 +129,29 @@ def load():
     return lib
 
 
+def hip_runtimes_loaded():
+    """Paths of every libamdhip64 mapped into this process.  PyTorch-ROCm wheels bundle their own copy and ask for it
+    by the unversioned name, so a process that loads libr3d_hip.so BEFORE importing torch ends up with two HIP runtimes:
+    device addresses still work across them, but a hipStream_t made by one is garbage to the other."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def require_single_hip_runtime(what):
+    libs = hip_runtimes_loaded()
+    if len(libs) > 1:
+        raise R3DError(ERR_INVALID, "%s needs ONE HIP runtime in the process, found %s: import torch before the first use "
+                                    "of this package (torch's bundled runtime is then shared), or keep to the default "
+                                    "stream" % (what, ", ".join(libs)))
+
+
 def last_error():
     msg = load().r3d_last_error()
     return msg.decode("utf-8", "replace") if msg else ""

@@ -19,7 +19,8 @@
 //     instruction must write one contiguous run of bytes, 12 B per lane at a 12-B lane stride, nontemporal
 //     (`global_store_dwordx3 ... nt` = 768 contiguous bytes per wave instruction; partial lines must not allocate in L2).
 //       - f32 xyz  (fuse_lane_kernel): lane `tid` takes pixels tid, tid+256, tid+512, tid+768 of the tile; one x3 store
-//         per pixel.  6.6-6.8 TB/s = 0.83-0.85 of the 8 TB/s peak.  Grid: 8 workgroups per CU striding over tiles.
+//         per pixel.  6.6-6.8 TB/s = 0.83-0.85 of the 8 TB/s peak (C2, byte raster).  Grid: 8 workgroups per CU
+//         striding over tiles for byte rasters, one tile per workgroup otherwise.
 //       - f64 xyz  (fuse_pair_kernel): a 24-B row cannot leave in one instruction, and every split of it by instruction
 //         (x4+x2, 3 x x2) leaves gaps inside each wave instruction (2.7 TB/s).  So TWO LANES share a pixel: the even lane
 //         computes world x,y and stores (x_lo x_hi y_lo), the odd lane computes y,z and stores (y_hi z_lo z_hi) -- again
@@ -27,7 +28,10 @@
 //         6.4 TB/s = 0.80 of peak (the LDS-transposed 16-B-store kernel of round 1: 5.4-5.6).  Grid: one tile per
 //         workgroup.
 //       - f32 xyz + colour (fuse_rgb_kernel): the tile's 3072 rgb bytes come in as 192 16-byte loads through LDS, each
-//         pixel leaves one nontemporal dword (r | g<<8 | b<<16, alpha 0).  7.1 TB/s = 0.89 of peak at 20 B/point.
+//         pixel leaves one nontemporal dword (r | g<<8 | b<<16, alpha 0).  7.1-7.3 TB/s = 0.89-0.91 of peak at
+//         20 B/point when the inputs sit in the 256 MiB Infinity Cache between launches (C2), 5.3-6.0 TB/s when
+//         depth + colour really stream from HBM (config 5: 1080p f32 depth, 23 B/point).
+#include <cstdlib>
 #include <type_traits>
 
 #include "r3d_internal.h"
@@ -90,6 +94,7 @@ __device__ __forceinline__ void point(double z, double u, double v, const Pose& 
 }
 
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 // one global_store_dwordx3 with the nontemporal hint (4-byte alignment suffices on gfx950)
@@ -101,6 +106,28 @@ __device__ __forceinline__ void store_x3_nt(void* dst, u32x3 v) {
 }
 
 // ---- f32 xyz: lane-per-pixel rounds ----------------------------------------------------------------------------
+// ITEMS loads per lane; item q = r*256 + tid reads pixel q >> SHIFT of the tile (SHIFT 1: two lanes share a pixel).
+// CLAMP: UNCONDITIONAL loads from a clamped index.  With a predicated load (`p < hw ? depth[p] : 0`) of a u16 / f32
+// element the compiler sinks each element's conversion into the load's own branch and puts an s_waitcnt vmcnt(0)
+// behind every load -- four serialised memory round trips per tile, invisible while the raster sits in the Infinity
+// Cache, a 1.3-1.5x loss when it really comes from HBM (1080p batches; profiles/r02_c5_probe.log).  Byte rasters keep
+// the predicated form: their loads were batched anyway and the clamped form schedules worse for them (measured).
+template <typename DT, int ITEMS, int SHIFT, bool CLAMP>
+__device__ __forceinline__ void load_tile(const DT* __restrict__ depth, const FuseDims& dm, uint32_t tile, uint32_t tid,
+                                          DT raw[ITEMS]) {
+  const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+  const uint32_t tf = tile - frame * dm.tiles_per_frame;
+  const uint64_t fbase = (uint64_t)frame * dm.hw;
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const uint32_t p = tf * kTile + ((r * kThreads + tid) >> SHIFT);
+    if (CLAMP)
+      raw[r] = depth[fbase + min(p, dm.hw - 1)];  // lanes past the frame's end read its last pixel and store nothing
+    else
+      raw[r] = p < dm.hw ? depth[fbase + p] : DT(0);
+  }
+}
+
 template <typename DT, bool POSE>
 __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restrict__ depth, float* __restrict__ out,
                                                              const double* __restrict__ u, const double* __restrict__ v,
@@ -113,11 +140,7 @@ __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restric
     load_pose<POSE>(pose, frame, P);
     const uint64_t fbase = (uint64_t)frame * dm.hw;
     DT raw[kPx];
-#pragma unroll
-    for (int r = 0; r < kPx; ++r) {
-      const uint32_t p = tf * kTile + r * kThreads + tid;
-      raw[r] = p < dm.hw ? depth[fbase + p] : DT(0);
-    }
+    load_tile<DT, kPx, 0, (sizeof(DT) > 1)>(depth, dm, tile, tid, raw);
 #pragma unroll
     for (int r = 0; r < kPx; ++r) {
       const uint32_t p = tf * kTile + r * kThreads + tid;
@@ -157,11 +180,7 @@ __global__ __launch_bounds__(kThreads) void fuse_pair_kernel(const DT* __restric
     }
     const uint64_t fbase = (uint64_t)frame * dm.hw;
     DT raw[kItems];
-#pragma unroll
-    for (int r = 0; r < kItems; ++r) {
-      const uint32_t p = tf * kTile + ((r * kThreads + tid) >> 1);
-      raw[r] = p < dm.hw ? depth[fbase + p] : DT(0);
-    }
+    load_tile<DT, kItems, 1, (sizeof(DT) > 1)>(depth, dm, tile, tid, raw);
     uint32_t* tile_out = reinterpret_cast<uint32_t*>(out) + (fbase + (uint64_t)tf * kTile) * 6;
 #pragma unroll
     for (int r = 0; r < kItems; ++r) {
@@ -200,23 +219,30 @@ __global__ __launch_bounds__(kThreads) void fuse_rgb_kernel(const DT* __restrict
                                                             const double* __restrict__ pose, const FuseDims dm) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kTile * 3];
   const uint32_t tid = threadIdx.x;
+  // whole, aligned tiles bring their 3072 colour bytes in as 192 16-byte loads (wave-uniform choice per tile)
+  auto is_staged = [&](uint32_t tile) {
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
+    return dm.rgb_vec_ok && (tf + 1) * kTile <= dm.hw;
+  };
+  auto colour_chunk = [&](uint32_t tile) -> u32x4 {
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
+    return reinterpret_cast<const u32x4*>(rgb + ((uint64_t)frame * dm.hw + (uint64_t)tf * kTile) * 3)[tid];
+  };
   for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
     const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
     const uint32_t tf = tile - frame * dm.tiles_per_frame;
     Pose P;
     load_pose<POSE>(pose, frame, P);
     const uint64_t fbase = (uint64_t)frame * dm.hw;
+    const bool staged = is_staged(tile);
     DT raw[kPx];
-#pragma unroll
-    for (int r = 0; r < kPx; ++r) {
-      const uint32_t p = tf * kTile + r * kThreads + tid;
-      raw[r] = p < dm.hw ? depth[fbase + p] : DT(0);
-    }
-    // whole, aligned tiles: 192 lanes bring the tile's 3072 colour bytes in as 16-byte loads (wave-uniform choice)
-    const bool staged = dm.rgb_vec_ok && (tf + 1) * kTile <= dm.hw;
+    u32x4 ccur = {0, 0, 0, 0};
+    load_tile<DT, kPx, 0, true>(depth, dm, tile, tid, raw);
+    if (staged && tid < kTile * 3 / 16) ccur = colour_chunk(tile);
     if (staged) {
-      if (tid < kTile * 3 / 16)
-        reinterpret_cast<uint4*>(lds)[tid] = reinterpret_cast<const uint4*>(rgb + (fbase + (uint64_t)tf * kTile) * 3)[tid];
+      if (tid < kTile * 3 / 16) reinterpret_cast<u32x4*>(lds)[tid] = ccur;
       __syncthreads();
     }
 #pragma unroll
@@ -348,11 +374,10 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   dm.rgb_vec_ok = d_rgb && ((uintptr_t)d_rgb % 16 == 0) && (hw % 16 == 0);
   const bool colour_after = d_rgb && out_dtype == R3D_F64;  // f64 xyz: colour goes through its own pass
   if (colour_after) p.rgb = nullptr;
-  // measured (profiles/): the f32 store stream likes 8 resident workgroups per CU striding over tiles, the pair
-  // kernel and the colour kernel one tile per workgroup
-  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks
-                    : (out_dtype == R3D_F64) ? total_tiles
-                                             : (uint64_t)ctx->num_cus * 8;
+  // measured (profiles/r02_c5_probe.log): one tile per workgroup everywhere except the byte-raster f32 kernel, whose
+  // store stream likes 8 resident workgroups per CU striding over tiles
+  const bool stride8 = out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
+  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : stride8 ? (uint64_t)ctx->num_cus * 8 : total_tiles;
   if (blocks > total_tiles) blocks = total_tiles;
   if (with_pose)
     launch_depth<true>(p, dm, depth_dtype, out_dtype, (int)blocks, ctx->stream);

@@ -93,6 +93,8 @@ class Context:
         if stream is None:
             L.check(self.lib.r3d_ctx_create(int(device), None, 0, C.byref(h)))
         else:
+            if int(stream) != 0:
+                L.require_single_hip_runtime("launching on another component's HIP stream")
             L.check(self.lib.r3d_ctx_create(int(device), C.c_void_p(int(stream)), L.CTX_EXTERNAL_STREAM, C.byref(h)))
         self.handle = h.value
         self.device = int(device)

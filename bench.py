@@ -124,12 +124,24 @@ def secondary(a):
     rng = np.random.default_rng(1234)
 
     def timed(fn, iters):
-        fn()
-        ctx.sync()
-        ctx.timer_start()
-        for _ in range(iters):
+        """Median of 5 groups of `iters`/5 launches, after a warm-up of >= 5 launches and >= 60 ms (the clocks of an
+        idle GPU boost for the first ~2 ms and then dip for ~20 ms: profiles/r02_*: neither belongs in a rate)."""
+        t0 = time.perf_counter()
+        k = 0
+        while k < 5 or time.perf_counter() - t0 < 0.06:
             fn()
-        return ctx.timer_stop() / iters
+            k += 1
+            if k % 5 == 0:
+                ctx.sync()
+        ctx.sync()
+        per = max(iters // 5, 1)
+        groups = []
+        for _ in range(5):
+            ctx.timer_start()
+            for _ in range(per):
+                fn()
+            groups.append(ctx.timer_stop() / per)
+        return sorted(groups)[2]
 
     if a.workload == "apply":
         n = FRAMES_PER_GPU * H * W

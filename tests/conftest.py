@@ -9,6 +9,14 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# PyTorch-ROCm bundles its own libamdhip64 and asks for it by the unversioned name: whoever loads first decides whether
+# the process ends up with one HIP runtime or two (3d_reconstruction_system_amd/_lib.py: hip_runtimes_loaded).  Tests mix
+# torch tensors / streams with the library, so torch goes first.
+try:
+    import torch  # noqa: F401,E402
+except ImportError:
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
