@@ -189,22 +189,6 @@ __global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __res
   block_reduce_store(acc, red, partials + (int64_t)blockIdx.x * kSums);
 }
 
-// One workgroup per sum: 256 lanes stride over the per-workgroup partials in a fixed order, then a fixed LDS tree.
-__global__ __launch_bounds__(kThreads) void accumulate_final_kernel(const double* __restrict__ partials, int n_blocks,
-                                                                    double* __restrict__ sums) {
-  __shared__ double red[kThreads];
-  const int k = blockIdx.x;
-  double v = 0.0;
-  for (int b = threadIdx.x; b < n_blocks; b += kThreads) v += partials[(int64_t)b * kSums + k];
-  red[threadIdx.x] = v;
-  __syncthreads();
-  for (int half = kThreads / 2; half > 0; half >>= 1) {
-    if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) sums[k] = red[0];
-}
-
 // ---- device-side similarity solve: the ICP loop never waits for the host ---------------------------------
 __global__ void icp_state_reset_kernel(double* __restrict__ st) {
   for (int k = threadIdx.x; k < r3d_icp::kStateDoubles; k += blockDim.x) {
@@ -215,9 +199,8 @@ __global__ void icp_state_reset_kernel(double* __restrict__ st) {
 }
 
 // One thread: step = umeyama(sums); T_total <- step . T_total; history.  A degenerate fit leaves the identity step.
-__global__ void icp_solve_kernel(const double* __restrict__ sums, int with_scale, double* __restrict__ st) {
-  double s[kSums], T[16], rms = 0.0;
-  for (int k = 0; k < kSums; ++k) s[k] = sums[k];
+__device__ void icp_solve_step(const double* s, int with_scale, double* __restrict__ st) {
+  double T[16], rms = 0.0;
   const int bad = r3d_icp::umeyama_from_sums(s, with_scale, T, &rms);
   double tot[16], nt[16];
   for (int k = 0; k < 16; ++k) tot[k] = st[r3d_icp::kStateTTotal + k];
@@ -239,20 +222,65 @@ __global__ void icp_solve_kernel(const double* __restrict__ sums, int with_scale
   st[r3d_icp::kStatePairs] = s[0];
 }
 
+__global__ void icp_solve_kernel(const double* __restrict__ sums, int with_scale, double* __restrict__ st) {
+  double s[kSums];
+  for (int k = 0; k < kSums; ++k) s[k] = sums[k];
+  icp_solve_step(s, with_scale, st);
+}
+
+// ONE workgroup finishes a sums pass: (1) the per-workgroup partial rows, lane t taking rows t, t+256, ... in order;
+// (2) when the culled NN kernel handed sources to its exact fallback (flag != 0; *tie_count says whether any), their
+// pairs, lane t taking sources t, t+256, ...; (3) fixed shuffle / LDS tree -> the 18 sums; (4) optionally the similarity
+// solve and the ICP state update by lane 0.  Every order is fixed: bitwise repeatable.  One launch instead of
+// (flagged pass, final reduction, solve).
+__global__ __launch_bounds__(kThreads) void sums_finish_kernel(const double* __restrict__ partials, int n_rows,
+                                                               const float* __restrict__ src, int64_t n_src,
+                                                               const float* __restrict__ tgt, const uint32_t* __restrict__ idx,
+                                                               const float* __restrict__ d2, float max_d2, float dead_zone,
+                                                               const unsigned char* __restrict__ flag,
+                                                               const unsigned* __restrict__ tie_count,
+                                                               double* __restrict__ sums_out, int with_scale,
+                                                               double* __restrict__ state) {
+  __shared__ double red[kThreads / 64][kSums];
+  __shared__ double total[kSums];
+  double acc[kSums];
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+  for (int b = threadIdx.x; b < n_rows; b += kThreads) {
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] += partials[(int64_t)b * kSums + k];
+  }
+  if (flag != nullptr && *tie_count != 0u) {
+    for (int64_t i = threadIdx.x; i < n_src; i += kThreads) {
+      if (flag[i] == 0) continue;
+      if (max_d2 >= 0.f && !(d2[i] <= max_d2)) continue;
+      const int64_t j = idx[i];
+      const double p[3] = {(double)src[i * 3 + 0], (double)src[i * 3 + 1], (double)src[i * 3 + 2]};
+      const double q[3] = {(double)tgt[j * 3 + 0], (double)tgt[j * 3 + 1], (double)tgt[j * 3 + 2]};
+      pair_accumulate(acc, pair_weight(d2[i], dead_zone), p, q);
+    }
+  }
+  block_reduce_store(acc, red, total);
+  __syncthreads();
+  if (threadIdx.x < kSums) sums_out[threadIdx.x] = total[threadIdx.x];
+  if (threadIdx.x == 0 && state != nullptr) {
+    double s[kSums];
+    for (int k = 0; k < kSums; ++k) s[k] = total[k];
+    icp_solve_step(s, with_scale, state);
+  }
+}
+
 }  // namespace
 
-// Second half of the fused NN + sums path (r3d_nnindex.hip): partial rows [0, main_blocks) were written by the NN
-// kernel; the sources it handed to the exact fallback (flag != 0) are summed here in a fixed order into rows
-// [main_blocks, main_blocks + tie_blocks), then everything is reduced in a fixed order -> bitwise repeatable.
+// Second half of every sums pass (also of the fused NN + sums path of r3d_nnindex.hip): see sums_finish_kernel.
+// d_state != NULL additionally solves the similarity step on the GPU and updates the ICP state.
 int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
                         const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,
-                        const unsigned* d_tie_count, double* d_partials, int main_blocks, int tie_blocks,
-                        double* d_sums_out) {
-  hipLaunchKernelGGL(accumulate_kernel, dim3(tie_blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx, d_d2,
-                     max_d2 >= 0.f ? max_d2 : -1.f, dead_zone, d_flag, d_tie_count,
-                     d_partials + (size_t)main_blocks * kSums);
-  hipLaunchKernelGGL(accumulate_final_kernel, dim3(kSums), dim3(kThreads), 0, ctx->stream, d_partials,
-                     main_blocks + tie_blocks, d_sums_out);
+                        const unsigned* d_tie_count, const double* d_partials, int n_rows, double* d_sums_out,
+                        int with_scale, double* d_state) {
+  hipLaunchKernelGGL(sums_finish_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d_partials, n_rows, d_src, n_src, d_tgt,
+                     d_idx, d_d2, max_d2 >= 0.f ? max_d2 : -1.f, dead_zone, d_flag, d_tie_count, d_sums_out, with_scale,
+                     d_state);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
@@ -336,9 +364,9 @@ int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float
 }
 
 // sums over the matched pairs into a DEVICE array of 18 doubles; asynchronous on the ctx stream
-int r3d_icp_accumulate_dev(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
-                           const uint32_t* d_idx, const float* d_d2, float max_d2, float dead_zone,
-                           double* d_sums_out) {
+static int accumulate_impl(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                           const uint32_t* d_idx, const float* d_d2, float max_d2, float dead_zone, double* d_sums_out,
+                           int with_scale, double* d_state) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(n_src >= 0 && n_tgt >= 0, "negative cloud size");
@@ -359,10 +387,16 @@ int r3d_icp_accumulate_dev(r3d_ctx* ctx, const float* d_src, int64_t n_src, cons
   hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx,
                      (gated || dead_zone > 0.f) ? d_d2 : nullptr, gated ? max_d2 : -1.f, dead_zone,
                      (const unsigned char*)nullptr, (const unsigned*)nullptr, d_part);
-  hipLaunchKernelGGL(accumulate_final_kernel, dim3(kSums), dim3(kThreads), 0, ctx->stream, d_part, blocks, d_sums_out);
   R3D_HIP(hipGetLastError());
   (void)n_tgt;
-  return R3D_OK;
+  return r3d_icp_sums_finish(ctx, d_src, n_src, d_tgt, d_idx, d_d2, -1.f, 0.f, nullptr, nullptr, d_part, blocks, d_sums_out,
+                             with_scale, d_state);
+}
+
+int r3d_icp_accumulate_dev(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
+                           const uint32_t* d_idx, const float* d_d2, float max_d2, float dead_zone,
+                           double* d_sums_out) {
+  return accumulate_impl(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, dead_zone, d_sums_out, 0, nullptr);
 }
 
 int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
@@ -424,12 +458,13 @@ int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_s
   for (int it = 0; it < n_iters; ++it) {
     if (index) {
       // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud): no sort, sums fused
-      if ((rc = r3d_nn_index_query_sums(index, d_src, n_src, d_idx, d_d2, 1, max_d2, 0.f, d_sums))) return rc;
+      // (the last kernel of the sums pass also solves the step and updates d_state)
+      if ((rc = r3d_nn_index_query_solve(index, d_src, n_src, d_idx, d_d2, max_d2, d_sums, with_scale, d_state))) return rc;
     } else {
       if ((rc = r3d_icp_nn(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2))) return rc;
-      if ((rc = r3d_icp_accumulate_dev(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, 0.f, d_sums))) return rc;
+      if ((rc = accumulate_impl(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, 0.f, d_sums, with_scale, d_state)))
+        return rc;
     }
-    if ((rc = r3d_icp_solve_dev(ctx, d_sums, with_scale, d_state))) return rc;
     if ((rc = r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32))) return rc;
   }
   return R3D_OK;

@@ -76,11 +76,14 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
 // Stable LSD radix sort of 64-bit keys by their low `bits` bits (r3d_sort.hip); d_tmp holds n keys.
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits);
 
-// r3d_icp.hip: finish the fused NN + 18-sums path of r3d_nnindex.hip (flagged fallback sources + fixed-order reduction)
+// r3d_icp.hip: last kernel of a sums pass (partial rows + flagged fallback sources -> 18 sums [-> solve + ICP state])
 int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
                         const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,
-                        const unsigned* d_tie_count, double* d_partials, int main_blocks, int tie_blocks,
-                        double* d_sums_out);
+                        const unsigned* d_tie_count, const double* d_partials, int n_rows, double* d_sums_out,
+                        int with_scale, double* d_state);
+// r3d_nnindex.hip: presorted culled query + fused sums + device solve (one iteration's worth, used by r3d_icp_iterate)
+int r3d_nn_index_query_solve(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                             float max_d2, double* d_sums_out, int with_scale, double* d_state);
 
 static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
 static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

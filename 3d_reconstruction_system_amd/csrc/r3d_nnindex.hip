@@ -519,7 +519,7 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
 
 static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
                                int presorted, int64_t* h_tiles_swept, bool want_sums, float max_d2, float dead_zone,
-                               double* d_sums_out) {
+                               double* d_sums_out, int with_scale = 0, double* d_state = nullptr) {
   R3D_REQUIRE(ix != nullptr, "nn index is NULL");
   r3d_ctx* ctx = ix->ctx;
   int rc = r3d_ctx_enter(ctx);
@@ -557,11 +557,10 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   if (S != 1 && S != 2 && S != 4) S = 1;
   const int64_t per_block = (int64_t)kThreads * S;
   const unsigned blocks = (unsigned)((n_src + per_block - 1) / per_block);
-  const int tie_blocks = 64;  // fixed: the follow-up pass over flagged sources is part of the reduction order
   double* partials = nullptr;
   if (want_sums) {
     void* pv = nullptr;
-    if ((rc = r3d_scratch(ctx, 4, ((size_t)blocks + tie_blocks) * r3d_icp::kSums * sizeof(double), &pv))) return rc;
+    if ((rc = r3d_scratch(ctx, 4, (size_t)blocks * r3d_icp::kSums * sizeof(double), &pv))) return rc;
     partials = static_cast<double*>(pv);
   }
 #define R3D_LAUNCH_CULL(SS, FMT, PTR)                                                                                  \
@@ -584,7 +583,7 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   R3D_HIP(hipGetLastError());
   if (want_sums &&
       (rc = r3d_icp_sums_finish(ctx, d_src, n_src, ix->d_tgt, d_idx_out, d_d2_out, max_d2, dead_zone, tie_flag, tie_count,
-                                partials, (int)blocks, tie_blocks, d_sums_out)))
+                                partials, (int)blocks, d_sums_out, with_scale, d_state)))
     return rc;
   if (h_tiles_swept) {
     unsigned long long v = 0;
@@ -605,6 +604,16 @@ int r3d_nn_index_query_sums(r3d_nn_index* ix, const float* d_src, int64_t n_src,
   return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, presorted, nullptr, true, max_d2, dead_zone,
                              d_sums_out);
 }
+
+}  // extern "C"
+
+int r3d_nn_index_query_solve(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                             float max_d2, double* d_sums_out, int with_scale, double* d_state) {
+  return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, 1, nullptr, true, max_d2, 0.f, d_sums_out, with_scale,
+                             d_state);
+}
+
+extern "C" {
 
 // gathers xyz rows by the index part of sorted keys
 __global__ __launch_bounds__(kThreads) void gather3_kernel(const float* __restrict__ xyz, const uint64_t* __restrict__ keys,

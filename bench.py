@@ -456,7 +456,7 @@ def main():
     elapsed = max_over_ranks(elapsed)
 
     # which kernel the library dispatched for this launch (r3d_fuse.hip picks by output type)
-    kernel_label = "fuse_lane_kernel<u8,f32,pose>" if a.out_dtype == "float32" else "fuse_tile_kernel<u8,f64,pose>"
+    kernel_label = "fuse_lane_kernel<u8,f32,pose>" if a.out_dtype == "float32" else "fuse_pair_kernel<u8,f64,pose>"
     if rank == 0:
         total_pts = world * n_local * a.steps
         line = {

@@ -101,6 +101,7 @@ int main(int argc, char** argv) {
   pid_t pids[16];
   unsigned char id[R3D_COMM_ID_BYTES];
   printf("r3d version %d\n", r3d_version());
+  fflush(stdout); /* before any fork: children inherit stdio buffers */
   if (world < 1 || world > 16) return 1;
   /* counting devices happens in a child: the parent must not initialise the GPU before it forks */
   {
@@ -119,6 +120,7 @@ int main(int argc, char** argv) {
   }
   if (n_gpus < world) {
     printf("%d GPU(s) visible, %d ranks wanted: RCCL needs one GPU per rank -- skipped\n", n_gpus, world);
+    fflush(stdout);
     return 77;
   }
   for (rank = 0; rank < world; ++rank)
@@ -137,7 +139,11 @@ int main(int argc, char** argv) {
       } else if (read(pipes[rank][0], id, sizeof(id)) != (ssize_t)sizeof(id)) {
         _exit(1);
       }
-      _exit(run_rank(rank, world, id, n_frames));
+      {
+        int rc = run_rank(rank, world, id, n_frames);
+        fflush(NULL);
+        _exit(rc);
+      }
     }
   }
   for (rank = 0; rank < world; ++rank) {
