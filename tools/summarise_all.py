@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<round>/ (tools/collect_profiles.sh) -> tracked summaries under profiles/:
+  <round>_fuse_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the driver's bench command (verbatim)
+  <round>_fuse_summary.json       that kernel: stats row, trace median / steady-state mean, the bench line, PMC traffic
+  pmc_fuse_latest.json            HBM bytes per launch of the headline kernel (read by bench.py when the config matches)
+  <round>_all_kernels_stats.csv   stats of every kernel at BASELINE sizes (tools/profile_all.py), verbatim
+  <round>_all_kernels.json        per kernel: calls, avg / median ns, PMC FETCH_SIZE x2 + WRITE_SIZE bytes per launch,
+                                  algorithmic bytes, the ratio, achieved TB/s from the median
+MI355X_MICROARCH.md (HBM section): the counters are KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B (x2)."""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# algorithmic bytes per launch of tools/profile_all.py's launches (C2: 49,152,000 points; C3: 500k x 500k)
+N_C2 = 100 * 384 * 1280
+ALGO = {
+    "fuse_lane_kernel<unsigned char, true>": ("fused unproject+SE(3), u8 -> f32 xyz", N_C2 * 13),
+    "fuse_lane_kernel<unsigned char, false>": ("unproject only, u8 -> f32 xyz", N_C2 * 13),
+    "fuse_pair_kernel<unsigned char, true>": ("fused, u8 -> f64 xyz (lane pairs)", N_C2 * 25),
+    "fuse_rgb_kernel<unsigned char, true>": ("fused + colour, u8 depth + rgb -> f32 xyz + rgba", N_C2 * 20),
+    "apply_lane_kernel<float, false>": ("apply-T 4x4, f32 -> f32", N_C2 * 24),
+    "nn_cull_kernel<1, false>": ("culled exact NN + fused 18 sums, 500k x 500k (min bytes 12(N+M)+8N)", 500000 * (24 + 8)),
+    "voxel_insert_kernel<true>": ("voxel insert of the C2 cloud (12 B/point read; scattered 8-B atomics)", N_C2 * 12),
+}
+
+
+def one(pattern):
+    hits = glob.glob(pattern, recursive=True)
+    if not hits:
+        raise SystemExit("nothing matches " + pattern)
+    return hits[0]
+
+
+def pmc(dirname, counter):
+    out = {}
+    f = one(os.path.join(dirname, "**", "*_counter_collection.csv"))
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            out.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: statistics.median(v) for k, v in out.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r02")
+    a = ap.parse_args()
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + a.round)
+    dst = os.path.join(ROOT, "profiles")
+    # ---- headline kernel under the driver's command
+    stats = one(os.path.join(src, "trace", "**", "*_kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(dst, "%s_fuse_kernel_stats.csv" % a.round))
+    row = [r for r in csv.DictReader(open(stats)) if "fuse_lane_kernel" in r["Name"]][0]
+    tr = [r for r in csv.DictReader(open(one(os.path.join(src, "trace", "**", "*_kernel_trace.csv")))) if "fuse_lane_kernel" in r["Kernel_Name"]]
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
+    summary = {"round": a.round, "command": "python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline",
+               "rocprof_kernel_stats": {"name": row["Name"], "calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]),
+                                        "min_ns": int(row["MinNs"]), "max_ns": int(row["MaxNs"])},
+               "rocprof_kernel_trace": {"n": len(d), "median_ns": statistics.median(d), "last_half_mean_ns": statistics.mean(d[len(d) // 2:]),
+                                        "first_30_ns": d[:30], "grid": tr[0]["Grid_Size_X"], "workgroup": tr[0]["Workgroup_Size_X"],
+                                        "vgpr": tr[0]["VGPR_Count"], "sgpr": tr[0]["SGPR_Count"], "lds": tr[0]["LDS_Block_Size"],
+                                        "note": "an idle GPU boosts for ~20 launches (~93 us), dips for ~20 ms (up to ~140 us), then settles"}}
+    for line in open(os.path.join(src, "trace.log")):
+        if line.startswith("{"):
+            summary["bench_line_under_rocprof"] = json.loads(line)
+    fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    kf = [k for k in fetch if "fuse_lane_kernel" in k][0]
+    rd, wr = fetch[kf] * 1024 * 2, write[kf] * 1024
+    summary.update({"pmc_raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf]}, "hbm_read_bytes_per_launch_corrected_x2": rd,
+                    "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": N_C2 * 13,
+                    "traffic_over_algorithmic": (rd + wr) / (N_C2 * 13)})
+    json.dump(summary, open(os.path.join(dst, "%s_fuse_summary.json" % a.round), "w"), indent=1)
+    json.dump({"round": a.round, "config": {"frames": 100, "out_dtype": "float32", "depth": "u8"}, "hbm_bytes_per_launch": rd + wr,
+               "read_bytes_x2_corrected": rd, "write_bytes": wr, "raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf]},
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --gpus 1 --steps 20 --warmup 5`"},
+              open(os.path.join(dst, "pmc_fuse_latest.json"), "w"), indent=1)
+    # ---- every kernel
+    stats = one(os.path.join(src, "all", "**", "*_kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(dst, "%s_all_kernels_stats.csv" % a.round))
+    rows = list(csv.DictReader(open(stats)))
+    trace = list(csv.DictReader(open(one(os.path.join(src, "all", "**", "*_kernel_trace.csv")))))
+    fetch, write = pmc(os.path.join(src, "all_pmc_FETCH_SIZE"), "FETCH_SIZE"), pmc(os.path.join(src, "all_pmc_WRITE_SIZE"), "WRITE_SIZE")
+    out = {}
+    for r in rows:
+        name = r["Name"]
+        d = [int(t["End_Timestamp"]) - int(t["Start_Timestamp"]) for t in trace if t["Kernel_Name"] == name]
+        e = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "median_ns": statistics.median(d) if d else None,
+             "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
+        if name in fetch and name in write:
+            e["pmc_hbm_read_bytes_x2"] = fetch[name] * 2048
+            e["pmc_hbm_write_bytes"] = write[name] * 1024
+        for key, (what, algo) in ALGO.items():
+            if key in name:
+                e["what"] = what
+                e["algorithmic_bytes"] = algo
+                if "pmc_hbm_read_bytes_x2" in e:
+                    e["traffic_over_algorithmic"] = round((e["pmc_hbm_read_bytes_x2"] + e["pmc_hbm_write_bytes"]) / algo, 4)
+                if e["median_ns"]:
+                    e["TBps_algorithmic_at_median"] = round(algo / e["median_ns"] / 1e3, 3)
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        out[short.split("(")[0]] = e
+    hip_events = None
+    for line in open(os.path.join(src, "all.log")):
+        pass
+    text = open(os.path.join(src, "all.log")).read()
+    if "{" in text:
+        try:
+            hip_events = json.loads(text[text.index("{\n"):text.rindex("}") + 1])
+        except Exception:
+            hip_events = None
+    json.dump({"round": a.round, "kernels": out, "hip_event_timings_profile_all": hip_events,
+               "note": "PMC columns: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/profile_all.py --short; "
+                       "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B reads as 64 B)"},
+              open(os.path.join(dst, "%s_all_kernels.json" % a.round), "w"), indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("calls", "median_ns", "traffic_over_algorithmic", "TBps_algorithmic_at_median")}
+                      for k, v in out.items() if "what" in v}, indent=1))
+    print(json.dumps({k: summary[k] for k in ("rocprof_kernel_stats", "traffic_over_algorithmic")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
