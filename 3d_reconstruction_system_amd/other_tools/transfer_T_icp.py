@@ -5,7 +5,9 @@ clouds, the second one moved by the 4x4 in T_data.txt.
 The reference file is a module-level script (it runs on import) that only APPLIES a T obtained
 from an external ICP tool.  Here the same work sits in main() behind a __main__ guard, the apply
 runs on the GPU, and `estimate_T()` adds the missing step: it computes T_data.txt on the GPU
-(brute-force NN + cross-covariance + Umeyama) so the external tool is no longer needed.
+(icp.icp_similarity: moments init -> symmetric dead-zone ICP -> plain ICP with exact culled NN, fused
+cross-covariance sums and a device-side Umeyama solve; no initial guess needed, closes the
+monocular-depth vs COLMAP scale gap of readme.md:25,104) so the external tool is no longer needed.
 Run `python transfer_T_icp.py` for the reference behaviour, `python transfer_T_icp.py --estimate`
 to (re)compute T_data.txt from ./point/24.txt -> ./point/0.txt first.
 """
@@ -74,7 +76,8 @@ def main(argv=None):
     path_ply = './ply/icp/024.ply'
     if '--estimate' in argv:
         T, info = estimate_T(path_T=path_T)
-        print('ICP: %d iterations, rms %.6g' % (info["iterations"], info["rms_history"][-1]))
+        print('ICP: %d coarse + %d fine iterations, rms %.6g' % (info["coarse_iterations"], info["iterations"],
+                                                                  info["rms_history"][-1]))
     T = get_T(path_T)
     xcord, ycord, zcord = [], [], []
     with open(path_world, 'w') as file_w:

@@ -132,6 +132,16 @@ int r3d_fuse_frames_rgb(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth
                         double depth_scale, const double* d_pose, const unsigned char* d_rgb, void* d_xyz_out,
                         int out_dtype, uint32_t* d_rgba_out);
 
+/* f4, torch-facing: the BackprojectDepth layer the reference's trainer calls (monodepth2/trainer.py:150-160, 387-390;
+ * upstream monodepth2 layers.py, not vendored by the reference):
+ *     cam_points[b][c][p] = depth[b][p] * (inv_K[b][c][0]*x + inv_K[b][c][1]*y + inv_K[b][c][2]),  c = 0..2;  [b][3][p] = 1
+ * with p = y*W + x, all fp32 like the layer.  d_depth [B][H*W], d_inv_K [B][4][4] row-major, d_cam_points [B][4][H*W].
+ * The _grad entry point is the layer's backward with respect to depth: grad_depth[b][p] = sum_c grad_cam[b][c][p]*ray_c. */
+int r3d_backproject_depth_f32(r3d_ctx* ctx, const float* d_depth, const float* d_inv_K, int batch, int height, int width,
+                              float* d_cam_points);
+int r3d_backproject_depth_grad_f32(r3d_ctx* ctx, const float* d_grad_cam_points, const float* d_inv_K, int batch, int height,
+                                   int width, float* d_grad_depth);
+
 /* ---- a4 on an existing cloud: p_world = Rinv . (p_cam - t), the evaluation order of point_camera()
  * (camera_to_world.py:57-59) and of the fused kernel, so fuse_frames(depth) == se3_apply(unproject(depth))
  * bit for bit.  h_pose is ALWAYS a host pointer: 12 doubles [Rinv row-major (9), t (3)].  In-place allowed. */

@@ -198,3 +198,25 @@ def test_read_xyz_txt_takes_first_three_fields_and_names_bad_lines(R, tmp_path):
     p.write_text("1,2,3\n4,x,6\n")
     with pytest.raises(ValueError, match="line 2"):
         R.cloud_io.read_xyz_txt(str(p))
+
+
+def test_colmap_depth_prep_drop_in(tmp_path):
+    """other_tools/data_transfer.py:5-16 (parity unpinned: OpenCV is absent): 640x480 grey uint8 .npy, nearest-neighbour
+    index rule and Q14 grey weights as restated."""
+    from PIL import Image
+    dt = importlib.import_module(PKG + ".other_tools.data_transfer")
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "a.png")
+    out = dt.get_data(str(tmp_path / "a.png"), str(tmp_path / "a.npy"))
+    saved = np.load(tmp_path / "a.npy")
+    assert saved.shape == (480, 640) and saved.dtype == np.uint8
+    np.testing.assert_array_equal(out, saved)
+    for (y, x) in ((0, 0), (479, 639), (100, 333), (240, 320)):
+        sy, sx = min(int(np.floor(y * 37 / 480)), 36), min(int(np.floor(x * 53 / 640)), 52)
+        r, g, b = (int(v) for v in rgb[sy, sx])
+        assert saved[y, x] == (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14
+    grey = np.full((5, 5, 3), 200, np.uint8)
+    assert (dt.bgr_to_gray(grey) == 200).all()                   # the weights sum to 2^14
+    big = rng.integers(0, 256, (960, 1280, 3), dtype=np.uint8)    # exact 2x downscale picks every other pixel
+    np.testing.assert_array_equal(dt.resize_nearest(big, 640, 480), big[::2, ::2])
