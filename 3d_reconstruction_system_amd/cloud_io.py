@@ -69,6 +69,40 @@ def read_depth_batch(paths, out=None):
     return np.stack(rasters)
 
 
+def read_rgb_batch(paths, out=None):
+    """[F,H,W,3] uint8 (R,G,B) for a list of colour images -- the colour planes of the RGBD path (fuse_frames_rgb).
+    8-bit RGB / RGBA / grey PNGs are decoded by the library's host threads into one contiguous (optionally pinned) buffer;
+    anything else goes through PIL file by file."""
+    paths = [os.fspath(p) for p in paths]
+    if not paths:
+        return np.empty((0, 0, 0, 3), np.uint8)
+    lib = L.load()
+    h, w, ch = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.r3d_png_rgb_info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch))
+    if rc == L.OK:
+        shape = (len(paths), h.value, w.value, 3)
+        if out is None:
+            out = np.empty(shape, np.uint8)
+        elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        rc = lib.r3d_png_rgb_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value)
+        if rc == L.OK:
+            return out
+        if rc != L.ERR_UNSUPPORTED:
+            L.check(rc)
+    elif rc != L.ERR_UNSUPPORTED:
+        if not os.path.exists(paths[0]):
+            raise FileNotFoundError("cannot read image %r" % paths[0])
+        L.check(rc)
+    from PIL import Image
+    imgs = [np.array(Image.open(p).convert("RGB")) for p in paths]
+    for p, r in zip(paths, imgs):
+        if r.shape != imgs[0].shape:
+            raise ValueError("image %s is %s, expected %s" % (p, r.shape, imgs[0].shape))
+    return np.stack(imgs)
+
+
 def read_depth_unchanged(path):
     """IMREAD_UNCHANGED: channels in BGR order like OpenCV (p2c:133 then takes channel 1)."""
     try:

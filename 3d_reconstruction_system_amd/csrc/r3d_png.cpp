@@ -1,4 +1,5 @@
-// f3 ingestion: grey PNG -> raster, on host threads (zlib inflate + PNG unfiltering).
+// f3 ingestion: PNG -> raster, on host threads (zlib inflate + PNG unfiltering): grey depth rasters and, for the RGBD
+// path (config 5; colour attach of pixel_to_camera.py:55-91), 8-bit colour images as R,G,B bytes.
 //
 // Replaces `cv.imread('./depth/'+name, cv.IMREAD_GRAYSCALE)` of camera_to_world.py:160 for the files that path
 // actually reads: non-interlaced greyscale PNGs (colour type 0) of 8 bits (-> uint8, identical to OpenCV) or
@@ -82,53 +83,43 @@ inline int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg);
-
-// decode one grey PNG into out (row-major, H*W samples of bits/8 bytes, host byte order); never throws
-int decode_gray(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
-  try {
-    return decode_gray_impl(path, out, cap_bytes, h_out, w_out, bits_out, msg);
-  } catch (const std::exception& e) {
-    try {
-      *msg = std::string("'") + path + "': " + e.what();
-    } catch (...) {
-    }
-    return R3D_ERR_NOMEM;
-  }
-}
-
-int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
-  PngInfo info;
+// Inflate + unfilter one non-interlaced PNG: `pixels` receives height rows of `stride` bytes (no filter bytes).
+// channels_out = samples per pixel in the file (1 grey, 2 grey+alpha, 3 RGB, 4 RGBA).  Palette / interlace / sub-byte
+// depths -> R3D_ERR_UNSUPPORTED.  header_only: stop after IHDR checks.
+int decode_png(const char* path, bool header_only, PngInfo* info, int* channels_out, std::vector<unsigned char>* pixels,
+               std::string* msg) {
   std::vector<unsigned char> idat;
-  int rc = read_png(path, &info, &idat, msg);
+  int rc = read_png(path, info, &idat, msg);
   if (rc) return rc;
-  if (h_out) *h_out = (int)info.height;
-  if (w_out) *w_out = (int)info.width;
-  if (bits_out) *bits_out = info.bit_depth;
-  if (info.width == 0 || info.height == 0 || info.width > (1u << 20) || info.height > (1u << 20)) {
+  if (info->width == 0 || info->height == 0 || info->width > (1u << 20) || info->height > (1u << 20)) {
     *msg = std::string("'") + path + "': implausible PNG dimensions";
     return R3D_ERR_INVALID;
   }
-  if (info.colour_type != 0 || info.interlace != 0 || (info.bit_depth != 8 && info.bit_depth != 16)) {
-    *msg = std::string("'") + path + "': only non-interlaced 8/16-bit greyscale PNGs are decoded natively";
+  int channels = 0;
+  switch (info->colour_type) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: channels = 0; break;  // 3 = palette
+  }
+  if (channels == 0 || info->interlace != 0 || (info->bit_depth != 8 && info->bit_depth != 16)) {
+    *msg = std::string("'") + path + "': only non-interlaced 8/16-bit grey / RGB(A) PNGs are decoded natively";
     return R3D_ERR_UNSUPPORTED;
   }
-  if (!out) return R3D_OK;  // header query
-  const size_t bpp = info.bit_depth / 8, stride = (size_t)info.width * bpp;
-  const size_t need = stride * info.height;
-  if (cap_bytes < need) {
-    *msg = std::string("'") + path + "': output buffer too small";
-    return R3D_ERR_NOMEM;
-  }
-  std::vector<unsigned char> raw((stride + 1) * info.height);
+  *channels_out = channels;
+  if (header_only) return R3D_OK;
+  const size_t bpp = (size_t)channels * info->bit_depth / 8, stride = (size_t)info->width * bpp;
+  std::vector<unsigned char> raw((stride + 1) * info->height);
   uLongf raw_len = (uLongf)raw.size();
   const int z = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
   if (z != Z_OK || raw_len != raw.size()) {
     *msg = std::string("'") + path + "': zlib inflate failed";
     return R3D_ERR_INVALID;
   }
-  unsigned char* dst = static_cast<unsigned char*>(out);
-  for (uint32_t y = 0; y < info.height; ++y) {
+  pixels->resize(stride * info->height);
+  unsigned char* dst = pixels->data();
+  for (uint32_t y = 0; y < info->height; ++y) {
     const unsigned char* src = &raw[(stride + 1) * y];
     const int filter = src[0];
     unsigned char* row = dst + stride * y;
@@ -150,12 +141,128 @@ int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, 
       row[x] = (unsigned char)v;
     }
   }
-  if (bpp == 2) {  // PNG samples are big-endian
+  return R3D_OK;
+}
+
+// one grey PNG into out (row-major, H*W samples of bits/8 bytes, host byte order); out == NULL: header query
+int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
+  PngInfo info;
+  int channels = 0;
+  std::vector<unsigned char> px;
+  // one pass over the file: the pixels are decoded only when there is somewhere to put them and the file is grey
+  int rc = decode_png(path, out == nullptr, &info, &channels, &px, msg);
+  if (h_out) *h_out = (int)info.height;
+  if (w_out) *w_out = (int)info.width;
+  if (bits_out) *bits_out = info.bit_depth;
+  if (rc) return rc;
+  if (channels != 1) {
+    *msg = std::string("'") + path + "': not a greyscale PNG (the colour -> grey conversion is the caller's to define)";
+    return R3D_ERR_UNSUPPORTED;
+  }
+  if (!out) return R3D_OK;
+  const size_t need = (size_t)info.width * info.height * (info.bit_depth / 8);
+  if (cap_bytes < need) {
+    *msg = std::string("'") + path + "': output buffer too small";
+    return R3D_ERR_NOMEM;
+  }
+  unsigned char* dst = static_cast<unsigned char*>(out);
+  if (info.bit_depth == 8) {
+    memcpy(dst, px.data(), need);
+  } else {  // PNG samples are big-endian
     for (size_t k = 0; k < need; k += 2) {
-      const unsigned char t = dst[k];
-      dst[k] = dst[k + 1];
-      dst[k + 1] = t;
+      dst[k] = px[k + 1];
+      dst[k + 1] = px[k];
     }
+  }
+  return R3D_OK;
+}
+
+int decode_gray(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
+  try {
+    return decode_gray_impl(path, out, cap_bytes, h_out, w_out, bits_out, msg);
+  } catch (const std::exception& e) {
+    try {
+      *msg = std::string("'") + path + "': " + e.what();
+    } catch (...) {
+    }
+    return R3D_ERR_NOMEM;
+  }
+}
+
+// one 8-bit PNG as R,G,B bytes ([H][W][3]); grey is replicated, alpha is dropped; out == NULL: header query
+int decode_rgb(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, int* channels_out, std::string* msg) {
+  try {
+    PngInfo info;
+    int channels = 0;
+    std::vector<unsigned char> px;
+    int rc = decode_png(path, out == nullptr, &info, &channels, &px, msg);
+    if (h_out) *h_out = (int)info.height;
+    if (w_out) *w_out = (int)info.width;
+    if (channels_out) *channels_out = channels;
+    if (rc) return rc;
+    if (info.bit_depth != 8) {
+      *msg = std::string("'") + path + "': 16-bit samples are not a colour image this path reads";
+      return R3D_ERR_UNSUPPORTED;
+    }
+    if (!out) return R3D_OK;
+    const size_t n = (size_t)info.width * info.height;
+    if (cap_bytes < n * 3) {
+      *msg = std::string("'") + path + "': output buffer too small";
+      return R3D_ERR_NOMEM;
+    }
+    const unsigned char* s = px.data();
+    if (channels == 3) {
+      memcpy(out, s, n * 3);
+    } else if (channels == 4) {
+      for (size_t k = 0; k < n; ++k) {
+        out[3 * k] = s[4 * k];
+        out[3 * k + 1] = s[4 * k + 1];
+        out[3 * k + 2] = s[4 * k + 2];
+      }
+    } else {  // grey (+ alpha): replicate
+      for (size_t k = 0; k < n; ++k) out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = s[(size_t)channels * k];
+    }
+    return R3D_OK;
+  } catch (const std::exception& e) {
+    try {
+      *msg = std::string("'") + path + "': " + e.what();
+    } catch (...) {
+    }
+    return R3D_ERR_NOMEM;
+  }
+}
+
+// runs decode_one(k) for k in [0, n) on a thread pool; first failure wins
+template <typename F>
+int run_batch(int n_files, const char* what, F&& decode_one) {
+  unsigned hw = std::thread::hardware_concurrency();
+  const unsigned n_threads = std::max(1u, std::min<unsigned>(hw == 0 ? 1 : hw, std::min(32, n_files)));
+  std::atomic<int> next{0}, first_rc{R3D_OK};
+  std::string first_msg;
+  std::atomic<bool> have_msg{false};
+  auto worker = [&]() {
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= n_files || first_rc.load() != R3D_OK) return;
+      std::string msg;
+      const int rc = decode_one(k, &msg);
+      if (rc != R3D_OK) {
+        int expected = R3D_OK;
+        if (first_rc.compare_exchange_strong(expected, rc)) {
+          first_msg = msg.empty() ? "bad path" : msg;
+          have_msg.store(true);
+        }
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  if (first_rc.load() != R3D_OK) {
+    r3d_set_error("%s", have_msg.load() ? first_msg.c_str() : what);
+    return first_rc.load();
   }
   return R3D_OK;
 }
@@ -181,44 +288,46 @@ int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out
     return R3D_ERR_INVALID;
   }
   const size_t frame_bytes = (size_t)height * width * (bit_depth / 8);
-  unsigned hw = std::thread::hardware_concurrency();
-  const unsigned n_threads = std::max(1u, std::min<unsigned>(hw == 0 ? 1 : hw, std::min(32, n_files)));
-  std::atomic<int> next{0}, first_rc{R3D_OK};
-  std::string first_msg;
-  std::atomic<bool> have_msg{false};
-  auto worker = [&]() {
-    for (;;) {
-      const int k = next.fetch_add(1);
-      if (k >= n_files || first_rc.load() != R3D_OK) return;
-      int h = 0, w = 0, bits = 0;
-      std::string msg;
-      int rc = paths[k] ? decode_gray(paths[k], static_cast<char*>(h_out) + frame_bytes * k, frame_bytes, &h, &w, &bits, &msg)
-                        : R3D_ERR_INVALID;
-      if (rc == R3D_OK && (h != height || w != width || bits != bit_depth)) {
-        rc = R3D_ERR_INVALID;
-        msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + "x" +
-              std::to_string(bits) + " bits, the batch expects " + std::to_string(width) + "x" + std::to_string(height) + "x" +
-              std::to_string(bit_depth);
-      }
-      if (rc != R3D_OK) {
-        int expected = R3D_OK;
-        if (first_rc.compare_exchange_strong(expected, rc)) {
-          first_msg = msg.empty() ? "bad path" : msg;
-          have_msg.store(true);
-        }
-        return;
-      }
+  return run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
+    int h = 0, w = 0, bits = 0;
+    int rc = paths[k] ? decode_gray(paths[k], static_cast<char*>(h_out) + frame_bytes * k, frame_bytes, &h, &w, &bits, msg)
+                      : R3D_ERR_INVALID;
+    if (rc == R3D_OK && (h != height || w != width || bits != bit_depth)) {
+      rc = R3D_ERR_INVALID;
+      *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + "x" + std::to_string(bits) +
+             " bits, the batch expects " + std::to_string(width) + "x" + std::to_string(height) + "x" + std::to_string(bit_depth);
     }
-  };
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto& t : pool) t.join();
-  if (first_rc.load() != R3D_OK) {
-    r3d_set_error("%s", have_msg.load() ? first_msg.c_str() : "PNG decode failed");
-    return first_rc.load();
+    return rc;
+  });
+}
+
+int r3d_png_rgb_info(const char* path, int* height, int* width, int* channels) {
+  if (!path) {
+    r3d_set_error("r3d_png_rgb_info: path is NULL");
+    return R3D_ERR_INVALID;
   }
-  return R3D_OK;
+  std::string msg;
+  const int rc = decode_rgb(path, nullptr, 0, height, width, channels, &msg);
+  if (rc) r3d_set_error("%s", msg.c_str());
+  return rc;
+}
+
+int r3d_png_rgb_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width) {
+  if (n_files < 0 || (n_files > 0 && (!paths || !h_out)) || height <= 0 || width <= 0) {
+    r3d_set_error("r3d_png_rgb_decode_batch: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  const size_t frame_bytes = (size_t)height * width * 3;
+  return run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
+    int h = 0, w = 0, ch = 0;
+    int rc = paths[k] ? decode_rgb(paths[k], h_out + frame_bytes * k, frame_bytes, &h, &w, &ch, msg) : R3D_ERR_INVALID;
+    if (rc == R3D_OK && (h != height || w != width)) {
+      rc = R3D_ERR_INVALID;
+      *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + ", the batch expects " +
+             std::to_string(width) + "x" + std::to_string(height);
+    }
+    return rc;
+  });
 }
 
 }  // extern "C"

@@ -292,6 +292,11 @@ int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const voi
  * contiguous [n][height][width] buffer (pageable or pinned). */
 int r3d_png_gray_info(const char* path, int* height, int* width, int* bit_depth);
 int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out, int height, int width, int bit_depth);
+/* The colour images of the RGBD path (the `Image.open(imgpath)` of genply_noRGB, pixel_to_camera.py:58-60): non-interlaced
+ * 8-bit PNGs -- RGB, RGBA (alpha dropped) or grey (replicated) -- as R,G,B bytes, n files into one [n][height][width][3]
+ * buffer, which is what r3d_fuse_frames_rgb takes.  *channels = samples per pixel in the file. */
+int r3d_png_rgb_info(const char* path, int* height, int* width, int* channels);
+int r3d_png_rgb_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width);
 
 /* ---- f2: occupied-voxel set + OctoMap binary export.  Replaces the per-point tree.updateNode(xyz, True) loop,
  * updateInnerOccupancy() and writeBinary() of octomap/txt_transfer_octomap.py:16-36 and

@@ -220,3 +220,39 @@ def test_colmap_depth_prep_drop_in(tmp_path):
     assert (dt.bgr_to_gray(grey) == 200).all()                   # the weights sum to 2^14
     big = rng.integers(0, 256, (960, 1280, 3), dtype=np.uint8)    # exact 2x downscale picks every other pixel
     np.testing.assert_array_equal(dt.resize_nearest(big, 640, 480), big[::2, ::2])
+
+
+def test_native_rgb_png_batch_matches_pil(R, tmp_path):
+    """f3 for the RGBD path: 8-bit RGB / RGBA / grey PNGs -> [F,H,W,3] R,G,B bytes, byte-identical to PIL's decode;
+    palette and 16-bit files go through the fallback; mismatched sizes are an error."""
+    from PIL import Image
+    rng = np.random.default_rng(12)
+    H, W = 37, 53
+    imgs, paths = [], []
+    for k in range(5):
+        a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        a[k::7] = a[k::7] // 2 * 2          # some smooth rows so every PNG filter type gets used
+        p = tmp_path / ("c%d.png" % k)
+        Image.fromarray(a, "RGB").save(p, compress_level=1 + k)
+        imgs.append(a)
+        paths.append(str(p))
+    got = R.cloud_io.read_rgb_batch(paths)
+    assert got.shape == (5, H, W, 3) and got.dtype == np.uint8
+    np.testing.assert_array_equal(got, np.stack(imgs))
+    rgba = np.dstack([imgs[0], rng.integers(0, 256, (H, W), dtype=np.uint8)])
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "a.png")
+    grey = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    Image.fromarray(grey, "L").save(tmp_path / "g.png")
+    got2 = R.cloud_io.read_rgb_batch([str(tmp_path / "a.png"), str(tmp_path / "g.png")])
+    np.testing.assert_array_equal(got2[0], imgs[0])                   # alpha dropped
+    np.testing.assert_array_equal(got2[1], np.repeat(grey[..., None], 3, axis=2))
+    Image.fromarray(imgs[1], "RGB").convert("P").save(tmp_path / "p.png")   # palette: PIL fallback, still [.,.,3]
+    got3 = R.cloud_io.read_rgb_batch([str(tmp_path / "p.png")])
+    np.testing.assert_array_equal(got3[0], np.array(Image.open(tmp_path / "p.png").convert("RGB")))
+    Image.fromarray(imgs[0][:10], "RGB").save(tmp_path / "small.png")
+    with pytest.raises(Exception):
+        R.cloud_io.read_rgb_batch([paths[0], str(tmp_path / "small.png")])
+    with pytest.raises(FileNotFoundError):
+        R.cloud_io.read_rgb_batch([str(tmp_path / "missing.png")])
+    out = np.empty((5, H, W, 3), np.uint8)
+    assert R.cloud_io.read_rgb_batch(paths, out=out) is out
