@@ -105,6 +105,7 @@ class IcpDevice:
         if tgt.shape[0] < 1:
             raise ValueError("target cloud is empty")
         self.n, self.m = src.shape[0], tgt.shape[0]
+        self._tgt_host = tgt             # the target never moves: target_spacing() samples it without a D2H
         c = self.ctx
         self.d_src = c.alloc(max(src.nbytes, 16)).upload(src)
         self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
@@ -158,13 +159,13 @@ class IcpDevice:
         L.check(c.lib.r3d_icp_accumulate_dev(c.handle, buf.ptr, n, buf.ptr, n, None, None, -1.0, 0.0, self.d_sums.ptr))
         return self._download_sums()
 
-    def target_spacing(self, max_queries=65536):
+    def target_spacing(self, max_queries=32768):
         """Median nearest-neighbour distance between two interleaved halves of the target cloud: its sampling
         resolution, independent of how the clouds are aligned."""
         if self.m < 8:
             return 0.0
         c = self.ctx
-        tgt = self.d_tgt.download(np.float32, self.m * 3).reshape(-1, 3)
+        tgt = self._tgt_host
         base, probe = tgt[1::2], tgt[0::2]
         probe = probe[::max(1, probe.shape[0] // max_queries)]
         d_base = c.alloc(base.nbytes).upload(base)

@@ -145,7 +145,7 @@ def apply_T32(xyz, T):
     return (x @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
 
 
-def target_spacing(tgt, max_queries=65536):
+def target_spacing(tgt, max_queries=32768):
     """Median NN distance between the interleaved halves of the target (its sampling resolution)."""
     tgt = np.asarray(tgt, dtype=np.float32)
     base, probe = tgt[1::2], tgt[0::2]
