@@ -39,6 +39,7 @@ H, W, FRAMES_PER_GPU = 384, 1280, 100
 BYTES_PER_POINT = 13          # 1 B u8 depth read + 12 B f32 xyz written
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 XGMI_LINK_GBS = 153.0         # one xGMI link, per direction (7 links per GPU, full mesh of 8)
+OVERLAP_CHUNKS = 4            # slices of the pipelined 'inputs' assembly
 
 
 def cpu_baseline(sample_frames=1):
@@ -259,7 +260,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (100 = config C2)")
     ap.add_argument("--assemble", default="auto",
-                    choices=["auto", "inputs", "inputs_direct", "outputs", "outputs_direct", "none"],
+                    choices=["auto", "inputs", "inputs_direct", "inputs_overlap", "outputs", "outputs_direct", "none"],
                     help="N>1: how the headline step assembles the fused world cloud on every rank.  Every strategy is "
                          "timed before the headline region and printed under 'assemble'; 'auto' (default) then runs the "
                          "fastest one that leaves the whole cloud on every rank.  'outputs' = fuse own frames, all-gather "
@@ -330,6 +331,21 @@ def main():
         if transport is None:
             transport = D.TorchTransport()
             transport_note += "torch.distributed (%s)" % backend
+    # a second exchange channel on a side stream, for the pipelined strategy (gather chunk c+1 while chunk c is fused)
+    side = side_transport = ctx2 = None
+    if use_dist and a.frames % OVERLAP_CHUNKS == 0:
+        try:
+            side = torch.cuda.Stream(dev)
+            if isinstance(transport, D.R3dTransport):
+                CM = importlib.import_module("3d_reconstruction_system_amd.comm")
+                ctx2 = r3d.Context(dev_index, stream=side.cuda_stream)
+                box = [CM.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                side_transport = D.R3dTransport(CM.Comm(ctx2, box[0], rank, world))
+            else:
+                side_transport = transport        # torch collectives follow torch's current stream
+        except Exception:
+            side = side_transport = None
 
     # synthetic job: rank r owns frames [r*F, (r+1)*F) of a world*F-frame sequence
     F = a.frames
@@ -375,6 +391,31 @@ def main():
                 transport.allgather_rows(shard, points_pr, out=full)
             return step_outputs
 
+        if m == "inputs_overlap":
+            # the 'inputs' strategy as a pipeline: the rasters travel in OVERLAP_CHUNKS slices on a side stream while the
+            # main stream fuses the slices that have landed (one launch per rank's slice, straight into its place in the
+            # rank-major world cloud) -- same bits, step time ~ max(exchange, fuse) instead of their sum
+            C_, fc = OVERLAP_CHUNKS, F // OVERLAP_CHUNKS
+            per = H * W
+            d_chunks = [torch.empty((world * fc, H, W), dtype=torch.uint8, device=dev) for _ in range(C_)]
+            p_chunks = [torch.empty((world * fc, 12), dtype=torch.float64, device=dev) for _ in range(C_)]
+            events = [torch.cuda.Event() for _ in range(C_)]
+
+            def step_overlap():
+                side.wait_stream(stream)                      # inputs are ready / last step's fuses have read the chunks
+                with torch.cuda.stream(side):
+                    for c in range(C_):
+                        side_transport.allgather_rows(depth[c * fc:(c + 1) * fc], [fc] * world, out=d_chunks[c])
+                        side_transport.allgather_rows(table[c * fc:(c + 1) * fc], [fc] * world, out=p_chunks[c])
+                        events[c].record(side)
+                for c in range(C_):
+                    stream.wait_event(events[c])
+                    for r in range(world):
+                        r3d.fuse_frames_device(ctx, cam, d_chunks[c][r * fc:].data_ptr(), np.uint8, fc,
+                                               p_chunks[c][r * fc:].data_ptr(),
+                                               full[(r * F + c * fc) * per:].data_ptr(), out_np)
+            return step_overlap
+
         def step_inputs():
             with_algo(algo)
             transport.allgather_rows(depth, frames_pr, out=depth_all)
@@ -411,6 +452,8 @@ def main():
         modes = ["none", "outputs", "inputs"]
         if isinstance(transport, D.R3dTransport):
             modes += ["outputs_direct", "inputs_direct"]
+        if side_transport is not None:
+            modes.append("inputs_overlap")
         for m in modes:
             try:   # a side measurement must never cost the headline line
                 st = make_step(m)
@@ -424,6 +467,11 @@ def main():
                 sec = max_over_ranks((time.perf_counter() - t1) / 10)
                 fabric_in = 0 if m == "none" else (world - 1) * (n_local * xyz_bytes if m.startswith("outputs")
                                                                  else F * (H * W + 96))
+                if m == "inputs_overlap":    # same bits as 'inputs': checked here once, cheaply, on a strided sample
+                    probe = full[::997].clone()
+                    make_step("inputs")()
+                    if not torch.equal(probe, full[::997]):
+                        raise RuntimeError("pipelined assembly differs from the plain one")
                 entry = {"ms_per_step": round(sec * 1e3, 4), "Mpoints_s": round(world * n_local / sec / 1e6, 1),
                          "fabric_bytes_in_per_gpu": fabric_in}
                 if fabric_in and world > 1:
@@ -479,8 +527,10 @@ def main():
                                 "outputs": "1 fused launch + all-gather of xyz shards (12 B/point over xGMI)",
                                 "inputs": "all-gather of depth+poses (1 B/point over xGMI) + 1 fused launch over "
                                           "all ranks' frames on every rank (replicated compute: each GPU writes the "
-                                          "whole cloud into its own HBM)"}[mode.replace("_direct", "")]
-                               + (" [grouped send/recv per peer]" if mode.endswith("_direct") else ""),
+                                          "whole cloud into its own HBM)"}[mode.replace("_direct", "").replace("_overlap", "")]
+                               + (" [grouped send/recv per peer]" if mode.endswith("_direct") else "")
+                               + (" [pipelined: %d slices gathered on a side stream while the landed ones are fused]"
+                                  % OVERLAP_CHUNKS if mode.endswith("_overlap") else ""),
                        "assemble": mode,
                        "assemble_choice": a.assemble,
                        "parallelism": "frames sharded, %d rank(s), one process per GPU" % world},
@@ -510,6 +560,8 @@ def main():
     if use_dist:
         fence()
         dist.destroy_process_group()
+    if ctx2 is not None:
+        ctx2.close()
     ctx.close()
 
 
