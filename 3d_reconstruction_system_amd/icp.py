@@ -194,17 +194,29 @@ class IcpDevice:
         self._back = {"index": ix, "tgt": d_tgt_b, "moved": c.alloc(self.m * 12), "idx": c.alloc(self.m * 4),
                       "d2": c.alloc(self.m * 4), "sums": c.alloc(18 * 8)}
 
-    def back_sums(self, T_since, dead_zone=0.0):
+    def d2_quantile(self, q):
+        """The q-quantile of the current source -> target squared match distances (after nn() / nn_sums())."""
+        d2 = self.d_d2.download(np.float32, self.n)
+        d2 = d2[np.isfinite(d2)]
+        return float(np.quantile(d2, q)) if d2.size else -1.0
+
+    def back_sums(self, T_since, dead_zone=0.0, trim=None):
         """18 sums over the pairs (p = CURRENT source point nearest to target point q, q): the target is taken
-        into the snapshot's frame by T_since^-1, searched there, and the sums are formed in the world frame."""
+        into the snapshot's frame by T_since^-1, searched there, and the sums are formed in the world frame.
+        trim: keep only the pairs up to that quantile of the match distances (outlier rejection)."""
         c, b = self.ctx, self._back
         T_inv = np.ascontiguousarray(np.linalg.inv(T_since), dtype=np.float64)
         s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
         L.check(c.lib.r3d_apply_T(c.handle, b["tgt"].ptr, L.F32, self.m, T_inv.ctypes.data, b["moved"].ptr, L.F32))
         b["index"].query(b["moved"].ptr, self.m, b["idx"].ptr, b["d2"].ptr, presorted=True)
+        gate = -1.0
+        if trim is not None and trim < 1.0:
+            d2 = b["d2"].download(np.float32, self.m)
+            d2 = d2[np.isfinite(d2)]
+            gate = float(np.quantile(d2, trim)) if d2.size else -1.0
         # roles swapped: "src" = target rows (world frame), "tgt" = current source rows; d2 lives in the snapshot frame
         L.check(c.lib.r3d_icp_accumulate_dev(c.handle, b["tgt"].ptr, self.m, self.d_src.ptr, self.n, b["idx"].ptr,
-                                             b["d2"].ptr, -1.0, float(dead_zone) / s_since if dead_zone > 0 else 0.0,
+                                             b["d2"].ptr, gate, float(dead_zone) / s_since if dead_zone > 0 else 0.0,
                                              b["sums"].ptr))
         return swap_pair_sums(b["sums"].download(np.float64, 18))
 
@@ -293,7 +305,7 @@ def _step_size(T, extent):
 
 
 def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=None, ctx=None, culled=True, init="auto",
-                   check_every=4, dead_zone=None, max_coarse=40, coarse_tol=2e-4):
+                   check_every=4, dead_zone=None, max_coarse=40, coarse_tol=2e-4, trim=None, coarse_trim=None):
     """Similarity (s, R, t) that maps `src` onto `tgt`: the T_data.txt of transfer_T_icp.py:99-108.
     Returns (T 4x4, info dict).  Three stages, all on device-resident clouds:
 
@@ -308,7 +320,13 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
       fine   plain ICP, nearest neighbour -> 18 sums -> Umeyama -> move, until the RMS match distance stops improving
              by more than `tol` (relative).  Runs in blocks of `check_every` iterations enqueued with no host round trip
              (r3d_icp_iterate: fused NN + sums, device-side solve); the host only reads the rms history per block.
-    trim_d2: ignore pairs whose squared distance exceeds it in the fine stage (None = use all)."""
+    trim_d2: ignore pairs whose squared distance exceeds it in the fine stage (None = use all).
+    trim: outlier rejection by rank -- in every step of both stages only the pairs up to that quantile of the current
+          match distances take part (e.g. 0.9 drops the worst 10 %; least squares has no defence against gross outliers,
+          and the coarse stage by construction listens to the FAR pairs).  None = use all.  The coarse stage trims more
+          gently, at coarse_trim (default 1 - (1 - trim)/4): there the far pairs ARE the signal.  Reliable on structured
+          scenes (surfaces); on a featureless uniform volume outliers and extent mismatch look alike and coarse_trim has
+          to match the outlier share."""
     dev = IcpDevice(src, tgt, ctx, culled)
     info = {"init": init if isinstance(init, str) else "matrix", "coarse_iterations": 0, "coarse_history": []}
     T_total = np.eye(4)
@@ -337,8 +355,14 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
             if d0 > 0 and extent > 0:
                 dev.back_begin()
                 T_since = np.eye(4)
+                ct = coarse_trim if coarse_trim is not None else (None if trim is None else 1.0 - (1.0 - trim) / 4.0)
+                info["coarse_trim"] = ct
                 for _ in range(max_coarse):
-                    sums = dev.nn_sums(-1.0, d0) + dev.back_sums(T_since, d0)
+                    if ct is not None and ct < 1.0:
+                        dev.nn()
+                        sums = dev.sums(dev.d2_quantile(ct), d0) + dev.back_sums(T_since, d0, ct)
+                    else:
+                        sums = dev.nn_sums(-1.0, d0) + dev.back_sums(T_since, d0)
                     info["coarse_history"].append(float(sums[0]))
                     if not sums[0] >= 3.0:
                         break                       # every match is inside the dead zone: extents agree
@@ -359,6 +383,11 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
         done, stop_at = 0, None
         while done < max_iter and stop_at is None:
             k = min(max(int(check_every), 1), max_iter - done)
+            if trim is not None and trim < 1.0:          # re-rank once per block
+                dev.nn()
+                max_d2 = dev.d2_quantile(trim)
+                if trim_d2 is not None:
+                    max_d2 = min(max_d2, float(trim_d2))
             dev.iterate(k, with_scale, max_d2)
             done += k
             st = dev.state()

@@ -155,7 +155,7 @@ def target_spacing(tgt, max_queries=32768):
 
 
 def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_zone=None, max_coarse=40,
-                        coarse_tol=2e-4):
+                        coarse_tol=2e-4, trim=None, check_every=4):
     """The build's full estimator restated: moments init -> symmetric dead-zone ICP -> plain ICP
     (3d_reconstruction_system_amd/icp.py: icp_similarity(init="auto")).  Brute-force NN: small clouds only."""
     src = np.asarray(src, dtype=np.float32)
@@ -174,12 +174,14 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
     coarse = 0
     for _ in range(max_coarse):
         ia, da = nearest_neighbours(cur, tgt)
-        sums = pair_sums(cur, tgt, ia, da, -1.0, d0)
+        ga = float(np.quantile(da, trim)) if trim is not None and trim < 1.0 else -1.0
+        sums = pair_sums(cur, tgt, ia, da, ga, d0)
         T_inv = np.linalg.inv(T_since)
         s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
         moved = apply_T32(tgt, T_inv)
         ib, db = nearest_neighbours(moved, snap)
-        sums = sums + swap_pair_sums(pair_sums(tgt, cur, ib, db, -1.0, d0 / s_since))
+        gb = float(np.quantile(db, trim)) if trim is not None and trim < 1.0 else -1.0
+        sums = sums + swap_pair_sums(pair_sums(tgt, cur, ib, db, gb, d0 / s_since))
         if not sums[0] >= 3.0:
             break
         T = umeyama_from_sums(sums, with_scale)
@@ -192,9 +194,12 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
             break
     prev = None
     fine = 0
-    for _ in range(max_iter):
+    gate = -1.0
+    for it in range(max_iter):
         idx, d2 = nearest_neighbours(cur, tgt)
-        sums = pair_sums(cur, tgt, idx)
+        if trim is not None and trim < 1.0 and it % check_every == 0:     # re-ranked once per block, like the GPU loop
+            gate = float(np.quantile(d2, trim))
+        sums = pair_sums(cur, tgt, idx, d2, gate)
         rms = float(np.sqrt(max(sums[16] + sums[17] - 2 * (sums[7] + sums[11] + sums[15]), 0.0) / sums[0]))
         T = umeyama_from_sums(sums, with_scale)
         cur = apply_T32(cur, T)
