@@ -1,0 +1,61 @@
+"""GPU: the driver's contract with bench.py -- one JSON line, the required keys, a self-consistent roofline object --
+checked on the exact command shape the driver uses (short run), and on the N>1 code path rehearsed with one RCCL rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def run_bench(args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_headline_line_is_complete_and_self_consistent():
+    d = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    for k in REQUIRED + ["cpu_baseline"]:
+        assert k in d, k
+    assert d["metric"].startswith("Mpoints/s fused (1280x384 depth") and d["unit"] == "Mpoints/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["algorithmic_bytes_per_launch"] == 100 * 384 * 1280 * 13
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1.0
+    # the sustained kernel time and the K-step wall clock describe the same launch: they agree within a few per cent
+    assert 0.9 <= rf["kernel_ms_over_ms_per_step"] <= 1.06, rf
+    assert abs(d["value"] - 100 * 384 * 1280 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
+    assert 0.5 < rf["frac"] < 1.0
+    assert rf["traffic"] is None or 0.99 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.02
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Mpoints/s" and cb["value"] > 0 and cb["cpu_model"]
+
+
+def test_multi_rank_code_path_rehearsed_with_one_rccl_rank():
+    d = run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], env={"R3D_BENCH_FORCE_COLLECTIVES": "1"})
+    assert "r3d_comm over RCCL" in d["transport"], d["transport"]
+    modes = d["assemble"]
+    for m in ("none", "outputs", "inputs", "outputs_direct", "inputs_direct", "inputs_overlap"):
+        assert m in modes and "ms_per_step" in modes[m], (m, modes.get(m))
+    assert d["config"]["assemble"] in modes and d["config"]["assemble"] != "none"
+    assert d["roofline"]["traffic"] is not None            # the profiled launch is this rank's 100-frame u8 -> f32 launch
+
+
+def test_secondary_workloads_print_a_roofline():
+    for w, bound in (("apply", "hbm"), ("c5", "hbm")):
+        d = run_bench(["--workload", w, "--steps", "200"])
+        assert d["roofline"]["bound"] == bound and 0.3 < d["roofline"]["frac"] < 1.0, d
