@@ -49,6 +49,9 @@ int main(int argc, char** argv) {
   std::vector<unsigned char> rgb(v.size());
   for (auto& c : rgb) c = (unsigned char)rng();
   if (r3d_write_ply_rgb("/tmp/r3d_fuzz_rgb.ply", vf.data(), R3D_F32, rgb.data(), n) != R3D_OK) return 1;
+  std::vector<uint32_t> rgba((size_t)n);
+  for (auto& c : rgba) c = (uint32_t)rng() & 0x00ffffffu;
+  if (r3d_write_ply_rgba("/tmp/r3d_fuzz_rgba.ply", vf.data(), R3D_F32, rgba.data(), n) != R3D_OK) return 1;
   if (r3d_write_ply("/tmp/r3d_fuzz.ply", vf.data(), R3D_F32, n) != R3D_OK) return 1;
   std::vector<uint16_t> zraw((size_t)n);
   for (auto& z : zraw) z = (uint16_t)rng();
@@ -80,6 +83,35 @@ int main(int argc, char** argv) {
       int hh = 0, ww = 0, bb = 0;
       if (r3d_png_gray_info(p[0], &hh, &ww, &bb) == R3D_OK && hh == h && ww == w && bb == bits)
         survived += r3d_png_gray_decode_batch(p, 1, out.data(), h, w, bits) == R3D_OK;
+      // the colour reader on the same hostile bytes (a grey file is a valid input to it: replicated channels)
+      int ch = 0;
+      if (r3d_png_rgb_info(p[0], &hh, &ww, &ch) == R3D_OK && hh == h && ww == w) {
+        std::vector<unsigned char> rgb_out((size_t)h * w * 3);
+        (void)r3d_png_rgb_decode_batch(p, 1, rgb_out.data(), h, w);
+      }
+    }
+    // colour files given as further arguments: valid decode, then corrupted copies
+    for (int a = 2; a < argc; ++a) {
+      int ch = 0, ch2 = 0, h2 = 0, w2 = 0;
+      if (r3d_png_rgb_info(argv[a], &h2, &w2, &ch) != R3D_OK) return 5;
+      std::vector<unsigned char> rgb_out((size_t)h2 * w2 * 3);
+      const char* one2[1] = {argv[a]};
+      if (r3d_png_rgb_decode_batch(one2, 1, rgb_out.data(), h2, w2) != R3D_OK) return 6;
+      FILE* f2 = fopen(argv[a], "rb");
+      std::vector<unsigned char> png2;
+      while ((k = fread(tmp, 1, sizeof(tmp), f2)) > 0) png2.insert(png2.end(), tmp, tmp + k);
+      fclose(f2);
+      for (int trial = 0; trial < 200; ++trial) {
+        std::vector<unsigned char> bad = png2;
+        for (int j = 0; j < 1 + (int)(rng() % 6); ++j) bad[rng() % bad.size()] = (unsigned char)rng();
+        if (trial % 5 == 0) bad.resize(rng() % bad.size());
+        FILE* g = fopen("/tmp/r3d_fuzz_c.png", "wb");
+        fwrite(bad.data(), 1, bad.size(), g);
+        fclose(g);
+        const char* p[1] = {"/tmp/r3d_fuzz_c.png"};
+        int hh = 0, ww = 0;
+        if (r3d_png_rgb_info(p[0], &hh, &ww, &ch2) == R3D_OK && hh == h2 && ww == w2) (void)r3d_png_rgb_decode_batch(p, 1, rgb_out.data(), h2, w2);
+      }
     }
     printf("corrupted PNG trials decoded without error: %d of 400 (no crash either way)\n", survived);
   }

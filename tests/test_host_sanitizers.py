@@ -19,7 +19,13 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path, golden_dir):
     if build.returncode != 0 and "sanitize" in build.stderr:
         pytest.skip("this g++ has no sanitizer runtime")
     assert build.returncode == 0, build.stderr[-3000:]
-    run = subprocess.run([exe, os.path.join(golden_dir, "scene3", "depth", "000.png")], capture_output=True, text=True,
+    from PIL import Image
+    import numpy as np
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 256, (33, 47, 3), dtype=np.uint8), "RGB").save(tmp_path / "c.png")
+    Image.fromarray(rng.integers(0, 256, (33, 47, 4), dtype=np.uint8), "RGBA").save(tmp_path / "a.png")
+    run = subprocess.run([exe, os.path.join(golden_dir, "scene3", "depth", "000.png"), str(tmp_path / "c.png"),
+                          str(tmp_path / "a.png")], capture_output=True, text=True,
                          timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "host fuzz OK" in run.stdout
