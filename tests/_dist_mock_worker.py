@@ -1,0 +1,66 @@
+"""Worker for tests/test_gpu_comm.py: N ranks SHARE the one GPU of the test box; the exchange step goes through the C ABI
+(r3d_comm_* / dist.R3dTransport) bound to tests/c/mock_rccl.cpp via R3D_RCCL_PATH (RCCL itself refuses two ranks on one
+device).  gloo only carries the 128-byte id and the final barrier.  Checks: ragged frame blocks, both assemblies, both
+all-gather algorithms, preallocated in-place slots, the all-reduce -- all against the single-GPU cloud."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+r3d = importlib.import_module("3d_reconstruction_system_amd")
+D = importlib.import_module("3d_reconstruction_system_amd.dist")
+CM = importlib.import_module("3d_reconstruction_system_amd.comm")
+
+
+def main():
+    out_path, n_frames = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0)
+    ctx = r3d.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    box = [CM.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = CM.Comm(ctx, box[0], rank, world)
+    H, W = 48, 64
+    rng = np.random.default_rng(5)
+    depths = rng.integers(0, 256, size=(n_frames, H, W), dtype=np.uint8)
+    quats, ts = rng.normal(size=(n_frames, 4)), rng.normal(size=(n_frames, 3)) * 10
+    table_all = r3d.pose_table(quats, ts)
+    want = r3d.fuse_frames(depths, quats, ts, ctx=ctx)                      # the single-GPU cloud
+    lo, hi = D.shard_range(n_frames, rank, world)
+    counts = D.shard_counts(n_frames, world)
+    dd = torch.from_numpy(depths[lo:hi].copy()).to(dev)
+    pp = torch.from_numpy(table_all[lo:hi].copy()).to(dev)
+    ok = True
+    for algo in (CM.GATHER_AUTO, CM.GATHER_DIRECT):
+        eng = D.ShardedFusion(H, W, r3d.REF_INTRINSICS, out_dtype="float32", transport=D.R3dTransport(comm, algo))
+        a = eng.fuse_and_gather(dd, pp, counts)
+        b = eng.gather_inputs_and_fuse(dd, pp, counts)
+        pre = torch.full((n_frames * H * W, 3), float("nan"), dtype=torch.float32, device=dev)
+        c = eng.fuse_and_gather(dd, pp, counts, out=pre)                  # own block fused straight into its slot
+        torch.cuda.synchronize()
+        for got in (a, b, c):
+            ok = ok and np.array_equal(got.cpu().numpy(), want)
+    if all(x == counts[0] for x in counts):                                  # equal shards: the ncclAllGather algorithm too
+        eng = D.ShardedFusion(H, W, r3d.REF_INTRINSICS, out_dtype="float32", transport=D.R3dTransport(comm, CM.GATHER_NCCL))
+        ok = ok and np.array_equal(eng.fuse_and_gather(dd, pp, counts).cpu().numpy(), want)
+    sums = torch.arange(18, dtype=torch.float64, device=dev) * (rank + 1)
+    comm.allreduce_sum_f64(sums.data_ptr(), 18)
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(sums.cpu().numpy(), np.arange(18) * (world * (world + 1) / 2))
+    with open("%s.rank%d" % (out_path, rank), "w") as f:
+        f.write("ok=%d lo=%d hi=%d origin=%s\n" % (ok, lo, hi, comm.rccl_origin()))
+    dist.barrier()
+    comm.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,7 +34,7 @@ static void make_job(int n_frames, unsigned char* depth, double* pose) {
   }
 }
 
-static int run_rank(int rank, int world, const unsigned char* id, int n_frames) {
+static int run_rank(int rank, int world, const unsigned char* id, int n_frames, int algo, int n_gpus) {
   r3d_ctx* ctx = NULL;
   r3d_camera* cam = NULL;
   r3d_comm* comm = NULL;
@@ -54,7 +54,7 @@ static int run_rank(int rank, int world, const unsigned char* id, int n_frames) 
       hi = h;
     }
   }
-  CHECK(r3d_ctx_create(rank, NULL, 0, &ctx));
+  CHECK(r3d_ctx_create(rank % n_gpus, NULL, 0, &ctx)); /* rank % n_gpus only matters for the shared-GPU rehearsal */
   CHECK(r3d_camera_create(ctx, H, W, 600.391, 600.079, 320, 240, &cam));
   CHECK(r3d_comm_create(ctx, id, rank, world, &comm));
   CHECK(r3d_dev_alloc(ctx, n_all, &d_depth));
@@ -71,13 +71,50 @@ static int run_rank(int rank, int world, const unsigned char* id, int n_frames) 
     char* slot = (char*)d_full + (size_t)lo * H * W * 12;
     CHECK(r3d_fuse_frames(ctx, cam, (char*)d_depth + (size_t)lo * H * W, R3D_DEPTH_U8, hi - lo, 1.0,
                           (const double*)d_pose + (size_t)lo * 12, slot, R3D_F32));
-    CHECK(r3d_allgather_xyz(comm, slot, pts, R3D_F32, d_full, R3D_GATHER_AUTO));
+    CHECK(r3d_allgather_xyz(comm, slot, pts, R3D_F32, d_full, algo));
   }
   CHECK(r3d_memcpy_d2h(ctx, got, d_full, n_all * 12));
   CHECK(r3d_ctx_sync(ctx));
   if (memcmp(got, want, n_all * 12) != 0) {
     fprintf(stderr, "rank %d: gathered cloud differs from the single-GPU cloud\n", rank);
     return 1;
+  }
+  /* the other assembly: all-gather the rasters + pose rows of every rank, then ONE fused launch over all frames */
+  {
+    int64_t fpr[16];
+    void *d_depth_all = NULL, *d_pose_all = NULL;
+    for (r = 0; r < world; ++r) fpr[r] = pts[r] / (H * W);
+    CHECK(r3d_dev_alloc(ctx, n_all, &d_depth_all));
+    CHECK(r3d_dev_alloc(ctx, (size_t)n_frames * 96, &d_pose_all));
+    CHECK(r3d_memset(ctx, d_full, 0xff, n_all * 12));
+    CHECK(r3d_allgather_inputs(comm, (char*)d_depth + (size_t)lo * H * W, R3D_DEPTH_U8, fpr, H, W,
+                               (const double*)d_pose + (size_t)lo * 12, d_depth_all, (double*)d_pose_all, algo));
+    CHECK(r3d_fuse_frames(ctx, cam, d_depth_all, R3D_DEPTH_U8, n_frames, 1.0, (const double*)d_pose_all, d_full, R3D_F32));
+    CHECK(r3d_memcpy_d2h(ctx, got, d_full, n_all * 12));
+    CHECK(r3d_ctx_sync(ctx));
+    if (memcmp(got, want, n_all * 12) != 0) {
+      fprintf(stderr, "rank %d: cloud fused from gathered inputs differs from the single-GPU cloud\n", rank);
+      return 1;
+    }
+    r3d_dev_free(ctx, d_depth_all);
+    r3d_dev_free(ctx, d_pose_all);
+  }
+  /* all-reduce: every rank contributes rank+1 in 18 slots */
+  {
+    double h[18], *d_s = NULL;
+    int k;
+    for (k = 0; k < 18; ++k) h[k] = (rank + 1) * (k + 1);
+    CHECK(r3d_dev_alloc(ctx, sizeof(h), (void**)&d_s));
+    CHECK(r3d_memcpy_h2d(ctx, d_s, h, sizeof(h)));
+    CHECK(r3d_comm_allreduce_sum_f64(comm, d_s, 18));
+    CHECK(r3d_memcpy_d2h(ctx, h, d_s, sizeof(h)));
+    CHECK(r3d_ctx_sync(ctx));
+    for (k = 0; k < 18; ++k)
+      if (h[k] != (k + 1) * (world * (world + 1) / 2)) {
+        fprintf(stderr, "rank %d: all-reduce slot %d = %g\n", rank, k, h[k]);
+        return 1;
+      }
+    r3d_dev_free(ctx, d_s);
   }
   printf("rank %d of %d: frames [%d,%d) fused, %lld points assembled, identical to the single-GPU cloud\n", rank, world, lo, hi,
          (long long)(n_all));
@@ -96,6 +133,8 @@ static int run_rank(int rank, int world, const unsigned char* id, int n_frames) 
 
 int main(int argc, char** argv) {
   int world = argc > 1 ? atoi(argv[1]) : 2, n_frames = argc > 2 ? atoi(argv[2]) : 5;
+  int algo = argc > 3 ? atoi(argv[3]) : R3D_GATHER_AUTO;
+  const int share_gpu = getenv("R3D_SHARE_GPU") != NULL; /* rehearsal with a stand-in transport: ranks share GPU 0 */
   int n_gpus = 0, rank, status = 0, fail = 0;
   int pipes[16][2];
   pid_t pids[16];
@@ -118,7 +157,10 @@ int main(int argc, char** argv) {
     if (read(pc[0], &n_gpus, sizeof(n_gpus)) != sizeof(n_gpus)) n_gpus = 0;
     waitpid(p, &status, 0);
   }
-  if (n_gpus < world) {
+  if (n_gpus >= 1 && share_gpu) {
+    printf("R3D_SHARE_GPU: %d ranks share %d GPU(s) (needs a transport that allows it, e.g. the test's mock)\n", world, n_gpus);
+    fflush(stdout);
+  } else if (n_gpus < world) {
     printf("%d GPU(s) visible, %d ranks wanted: RCCL needs one GPU per rank -- skipped\n", n_gpus, world);
     fflush(stdout);
     return 77;
@@ -140,7 +182,7 @@ int main(int argc, char** argv) {
         _exit(1);
       }
       {
-        int rc = run_rank(rank, world, id, n_frames);
+        int rc = run_rank(rank, world, id, n_frames, algo, n_gpus > 0 ? n_gpus : 1);
         fflush(NULL);
         _exit(rc);
       }

@@ -93,3 +93,45 @@ def test_plain_c_multi_rank_consumer(tmp_path):
     assert one.returncode == 0 and "identical to the single-GPU cloud" in one.stdout, one.stdout + one.stderr
     two = subprocess.run([exe, "2", "5"], capture_output=True, text=True, timeout=300)        # runs only with >= 2 GPUs
     assert two.returncode in (0, 77), two.stdout + two.stderr
+
+
+# ---- N > 1 on the one-GPU box: the C ABI's exchange logic against a stand-in transport ----------------------------------
+@pytest.fixture(scope="module")
+def mock_rccl(tmp_path_factory):
+    """tests/c/mock_rccl.cpp: the ten nccl* symbols r3d_comm.hip binds, moving bytes between processes through /dev/shm."""
+    so = str(tmp_path_factory.mktemp("mock") / "libmockrccl.so")
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "c", "mock_rccl.cpp"),
+                            "-o", so], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    return so
+
+
+@pytest.mark.parametrize("world,n_frames,algo", [(2, 5, 0), (2, 6, 1), (3, 7, 2), (4, 9, 0), (4, 8, 1), (3, 2, 0)])
+def test_plain_c_consumer_multi_rank_over_mock_transport(tmp_path, mock_rccl, world, n_frames, algo):
+    """world ranks share the GPU; ragged blocks (and an EMPTY last block: 3 ranks, 2 frames), both assemblies, the
+    all-reduce; algo 0 auto / 1 ncclAllGather (equal shards) / 2 direct send/recv."""
+    exe = str(tmp_path / "comm_2rank")
+    libdir = os.path.join(ROOT, PKG)
+    build = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c", "comm_2rank.c"), "-o", exe, "-L", libdir, "-lr3d_hip", "-lm",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe, str(world), str(n_frames), str(algo)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, R3D_RCCL_PATH=mock_rccl, R3D_SHARE_GPU="1"))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.count("identical to the single-GPU cloud") == world, run.stdout
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 6), (2, 5), (3, 7)])
+def test_sharded_engine_multi_rank_over_mock_transport(tmp_path, mock_rccl, world, n_frames):
+    out = str(tmp_path / "res")
+    port = 29800 + (os.getpid() + 7 * n_frames + world) % 150
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_mock_worker.py"), out, str(n_frames)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", R3D_RCCL_PATH=mock_rccl))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for rank in range(world):
+        line = open("%s.rank%d" % (out, rank)).read()
+        assert "ok=1" in line and "R3D_RCCL_PATH" in line, line
