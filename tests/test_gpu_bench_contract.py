@@ -59,3 +59,29 @@ def test_secondary_workloads_print_a_roofline():
     for w, bound in (("apply", "hbm"), ("c5", "hbm")):
         d = run_bench(["--workload", w, "--steps", "200"])
         assert d["roofline"]["bound"] == bound and 0.3 < d["roofline"]["frac"] < 1.0, d
+
+
+def test_two_rank_bench_over_the_c_abi_transport(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run), two ranks sharing the one GPU: torch's own
+    process group on gloo, the exchange step through r3d_comm_* bound to the mock transport (tests/c/mock_rccl.cpp).
+    Every assembly strategy must run, agree (the pipelined one checks itself against the plain one) and be reported."""
+    so = str(tmp_path / "libmockrccl.so")
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "c", "mock_rccl.cpp"),
+                            "-o", so], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    port = 29950 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", R3D_DIST_BACKEND="gloo", R3D_BENCH_TRANSPORT="r3d",
+                                R3D_RCCL_PATH=so, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "R3D_RCCL_PATH" in d["transport"], d.get("transport")
+    for m in ("none", "outputs", "inputs", "outputs_direct", "inputs_direct", "inputs_overlap"):
+        assert "ms_per_step" in d["assemble"][m], (m, d["assemble"][m])
+        if m != "none":
+            assert d["assemble"][m]["fabric_bytes_in_per_gpu"] > 0 and "xgmi_GBps_per_link" in d["assemble"][m]
+    assert d["config"]["points_per_step"] == 2 * 8 * 384 * 1280 and d["config"]["assemble"] != "none"
