@@ -316,7 +316,8 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
              source matches together, each weighted w = max(0, 1 - dead_zone/d).  Matches closer than the target's
              sampling resolution (dead_zone, default 2 x target_spacing()) carry no weight, so the extents of the two
              clouds decide -- plain ICP stalls on a densely, evenly sampled volume, and one-directional ICP with a free
-             scale can always shrink the source into the target.  Host solve per step (a handful of steps).
+             scale can always shrink the source into the target.  Host solve per step (a handful of steps).  Needs the
+             culled index (culled=True); with the brute-force search "auto" degrades to "moments".
       fine   plain ICP, nearest neighbour -> 18 sums -> Umeyama -> move, until the RMS match distance stops improving
              by more than `tol` (relative).  Runs in blocks of `check_every` iterations enqueued with no host round trip
              (r3d_icp_iterate: fused NN + sums, device-side solve); the host only reads the rms history per block.
