@@ -5,6 +5,7 @@ BASELINE.json's full size.  Tolerance (north_star <= 1e-4 relative
               (the kernel rounds the fp64 result once, so the observed error is ~6e-8);
   f64 output: |d| <= 1e-12*(1+||ref||)  (summation order only).
 """
+import importlib
 import json
 import os
 
@@ -386,5 +387,55 @@ def test_config5_geometry_1080p_f32_rgbd(R, ctx):
     for f in (0, 17, 49):   # oracle on three whole frames
         want = O.fuse_frames(depth[f:f + 1], q[f:f + 1], t[f:f + 1], *intr)
         check(xyz[f * per:(f + 1) * per], want, np.float32)
+    for b in (d_depth, d_rgb, d_pose, d_xyz, d_rgba, d_xyz2, d_rgba2):
+        b.free()
+
+
+def test_config5_per_gpu_share_250_frames_single_launch(R, ctx):
+    """BASELINE config 5 per GPU at 8 GPUs: 250 frames of 1920x1080 f32 depth + RGB = 518.4 M points in ONE launch
+    (6.2 GB of xyz, 2.1 GB of rgba; 506,250 tiles).  The rasters are 10 distinct host frames replicated on the device; the
+    250 poses are all different.  Checks: one launch == 25 launches of 10 frames, bit for bit (xyz and colour); three frames
+    against the oracle; 64-bit addressing past 4 G bytes."""
+    F, H, W, U = 250, 1080, 1920, 10
+    rng = np.random.default_rng(55)
+    depth = (rng.random((U, H, W), dtype=np.float32) * 99.5 + 0.5)
+    rgb = rng.integers(0, 256, size=(U, H, W, 3), dtype=np.uint8)
+    q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10
+    intr = (960.0, 960.0, 959.5, 539.5)
+    cam = ctx.camera(H, W, *intr)
+    per = H * W
+    n = F * per
+    table = R.pose_table(q, t)
+    lib = R.load_library()
+    d_depth, d_rgb, d_pose = ctx.alloc(n * 4), ctx.alloc(n * 3), ctx.alloc(table.nbytes).upload(table)
+    d_depth.upload(depth)
+    d_rgb.upload(rgb)
+    for k in range(1, F // U):      # replicate the 10 frames 25 times in HBM
+        lib.r3d_memcpy_d2d(ctx.handle, d_depth.ptr + k * U * per * 4, d_depth.ptr, U * per * 4)
+        lib.r3d_memcpy_d2d(ctx.handle, d_rgb.ptr + k * U * per * 3, d_rgb.ptr, U * per * 3)
+    d_xyz, d_rgba = ctx.alloc(n * 12), ctx.alloc(n * 4)
+    R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, np.float32, d_rgba.ptr)
+    d_xyz2, d_rgba2 = ctx.alloc(U * per * 12), ctx.alloc(U * per * 4)
+    L_ = importlib.import_module(R.__name__ + "._lib")
+    want_rgba = (rgb.reshape(-1, 3).astype(np.uint32) * np.array([1, 256, 65536], dtype=np.uint32)).sum(1, dtype=np.uint32)
+    for k in range(F // U):
+        R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr + k * U * per * 4, np.float32, U, d_pose.ptr + k * U * 96,
+                                 d_rgb.ptr + k * U * per * 3, d_xyz2.ptr, np.float32, d_rgba2.ptr)
+        part = d_xyz2.download(np.float32, U * per * 3)
+        whole = np.empty(U * per * 3, np.float32)
+        L_.check(lib.r3d_memcpy_d2h(ctx.handle, whole.ctypes.data, d_xyz.ptr + k * U * per * 12, whole.nbytes))
+        ctx.sync()
+        assert np.array_equal(part, whole), k
+        if k in (0, 24):
+            col = np.empty(U * per, np.uint32)
+            L_.check(lib.r3d_memcpy_d2h(ctx.handle, col.ctypes.data, d_rgba.ptr + k * U * per * 4, col.nbytes))
+            ctx.sync()
+            assert np.array_equal(col, want_rgba)
+    for f in (0, 137, 249):
+        one = np.empty(per * 3, np.float32)
+        L_.check(lib.r3d_memcpy_d2h(ctx.handle, one.ctypes.data, d_xyz.ptr + f * per * 12, one.nbytes))
+        ctx.sync()
+        want = O.fuse_frames(depth[f % U:f % U + 1], q[f:f + 1], t[f:f + 1], *intr)
+        check(one.reshape(-1, 3), want, np.float32)
     for b in (d_depth, d_rgb, d_pose, d_xyz, d_rgba, d_xyz2, d_rgba2):
         b.free()
