@@ -105,6 +105,8 @@ SIGNATURES = {
     "r3d_voxelset_clear": (_i, [_vp]),
     "r3d_voxelset_insert": (_i, [_vp, _vp, _i64]),
     "r3d_voxelset_insert_host": (_i, [_vp, _vp, _i64]),
+    "r3d_voxelset_insert_codes": (_i, [_vp, _vp, _i64]),
+    "r3d_voxelset_union": (_i, [_vp, _vp]),
     "r3d_voxelset_stats": (_i, [_vp, _vp, _vp, _vp]),
     "r3d_voxelset_codes": (_i, [_vp, _vp, _i64, _vp]),
     "r3d_sort_u64": (_i, [_vp, _vp, _i64, _i]),

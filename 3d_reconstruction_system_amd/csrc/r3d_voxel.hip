@@ -157,6 +157,55 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
   }
 }
 
+// Insert ready-made 48-bit Morton codes (another rank's occupied voxels: the union step of a sharded map).
+__global__ __launch_bounds__(kThreads) void voxel_insert_codes_kernel(const uint64_t* __restrict__ codes, int64_t n,
+                                                                      uint64_t* __restrict__ table, int log2cap,
+                                                                      unsigned long long* __restrict__ counters) {
+  const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
+  const int lane = threadIdx.x & 63;
+  unsigned n_new = 0, n_ignored = 0, n_over = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n + lane; i += (int64_t)gridDim.x * kThreads) {
+    // (the loop bound keeps whole waves together for the shuffle below)
+    uint64_t code = i < n ? codes[i] : kEmpty;
+    bool live = i < n;
+    if (live && (code >> 48) != 0) {  // not a depth-16 octree key
+      ++n_ignored;
+      live = false;
+      code = kEmpty;
+    }
+    const uint64_t prev = __shfl_up(code, 1, 64);
+    if (live && lane > 0 && prev == code) live = false;  // sorted inputs repeat a code in neighbouring lanes
+    if (live) {
+      uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+      bool done = false;
+      for (uint64_t probe = 0; probe <= mask && !done; ++probe) {
+        const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
+                                       (unsigned long long)code);
+        if (old == kEmpty) {
+          ++n_new;
+          done = true;
+        } else if (old == code) {
+          done = true;
+        } else {
+          slot = (slot + 1) & mask;
+        }
+      }
+      if (!done) ++n_over;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_ignored += __shfl_down(n_ignored, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  if (lane == 0) {
+    if (n_new) atomicAdd(&counters[0], (unsigned long long)n_new);
+    if (n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);
+    if (n_over) atomicAdd(&counters[2], (unsigned long long)n_over);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void voxel_compact_kernel(const uint64_t* __restrict__ table, uint64_t capacity,
                                                                  uint64_t* __restrict__ out,
                                                                  unsigned long long* __restrict__ counters) {
@@ -429,18 +478,32 @@ int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, 
   return R3D_OK;
 }
 
-int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, int64_t* n_out) {
-  R3D_REQUIRE(vs != nullptr && n_out != nullptr, "NULL argument");
+int r3d_voxelset_insert_codes(r3d_voxelset* vs, const uint64_t* d_codes, int64_t n_codes) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  int rc = r3d_ctx_enter(vs->ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_codes >= 0, "n_codes must be >= 0");
+  if (n_codes == 0) return R3D_OK;
+  R3D_REQUIRE(d_codes != nullptr, "NULL device pointer");
+  int64_t blocks = (n_codes + kThreads - 1) / kThreads;
+  if (blocks > (int64_t)vs->ctx->num_cus * 16) blocks = (int64_t)vs->ctx->num_cus * 16;
+  hipLaunchKernelGGL(voxel_insert_codes_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, vs->ctx->stream, d_codes, n_codes,
+                     vs->d_table, vs->log2cap, vs->d_counters);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+// distinct codes of the set as a sorted list in HBM (scratch slot 1); *n_out = how many
+static int codes_to_device_list(r3d_voxelset* vs, uint64_t** d_list_out, int64_t* n_out) {
   int64_t n = 0, ign = 0, over = 0;
   int rc = r3d_voxelset_stats(vs, &n, &ign, &over);
   if (rc) return rc;
   *n_out = n;
+  *d_list_out = nullptr;
   if (over > 0) {
     r3d_set_error("voxel set overflowed (%lld points found no slot): create it with a larger capacity", (long long)over);
     return R3D_ERR_NOMEM;
   }
-  if (!h_codes_sorted) return R3D_OK;
-  R3D_REQUIRE(cap >= n, "buffer holds %lld codes, set has %lld", (long long)cap, (long long)n);
   if (n == 0) return R3D_OK;
   void *d_list = nullptr, *d_tmp = nullptr;
   if ((rc = r3d_scratch(vs->ctx, 1, (size_t)n * sizeof(uint64_t), &d_list))) return rc;
@@ -452,8 +515,65 @@ int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, 
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, vs->d_table, vs->capacity,
                      static_cast<uint64_t*>(d_list), vs->d_counters);
   R3D_HIP(hipGetLastError());
-  // octree order = ascending Morton code: 48 significant bits, six 8-bit passes on the GPU
   if ((rc = r3d_radix_sort_u64(vs->ctx, static_cast<uint64_t*>(d_list), static_cast<uint64_t*>(d_tmp), n, 48))) return rc;
+  *d_list_out = static_cast<uint64_t*>(d_list);
+  return R3D_OK;
+}
+
+// Config 5 (frames sharded, ONE map): every rank voxelises its own shard of the world cloud into its own HBM hash set --
+// 12 B/point never leave the GPU -- then the ranks exchange only their DISTINCT codes (8 B/voxel, unequal shards) and
+// each folds the others' into its set.  Afterwards every rank holds the union.
+int r3d_voxelset_union(r3d_voxelset* vs, r3d_comm* comm) {
+  R3D_REQUIRE(vs != nullptr && comm != nullptr, "NULL argument");
+  int rank = 0, world = 1;
+  int rc = r3d_comm_info(comm, &rank, &world, nullptr);
+  if (rc) return rc;
+  uint64_t* d_mine = nullptr;
+  int64_t n_mine = 0;
+  if ((rc = codes_to_device_list(vs, &d_mine, &n_mine))) return rc;
+  if (world == 1) return R3D_OK;
+  // how many codes every rank brings: an all-gather of one int64 each
+  void* d_cnt = nullptr;
+  if ((rc = r3d_scratch(vs->ctx, 3, (size_t)(world + 1) * sizeof(int64_t), &d_cnt))) return rc;
+  int64_t* d_counts = static_cast<int64_t*>(d_cnt);
+  R3D_HIP(hipMemcpyAsync(d_counts + world, &n_mine, sizeof(int64_t), hipMemcpyHostToDevice, vs->ctx->stream));
+  std::vector<int64_t> eight((size_t)world, (int64_t)sizeof(int64_t)), counts((size_t)world), bytes((size_t)world);
+  if ((rc = r3d_comm_allgather(comm, d_counts + world, eight.data(), d_counts, R3D_GATHER_AUTO))) return rc;
+  R3D_HIP(hipMemcpyAsync(counts.data(), d_counts, (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, vs->ctx->stream));
+  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
+  int64_t total = 0;
+  for (int r = 0; r < world; ++r) {
+    R3D_REQUIRE(counts[r] >= 0, "rank %d reports a negative code count", r);
+    bytes[r] = counts[r] * (int64_t)sizeof(uint64_t);
+    total += counts[r];
+  }
+  if (total == 0) return R3D_OK;
+  void* d_all = nullptr;
+  if ((rc = r3d_scratch(vs->ctx, 0, (size_t)total * sizeof(uint64_t), &d_all))) return rc;
+  if ((rc = r3d_comm_allgather(comm, d_mine, bytes.data(), d_all, R3D_GATHER_AUTO))) return rc;
+  return r3d_voxelset_insert_codes(vs, static_cast<const uint64_t*>(d_all), total);
+}
+
+int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, int64_t* n_out) {
+  R3D_REQUIRE(vs != nullptr && n_out != nullptr, "NULL argument");
+  if (!h_codes_sorted) {   // count only
+    int64_t n = 0, ign = 0, over = 0;
+    int rc = r3d_voxelset_stats(vs, &n, &ign, &over);
+    if (rc) return rc;
+    *n_out = n;
+    if (over > 0) {
+      r3d_set_error("voxel set overflowed (%lld points found no slot): create it with a larger capacity", (long long)over);
+      return R3D_ERR_NOMEM;
+    }
+    return R3D_OK;
+  }
+  uint64_t* d_list = nullptr;
+  int64_t n = 0;
+  int rc = codes_to_device_list(vs, &d_list, &n);
+  *n_out = n;
+  if (rc) return rc;
+  R3D_REQUIRE(cap >= n, "buffer holds %lld codes, set has %lld", (long long)cap, (long long)n);
+  if (n == 0) return R3D_OK;
   R3D_HIP(hipMemcpyAsync(h_codes_sorted, d_list, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, vs->ctx->stream));
   R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
   return R3D_OK;

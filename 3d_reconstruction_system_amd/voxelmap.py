@@ -62,6 +62,14 @@ class VoxelSet:
     def insert_device(self, d_xyz, n_points):
         L.check(self.ctx.lib.r3d_voxelset_insert(self.handle, d_xyz, int(n_points)))
 
+    def insert_codes_device(self, d_codes, n_codes):
+        L.check(self.ctx.lib.r3d_voxelset_insert_codes(self.handle, d_codes, int(n_codes)))
+
+    def union_across(self, comm):
+        """Collective over a comm.Comm: afterwards this set holds the occupied voxels of EVERY rank's set (config 5: frames
+        sharded, one map).  Only distinct codes cross the fabric, through the C ABI's all-gather of unequal shards."""
+        L.check(self.ctx.lib.r3d_voxelset_union(self.handle, comm.handle))
+
     def stats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(self.ctx.lib.r3d_voxelset_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))

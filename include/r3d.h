@@ -305,6 +305,7 @@ int r3d_png_rgb_decode_batch(const char* const* paths, int n_files, unsigned cha
  * The set lives in HBM as an open-addressing hash table of 48-bit Morton codes; `capacity` = slots
  * (rounded up to a power of two; >= 2x the expected number of distinct voxels keeps probing short). */
 typedef struct r3d_voxelset r3d_voxelset;
+struct r3d_comm; /* multi-GPU communicator, declared below */
 int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_voxelset** vs_out);
 int r3d_voxelset_destroy(r3d_voxelset* vs);
 int r3d_voxelset_clear(r3d_voxelset* vs);
@@ -317,6 +318,12 @@ int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, 
 /* distinct voxels as ascending 48-bit Morton codes (3 bits per level, x lowest: OctoMap's child index order).
  * h_codes_sorted == NULL only reports the count. */
 int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, int64_t* n_out);
+/* Insert ready-made 48-bit Morton codes (e.g. another rank's distinct voxels); codes with bits above 48 count as ignored. */
+int r3d_voxelset_insert_codes(r3d_voxelset* vs, const uint64_t* d_codes, int64_t n_codes);
+/* Config 5 (frames sharded over the GPUs, ONE map): collective over `comm`.  Every rank has voxelised its own shard of the
+ * world cloud into its own set; the ranks all-gather only their DISTINCT codes (8 B/voxel, unequal shards -- the 12 B/point
+ * of the clouds never leave their GPU) and fold them in.  Afterwards every rank's set is the union.  Synchronises. */
+int r3d_voxelset_union(r3d_voxelset* vs, struct r3d_comm* comm);
 /* In-place ascending sort of 64-bit keys in HBM by their low key_bits bits (stable LSD radix sort, 8-bit digits;
  * asynchronous on the ctx stream).  Building block of r3d_voxelset_codes, exported for tests and reuse. */
 int r3d_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, int64_t n_keys, int key_bits);

@@ -50,6 +50,19 @@ def main():
     if all(x == counts[0] for x in counts):                                  # equal shards: the ncclAllGather algorithm too
         eng = D.ShardedFusion(H, W, r3d.REF_INTRINSICS, out_dtype="float32", transport=D.R3dTransport(comm, CM.GATHER_NCCL))
         ok = ok and np.array_equal(eng.fuse_and_gather(dd, pp, counts).cpu().numpy(), want)
+    # config 5: every rank voxelises ITS shard of the world cloud, then the sets are united through the C ABI
+    V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
+    per = H * W
+    mine = want[lo * per:hi * per]
+    vs = V.VoxelSet(0.5, 1 << 18, ctx)
+    if hi > lo:
+        vs.insert(mine)
+    vs.union_across(comm)
+    whole = V.VoxelSet(0.5, 1 << 18, ctx)
+    whole.insert(want)
+    ok = ok and np.array_equal(vs.codes(), whole.codes()) and vs.stats()["overflow"] == 0
+    vs.close()
+    whole.close()
     sums = torch.arange(18, dtype=torch.float64, device=dev) * (rank + 1)
     comm.allreduce_sum_f64(sums.data_ptr(), 18)
     torch.cuda.synchronize()

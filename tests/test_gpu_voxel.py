@@ -145,3 +145,31 @@ def test_radix_sort_u64(ctx, n, bits):
     got = buf.download(np.uint64, n)
     np.testing.assert_array_equal(got, np.sort(keys))
     buf.free()
+
+
+def test_insert_codes_and_single_rank_union(R, V, ctx):
+    """Codes of one set folded into another == the set built from both clouds; codes beyond 48 bits are ignored; a world
+    of one rank leaves the set as it is."""
+    import importlib
+    CM = importlib.import_module(R.__name__ + ".comm")
+    rng = np.random.default_rng(2)
+    a = (rng.normal(size=(40000, 3)) * 3).astype(np.float32)
+    b = (rng.normal(size=(30000, 3)) * 3 + 2).astype(np.float32)
+    va, vb, vab = V.VoxelSet(0.1, 1 << 18, ctx), V.VoxelSet(0.1, 1 << 18, ctx), V.VoxelSet(0.1, 1 << 18, ctx)
+    va.insert(a)
+    vb.insert(b)
+    vab.insert(np.concatenate([a, b]))
+    cb = vb.codes()
+    bad = np.array([1 << 50, (1 << 48) | 5], dtype=np.uint64)
+    both = np.concatenate([cb, cb[:100], bad])                      # repeats and two non-keys
+    d = ctx.alloc(both.nbytes).upload(both)
+    va.insert_codes_device(d.ptr, both.shape[0])
+    np.testing.assert_array_equal(va.codes(), vab.codes())
+    assert va.stats()["ignored_points"] == 2
+    comm = CM.Comm(ctx, CM.Comm.unique_id(), 0, 1)
+    va.union_across(comm)
+    np.testing.assert_array_equal(va.codes(), vab.codes())
+    comm.close()
+    d.free()
+    for v in (va, vb, vab):
+        v.close()
