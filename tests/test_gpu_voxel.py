@@ -147,11 +147,10 @@ def test_radix_sort_u64(ctx, n, bits):
     buf.free()
 
 
-def test_insert_codes_and_single_rank_union(R, V, ctx):
+def test_insert_codes_and_single_rank_union(V, ctx):
     """Codes of one set folded into another == the set built from both clouds; codes beyond 48 bits are ignored; a world
     of one rank leaves the set as it is."""
-    import importlib
-    CM = importlib.import_module(R.__name__ + ".comm")
+    CM = importlib.import_module(PKG + ".comm")
     rng = np.random.default_rng(2)
     a = (rng.normal(size=(40000, 3)) * 3).astype(np.float32)
     b = (rng.normal(size=(30000, 3)) * 3 + 2).astype(np.float32)
