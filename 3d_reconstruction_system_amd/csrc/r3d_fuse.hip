@@ -19,8 +19,7 @@
 //     instruction must write one contiguous run of bytes, 12 B per lane at a 12-B lane stride, nontemporal
 //     (`global_store_dwordx3 ... nt` = 768 contiguous bytes per wave instruction; partial lines must not allocate in L2).
 //       - f32 xyz  (fuse_lane_kernel): lane `tid` takes pixels tid, tid+256, tid+512, tid+768 of the tile; one x3 store
-//         per pixel.  6.6-6.8 TB/s = 0.83-0.85 of the 8 TB/s peak (C2, byte raster).  Grid: 8 workgroups per CU
-//         striding over tiles for byte rasters, one tile per workgroup otherwise.
+//         per pixel.  7.0 TB/s = 0.87 of the 8 TB/s peak (C2, byte raster).  Grid: one tile per workgroup.
 //       - f64 xyz  (fuse_pair_kernel): a 24-B row cannot leave in one instruction, and every split of it by instruction
 //         (x4+x2, 3 x x2) leaves gaps inside each wave instruction (2.7 TB/s).  So TWO LANES share a pixel: the even lane
 //         computes world x,y and stores (x_lo x_hi y_lo), the odd lane computes y,z and stores (y_hi z_lo z_hi) -- again
@@ -110,8 +109,9 @@ __device__ __forceinline__ void store_x3_nt(void* dst, u32x3 v) {
 // CLAMP: UNCONDITIONAL loads from a clamped index.  With a predicated load (`p < hw ? depth[p] : 0`) of a u16 / f32
 // element the compiler sinks each element's conversion into the load's own branch and puts an s_waitcnt vmcnt(0)
 // behind every load -- four serialised memory round trips per tile, invisible while the raster sits in the Infinity
-// Cache, a 1.3-1.5x loss when it really comes from HBM (1080p batches; profiles/r02_c5_probe.log).  Byte rasters keep
-// the predicated form: their loads were batched anyway and the clamped form schedules worse for them (measured).
+// Cache, a 1.3-1.5x loss when it really comes from HBM (1080p batches; profiles/r02_c5_probe.log).  For byte rasters the
+// loads were batched either way; measured per kernel: the f32-xyz kernel is 4 % faster clamped at one tile per workgroup
+// (7.0 vs 6.7 TB/s on C2), the lane-pair f64 kernel is faster predicated (6.6 vs 5.5), so each takes its own form.
 template <typename DT, int ITEMS, int SHIFT, bool CLAMP>
 __device__ __forceinline__ void load_tile(const DT* __restrict__ depth, const FuseDims& dm, uint32_t tile, uint32_t tid,
                                           DT raw[ITEMS]) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restric
     load_pose<POSE>(pose, frame, P);
     const uint64_t fbase = (uint64_t)frame * dm.hw;
     DT raw[kPx];
-    load_tile<DT, kPx, 0, (sizeof(DT) > 1)>(depth, dm, tile, tid, raw);
+    load_tile<DT, kPx, 0, true>(depth, dm, tile, tid, raw);
 #pragma unroll
     for (int r = 0; r < kPx; ++r) {
       const uint32_t p = tf * kTile + r * kThreads + tid;
@@ -374,10 +374,8 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   dm.rgb_vec_ok = d_rgb && ((uintptr_t)d_rgb % 16 == 0) && (hw % 16 == 0);
   const bool colour_after = d_rgb && out_dtype == R3D_F64;  // f64 xyz: colour goes through its own pass
   if (colour_after) p.rgb = nullptr;
-  // measured (profiles/r02_c5_probe.log): one tile per workgroup everywhere except the byte-raster f32 kernel, whose
-  // store stream likes 8 resident workgroups per CU striding over tiles
-  const bool stride8 = out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
-  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : stride8 ? (uint64_t)ctx->num_cus * 8 : total_tiles;
+  // measured (profiles/r02_c5_probe.log, r02_ab_kernels.log): one tile per workgroup for every kernel
+  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : total_tiles;
   if (blocks > total_tiles) blocks = total_tiles;
   if (with_pose)
     launch_depth<true>(p, dm, depth_dtype, out_dtype, (int)blocks, ctx->stream);
