@@ -65,6 +65,38 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
+// ---- fuse -> f32 (the headline kernel) with PX pixels per lane, one tile per workgroup, clamped loads
+template <int PX>
+__global__ __launch_bounds__(kThreads) void fuse32_lane(const uint8_t* __restrict__ depth, float* __restrict__ out,
+                                                        const double* __restrict__ u, const double* __restrict__ v,
+                                                        const double* __restrict__ pose, const Dims dm, uint32_t tiles_per_frame,
+                                                        uint32_t total_tiles) {
+  constexpr uint32_t tile_px = kThreads * PX;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const uint32_t frame = tile / tiles_per_frame;
+    const uint32_t tf = tile - frame * tiles_per_frame;
+    Pose P;
+    load_pose(pose, frame, P);
+    const uint64_t fbase = (uint64_t)frame * dm.hw;
+    uint8_t raw[PX];
+#pragma unroll
+    for (int r = 0; r < PX; ++r) raw[r] = depth[fbase + min(tf * tile_px + r * kThreads + tid, dm.hw - 1)];
+#pragma unroll
+    for (int r = 0; r < PX; ++r) {
+      const uint32_t p = tf * tile_px + r * kThreads + tid;
+      if (p < dm.hw) {
+        const uint32_t j = p / dm.width, i = p - j * dm.width;
+        double w[3];
+        point((double)raw[r], u[i], v[j], P, w);
+        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + (fbase + p) * 3),
+                     "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]})
+                     : "memory");
+      }
+    }
+  }
+}
+
 // ---- fuse -> f64, candidate B: lane-per-pixel, one 16-byte + one 8-byte nontemporal store per lane (24-B lane stride)
 template <int MODE>  // 0: x4 nt + x2 nt, 1: three x2 nt, 2: x4 + x2 plain
 __global__ __launch_bounds__(kThreads) void fuse64_lane(const uint8_t* __restrict__ depth, double* __restrict__ out,
@@ -461,6 +493,34 @@ int main(int argc, char** argv) {
     printf("  %-34s %s\n", what, ok ? "bit-identical" : "MISMATCH");
     return ok;
   };
+
+  // ---------------- fuse -> f32: pixels per lane at one tile per workgroup
+  printf("== fuse u8 -> f32 xyz (headline), 13 B/point = %.1f MB\n", n * 13 / 1e6);
+  RK(r3d_fuse_frames(ctx, cam, d_depth, R3D_DEPTH_U8, F, 1.0, d_pose, d_ref32, R3D_F32));
+  CK(hipStreamSynchronize(st));
+  {
+    struct Cand32 { const char* name; std::function<void()> fn; };
+    auto tp = [&](int px) { return (uint32_t)((hw + 256 * px - 1) / (256 * px)); };
+    std::vector<Cand32> c32 = {
+        {"library", [&] { RK(r3d_fuse_frames(ctx, cam, d_depth, R3D_DEPTH_U8, F, 1.0, d_pose, d_out32, R3D_F32)); }},
+        {"1 px/lane, 1 tile/WG", [&] { hipLaunchKernelGGL(fuse32_lane<1>, dim3(tp(1) * F), dim3(kThreads), 0, st, d_depth, d_out32, d_u, d_v, d_pose, dm, tp(1), tp(1) * F); }},
+        {"2 px/lane, 1 tile/WG", [&] { hipLaunchKernelGGL(fuse32_lane<2>, dim3(tp(2) * F), dim3(kThreads), 0, st, d_depth, d_out32, d_u, d_v, d_pose, dm, tp(2), tp(2) * F); }},
+        {"4 px/lane, 1 tile/WG", [&] { hipLaunchKernelGGL(fuse32_lane<4>, dim3(tp(4) * F), dim3(kThreads), 0, st, d_depth, d_out32, d_u, d_v, d_pose, dm, tp(4), tp(4) * F); }},
+        {"8 px/lane, 1 tile/WG", [&] { hipLaunchKernelGGL(fuse32_lane<8>, dim3(tp(8) * F), dim3(kThreads), 0, st, d_depth, d_out32, d_u, d_v, d_pose, dm, tp(8), tp(8) * F); }},
+        {"16 px/lane, 1 tile/WG", [&] { hipLaunchKernelGGL(fuse32_lane<16>, dim3(tp(16) * F), dim3(kThreads), 0, st, d_depth, d_out32, d_u, d_v, d_pose, dm, tp(16), tp(16) * F); }},
+    };
+    for (auto& c : c32) {
+      CK(hipMemsetAsync(d_out32, 0xff, n * 12, st));
+      c.fn();
+      CK(hipStreamSynchronize(st));
+      same(d_out32, d_ref32, n * 12, c.name);
+    }
+    for (int round = 0; round < 3; ++round)
+      for (auto& c : c32) {
+        const float ms = time_ms(st, c.fn, 400);
+        printf("  round %d  %-32s %.4f ms  %.2f TB/s  (%.3f of 8)\n", round, c.name, ms, n * 13 / ms / 1e9, n * 13 / ms / 1e9 / 8);
+      }
+  }
 
   // ---------------- fuse -> f64
   printf("== fuse u8 -> f64 xyz, %dx%d x %d frames, 25 B/point = %.1f MB\n", W, H, F, n * 25 / 1e6);
