@@ -110,8 +110,9 @@ __device__ __forceinline__ void store_x3_nt(void* dst, u32x3 v) {
 // element the compiler sinks each element's conversion into the load's own branch and puts an s_waitcnt vmcnt(0)
 // behind every load -- four serialised memory round trips per tile, invisible while the raster sits in the Infinity
 // Cache, a 1.3-1.5x loss when it really comes from HBM (1080p batches; profiles/r02_c5_probe.log).  For byte rasters the
-// loads were batched either way; measured per kernel: the f32-xyz kernel is 4 % faster clamped at one tile per workgroup
-// (7.0 vs 6.7 TB/s on C2), the lane-pair f64 kernel is faster predicated (6.6 vs 5.5), so each takes its own form.
+// loads were batched either way; measured per kernel: the fused f32-xyz kernel is 4 % faster clamped at one tile per
+// workgroup (7.0 vs 6.7 TB/s on C2), the lane-pair f64 kernel and the pose-less unprojection are faster predicated
+// (6.6 vs 5.5, 7.1 vs 6.4), so each takes its own form.
 template <typename DT, int ITEMS, int SHIFT, bool CLAMP>
 __device__ __forceinline__ void load_tile(const DT* __restrict__ depth, const FuseDims& dm, uint32_t tile, uint32_t tid,
                                           DT raw[ITEMS]) {
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restric
     load_pose<POSE>(pose, frame, P);
     const uint64_t fbase = (uint64_t)frame * dm.hw;
     DT raw[kPx];
-    load_tile<DT, kPx, 0, true>(depth, dm, tile, tid, raw);
+    load_tile<DT, kPx, 0, (POSE || sizeof(DT) > 1)>(depth, dm, tile, tid, raw);  // measured per variant, see load_tile
 #pragma unroll
     for (int r = 0; r < kPx; ++r) {
       const uint32_t p = tf * kTile + r * kThreads + tid;
@@ -374,8 +375,10 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   dm.rgb_vec_ok = d_rgb && ((uintptr_t)d_rgb % 16 == 0) && (hw % 16 == 0);
   const bool colour_after = d_rgb && out_dtype == R3D_F64;  // f64 xyz: colour goes through its own pass
   if (colour_after) p.rgb = nullptr;
-  // measured (profiles/r02_c5_probe.log, r02_ab_kernels.log): one tile per workgroup for every kernel
-  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : total_tiles;
+  // measured (profiles/r02_c5_probe.log, r02_ab_kernels.log, r02_all_kernels.json): one tile per workgroup for every kernel
+  // but the pose-less byte-raster f32 one (unproject only: 89 us with 8 striding workgroups per CU, 100 us at one tile each)
+  const bool stride8 = !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
+  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : stride8 ? (uint64_t)ctx->num_cus * 8 : total_tiles;
   if (blocks > total_tiles) blocks = total_tiles;
   if (with_pose)
     launch_depth<true>(p, dm, depth_dtype, out_dtype, (int)blocks, ctx->stream);
