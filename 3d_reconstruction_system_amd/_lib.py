@@ -62,6 +62,7 @@ SIGNATURES = {
     "r3d_fuse_frames": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),
     "r3d_fuse_frames_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _i]),
     "r3d_fuse_frames_rgb": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
+    "r3d_fuse_frames_rgb_host": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _i, _vp]),
     "r3d_backproject_depth_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "r3d_backproject_depth_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "r3d_se3_apply": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),

@@ -123,7 +123,7 @@ int r3d_ctx_destroy(r3d_ctx* ctx) {
   if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   for (int i = 0; i < r3d_ctx::kScratchSlots; ++i)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < r3d_ctx::kPinnedSlots; ++i)
     if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
   for (int i = 0; i < 6; ++i)
     if (ctx->ev_pipe[i]) (void)hipEventDestroy(ctx->ev_pipe[i]);

@@ -427,6 +427,40 @@ int fuse_host_common(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, i
   return r3d_host_pipeline(ctx, n_frames, frame_in, frame_out, h_depth, h_out, d_in, d_out, launch);
 }
 
+// RGBD batch from host memory: depth + colour stream in, xyz + rgba stream out, chunk by chunk through the pinned pipeline
+int fuse_rgb_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames, double depth_scale,
+                  const double* h_pose, const unsigned char* h_rgb, void* h_xyz_out, int out_dtype, uint32_t* h_rgba_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(cam != nullptr, "camera is NULL");
+  R3D_REQUIRE(depth_dtype >= R3D_DEPTH_U8 && depth_dtype <= R3D_DEPTH_F32, "unknown depth dtype %d", depth_dtype);
+  R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
+  R3D_REQUIRE(n_frames >= 0, "n_frames must be >= 0");
+  if (n_frames == 0) return R3D_OK;
+  R3D_REQUIRE(h_depth && h_rgb && h_xyz_out && h_rgba_out, "NULL host pointer");
+  const size_t px = (size_t)cam->height * cam->width, n = px * n_frames;
+  const size_t f_depth = px * r3d_depth_size(depth_dtype), f_rgb = px * 3, f_xyz = px * 3 * r3d_xyz_size(out_dtype),
+               f_rgba = px * 4;
+  void *d_depth = nullptr, *d_xyz = nullptr, *d_pose = nullptr, *d_rgb = nullptr, *d_rgba = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, n * r3d_depth_size(depth_dtype), &d_depth))) return rc;
+  if ((rc = r3d_scratch(ctx, 1, n * 3 * r3d_xyz_size(out_dtype), &d_xyz))) return rc;
+  if ((rc = r3d_scratch(ctx, 3, n * 3, &d_rgb))) return rc;
+  if ((rc = r3d_scratch(ctx, 4, n * 4, &d_rgba))) return rc;
+  if (h_pose) {
+    if ((rc = r3d_scratch(ctx, 2, (size_t)n_frames * 12 * sizeof(double), &d_pose))) return rc;
+    R3D_HIP(hipMemcpyAsync(d_pose, h_pose, (size_t)n_frames * 12 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  const r3d_pipe_buf ins[2] = {{const_cast<void*>(h_depth), d_depth, f_depth}, {const_cast<unsigned char*>(h_rgb), d_rgb, f_rgb}};
+  const r3d_pipe_buf outs[2] = {{h_xyz_out, d_xyz, f_xyz}, {h_rgba_out, d_rgba, f_rgba}};
+  auto launch = [&](int64_t lo, int64_t cnt) -> int {
+    return fuse_common(ctx, cam, static_cast<char*>(d_depth) + (size_t)lo * f_depth, depth_dtype, (int)cnt, depth_scale,
+                       h_pose ? static_cast<const double*>(d_pose) + (size_t)lo * 12 : nullptr, h_pose != nullptr,
+                       static_cast<char*>(d_xyz) + (size_t)lo * f_xyz, out_dtype,
+                       static_cast<const uint8_t*>(d_rgb) + (size_t)lo * f_rgb, static_cast<uint32_t*>(d_rgba) + (size_t)lo * px);
+  };
+  return r3d_host_pipeline_multi(ctx, n_frames, ins, 2, outs, 2, launch);
+}
+
 }  // namespace
 
 extern "C" {
@@ -471,6 +505,12 @@ int r3d_fuse_frames_rgb(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth
   R3D_REQUIRE(n_frames == 0 || (d_rgb && d_rgba_out), "colour plane / rgba output is NULL");
   return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, d_pose, d_pose != nullptr, d_xyz_out, out_dtype,
                      d_rgb, d_rgba_out);
+}
+
+int r3d_fuse_frames_rgb_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,
+                             double depth_scale, const double* h_pose, const unsigned char* h_rgb, void* h_xyz_out,
+                             int out_dtype, uint32_t* h_rgba_out) {
+  return fuse_rgb_host(ctx, cam, h_depth, depth_dtype, n_frames, depth_scale, h_pose, h_rgb, h_xyz_out, out_dtype, h_rgba_out);
 }
 
 }  // extern "C"

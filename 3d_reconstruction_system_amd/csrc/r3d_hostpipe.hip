@@ -60,31 +60,48 @@ int pinned_slot(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
 
 }  // namespace
 
-int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
-                      void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch) {
+int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* ins, int n_in, const r3d_pipe_buf* outs,
+                            int n_out, const std::function<int(int64_t, int64_t)>& launch) {
   if (n_items <= 0) return R3D_OK;
+  R3D_REQUIRE(n_in >= 1 && n_in <= r3d_ctx::kPipeBufs && n_out >= 1 && n_out <= r3d_ctx::kPipeBufs,
+              "host pipeline takes 1..%d arrays per direction", r3d_ctx::kPipeBufs);
   int rc;
   unsigned n_threads = std::thread::hardware_concurrency();
   n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
-  const bool in_pinned = is_pinned(h_in), out_pinned = is_pinned(h_out);
-  // ~32 MiB of the larger direction per chunk, at least 4 chunks when the batch allows it
-  const size_t big = std::max(in_item_bytes, out_item_bytes);
-  int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)32 << 20) / big));
+  bool in_pinned[r3d_ctx::kPipeBufs], out_pinned[r3d_ctx::kPipeBufs];
+  size_t big = 0;
+  for (int k = 0; k < n_in; ++k) {
+    in_pinned[k] = is_pinned(ins[k].h);
+    big = std::max(big, ins[k].item_bytes);
+  }
+  for (int k = 0; k < n_out; ++k) {
+    out_pinned[k] = is_pinned(outs[k].h);
+    big = std::max(big, outs[k].item_bytes);
+  }
+  // ~32 MiB of the largest array per chunk, at least 4 chunks when the batch allows it
+  int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)32 << 20) / std::max<size_t>(big, 1)));
   chunk = std::min(chunk, std::max<int64_t>(1, (n_items + 3) / 4));
   const int64_t n_chunks = (n_items + chunk - 1) / chunk;
-  void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  // staging: slot (direction, array, parity)
+  void* pin_in[r3d_ctx::kPipeBufs][2] = {};
+  void* pin_out[r3d_ctx::kPipeBufs][2] = {};
   for (int b = 0; b < 2; ++b) {
-    if (!in_pinned && (rc = pinned_slot(ctx, b, (size_t)chunk * in_item_bytes, &pin_in[b]))) return rc;
-    if (!out_pinned && (rc = pinned_slot(ctx, 2 + b, (size_t)chunk * out_item_bytes, &pin_out[b]))) return rc;
+    for (int k = 0; k < n_in; ++k)
+      if (!in_pinned[k] && (rc = pinned_slot(ctx, (0 * r3d_ctx::kPipeBufs + k) * 2 + b, (size_t)chunk * ins[k].item_bytes, &pin_in[k][b])))
+        return rc;
+    for (int k = 0; k < n_out; ++k)
+      if (!out_pinned[k] &&
+          (rc = pinned_slot(ctx, (1 * r3d_ctx::kPipeBufs + k) * 2 + b, (size_t)chunk * outs[k].item_bytes, &pin_out[k][b])))
+        return rc;
   }
   if (!ctx->ev_pipe[0]) {
     for (int k = 0; k < 6; ++k) R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[k], hipEventDisableTiming));
     R3D_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
   }
   // uploads ride their own stream so H2D of chunk c+1 overlaps the kernel + D2H of chunk c (PCIe is full duplex):
-  //   upload_stream: [wait free(b)] H2D -> up(b)        main stream: [wait up(b)] kernel, D2H -> done(b) (+ free(b) for d_in reuse)
-  // d_in is a whole-batch buffer, so uploads never overwrite data a kernel still reads; the first upload waits for
-  // whatever the main stream did before this call.
+  //   upload_stream: H2D -> up(b)        main stream: [wait up(b)] kernel, D2H -> done(b)
+  // the device arrays hold the whole batch, so uploads never overwrite data a kernel still reads; the first upload waits
+  // for whatever the main stream did before this call.
   hipEvent_t* ev_done = ctx->ev_pipe;      // [0,1] results of chunk b landed in pinned_out[b] / user memory
   hipEvent_t* ev_up = ctx->ev_pipe + 2;    // [2,3] chunk uploaded
   hipEvent_t ev_entry = ctx->ev_pipe[4];
@@ -93,20 +110,26 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
   auto issue = [&](int64_t c) -> int {
     const int b = (int)(c & 1);
     const int64_t lo = c * chunk, n = std::min(chunk, n_items - lo);
-    const char* src = static_cast<const char*>(h_in) + (size_t)lo * in_item_bytes;
-    if (!in_pinned) {
-      parallel_memcpy(pin_in[b], src, (size_t)n * in_item_bytes, n_threads);
-      src = static_cast<const char*>(pin_in[b]);
+    for (int k = 0; k < n_in; ++k) {
+      const size_t ib = ins[k].item_bytes;
+      const char* src = static_cast<const char*>(ins[k].h) + (size_t)lo * ib;
+      if (!in_pinned[k]) {
+        parallel_memcpy(pin_in[k][b], src, (size_t)n * ib, n_threads);
+        src = static_cast<const char*>(pin_in[k][b]);
+      }
+      R3D_HIP(hipMemcpyAsync(static_cast<char*>(ins[k].d) + (size_t)lo * ib, src, (size_t)n * ib, hipMemcpyHostToDevice,
+                             ctx->upload_stream));
     }
-    R3D_HIP(hipMemcpyAsync(static_cast<char*>(d_in) + (size_t)lo * in_item_bytes, src, (size_t)n * in_item_bytes,
-                           hipMemcpyHostToDevice, ctx->upload_stream));
     R3D_HIP(hipEventRecord(ev_up[b], ctx->upload_stream));
     R3D_HIP(hipStreamWaitEvent(ctx->stream, ev_up[b], 0));
     int r = launch(lo, n);
     if (r) return r;
-    void* dst = out_pinned ? static_cast<void*>(static_cast<char*>(h_out) + (size_t)lo * out_item_bytes) : pin_out[b];
-    R3D_HIP(hipMemcpyAsync(dst, static_cast<char*>(d_out) + (size_t)lo * out_item_bytes, (size_t)n * out_item_bytes,
-                           hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < n_out; ++k) {
+      const size_t ob = outs[k].item_bytes;
+      void* dst = out_pinned[k] ? static_cast<void*>(static_cast<char*>(outs[k].h) + (size_t)lo * ob) : pin_out[k][b];
+      R3D_HIP(hipMemcpyAsync(dst, static_cast<char*>(outs[k].d) + (size_t)lo * ob, (size_t)n * ob, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    }
     R3D_HIP(hipEventRecord(ev_done[b], ctx->stream));
     return R3D_OK;
   };
@@ -114,9 +137,10 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
     const int b = (int)(c & 1);
     const int64_t lo = c * chunk, n = std::min(chunk, n_items - lo);
     R3D_HIP(hipEventSynchronize(ev_done[b]));
-    if (!out_pinned)
-      parallel_memcpy(static_cast<char*>(h_out) + (size_t)lo * out_item_bytes, pin_out[b], (size_t)n * out_item_bytes,
-                      n_threads);
+    for (int k = 0; k < n_out; ++k)
+      if (!out_pinned[k])
+        parallel_memcpy(static_cast<char*>(outs[k].h) + (size_t)lo * outs[k].item_bytes, pin_out[k][b],
+                        (size_t)n * outs[k].item_bytes, n_threads);
     return R3D_OK;
   };
   // On ANY failure copies may still be in flight into the caller's buffers or the staging ring: quiesce both streams
@@ -133,6 +157,12 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
   for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c)
     if ((rc = drain(c))) return bail(rc);
   return R3D_OK;
+}
+
+int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
+                      void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch) {
+  const r3d_pipe_buf in{const_cast<void*>(h_in), d_in, in_item_bytes}, out{h_out, d_out, out_item_bytes};
+  return r3d_host_pipeline_multi(ctx, n_items, &in, 1, &out, 1, launch);
 }
 
 extern "C" {

@@ -29,9 +29,11 @@ struct r3d_ctx {
   static constexpr int kScratchSlots = 6;
   void* scratch[kScratchSlots] = {};
   size_t scratch_bytes[kScratchSlots] = {};
-  // pinned staging buffers of the host pipeline: [0,1] inbound, [2,3] outbound
-  void* pinned[4] = {};
-  size_t pinned_bytes[4] = {};
+  // pinned staging buffers of the host pipeline: slot = ((direction * kPipeBufs + array) * 2 + parity)
+  static constexpr int kPipeBufs = 2;   // arrays per direction (depth + colour in, xyz + rgba out)
+  static constexpr int kPinnedSlots = 2 * kPipeBufs * 2;
+  void* pinned[kPinnedSlots] = {};
+  size_t pinned_bytes[kPinnedSlots] = {};
   hipEvent_t ev_pipe[6] = {};           // host pipeline: done[2], uploaded[2], entry, spare
   hipStream_t upload_stream = nullptr;  // H2D side of the host pipeline (full-duplex PCIe)
 };
@@ -72,6 +74,14 @@ int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p);
 // to d_in + lo*in_item_bytes, `launch(lo, n)` enqueues the kernel for them, and d_out + lo*out_item_bytes comes back.
 int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
                       void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch);
+// The same with up to r3d_ctx::kPipeBufs arrays per direction travelling together (e.g. depth + colour in, xyz + rgba out).
+struct r3d_pipe_buf {
+  void* h;            // host array (pageable or pinned); inputs are only read
+  void* d;            // whole-batch device array
+  size_t item_bytes;  // bytes per item (frame)
+};
+int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* ins, int n_in, const r3d_pipe_buf* outs,
+                            int n_out, const std::function<int(int64_t, int64_t)>& launch);
 
 // Stable LSD radix sort of 64-bit keys by their low `bits` bits (r3d_sort.hip); d_tmp holds n keys.
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits);

@@ -97,20 +97,9 @@ def fuse_frames_rgb(depths, rgb, quats_xyzw=None, ts=None, intrinsics=REF_INTRIN
         return out, rgba
     ctx = ctx or default_context()
     cam = ctx.camera(h, w, *intrinsics)
-    d_depth, d_rgb = ctx.alloc(d.nbytes).upload(d), ctx.alloc(rgb.nbytes).upload(rgb)
-    d_pose = ctx.alloc(table.nbytes).upload(table) if table is not None else None
-    d_xyz, d_rgba = ctx.alloc(out.nbytes), ctx.alloc(rgba.nbytes)
-    try:
-        fuse_frames_rgb_device(ctx, cam, d_depth.ptr, d.dtype, f, d_pose.ptr if d_pose else None, d_rgb.ptr, d_xyz.ptr,
-                               out.dtype, d_rgba.ptr, depth_scale)
-        L.check(ctx.lib.r3d_memcpy_d2h(ctx.handle, out.ctypes.data, d_xyz.ptr, out.nbytes))
-        L.check(ctx.lib.r3d_memcpy_d2h(ctx.handle, rgba.ctypes.data, d_rgba.ptr, rgba.nbytes))
-        ctx.sync()
-    finally:
-        for b in (d_depth, d_rgb, d_pose, d_xyz, d_rgba):
-            if b is not None:
-                b.free()
-    del code
+    L.check(ctx.lib.r3d_fuse_frames_rgb_host(ctx.handle, cam.handle, d.ctypes.data, depth_code(d.dtype), f, float(depth_scale),
+                                             table.ctypes.data if table is not None else None, rgb.ctypes.data,
+                                             out.ctypes.data, code, rgba.ctypes.data))
     return out, rgba
 
 

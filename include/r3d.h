@@ -131,6 +131,11 @@ int r3d_fuse_frames_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_dept
 int r3d_fuse_frames_rgb(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
                         double depth_scale, const double* d_pose, const unsigned char* d_rgb, void* d_xyz_out,
                         int out_dtype, uint32_t* d_rgba_out);
+/* The same from / to host arrays (pageable or pinned): depth + colour stream in and xyz + rgba stream out chunk by chunk
+ * through the library's pinned staging pipeline, both PCIe directions busy at once.  Synchronous. */
+int r3d_fuse_frames_rgb_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,
+                             double depth_scale, const double* h_pose, const unsigned char* h_rgb, void* h_xyz_out,
+                             int out_dtype, uint32_t* h_rgba_out);
 
 /* f4, torch-facing: the BackprojectDepth layer the reference's trainer calls (monodepth2/trainer.py:150-160, 387-390;
  * upstream monodepth2 layers.py, not vendored by the reference):

@@ -439,3 +439,19 @@ def test_config5_per_gpu_share_250_frames_single_launch(R, ctx):
         check(one.reshape(-1, 3), want, np.float32)
     for b in (d_depth, d_rgb, d_pose, d_xyz, d_rgba, d_xyz2, d_rgba2):
         b.free()
+
+
+@pytest.mark.parametrize("odtype", [np.float32, np.float64])
+def test_fuse_rgb_host_pipeline_many_chunks(R, ctx, odtype):
+    """The host entry point streams depth + colour in and xyz + rgba out through the pinned pipeline: a batch large enough
+    for many chunks (40 frames of 1280x384), pageable and pinned outputs, against the device-pointer path."""
+    F, H, W = 40, 384, 1280
+    rng = np.random.default_rng(8)
+    d = rng.integers(0, 256, size=(F, H, W), dtype=np.uint8)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10
+    xyz, rgba = R.fuse_frames_rgb(d, rgb, q, t, out_dtype=odtype, ctx=ctx)
+    np.testing.assert_array_equal(xyz, R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx))
+    np.testing.assert_array_equal(rgba, _rgba_words(rgb))
+    for f in (0, 39):
+        check(xyz[f * H * W:(f + 1) * H * W], O.fuse_frames(d[f:f + 1], q[f:f + 1], t[f:f + 1]), odtype)
