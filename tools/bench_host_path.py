@@ -40,25 +40,6 @@ for dt in (np.float32, np.float64):
             dt_s = time.perf_counter() - t0
             print("%s pinned out rep %d: %.1f ms  %.2f Gpoints/s  (%.1f GB/s)" % (np.dtype(dt).name, rep, dt_s * 1e3,
                   F * H * W / dt_s / 1e9, pin.nbytes / dt_s / 1e9))
-# RGBD batch from host memory (config 5's flow on real data: decoded PNGs in, coloured cloud out)
-F, H, W = 100, 384, 1280
-rng = np.random.default_rng(3)
-d = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
-rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
-q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10
-tab = r3d.pose_table(q, t)
-n = F * H * W
-cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
-for label, alloc in (("pageable (pre-touched)", lambda shape, dt: np.zeros(shape, dt)), ("pinned", ctx.pinned_empty)):
-    xyz, rgba = alloc((n, 3), np.float32), alloc((n,), np.uint32)
-    for rep in range(3):
-        t0 = time.perf_counter()
-        L.check(ctx.lib.r3d_fuse_frames_rgb_host(ctx.handle, cam.handle, d.ctypes.data, 0, F, 1.0, tab.ctypes.data, rgb.ctypes.data,
-                                                 xyz.ctypes.data, 0, rgba.ctypes.data))
-        dt_s = time.perf_counter() - t0
-    print("fuse_frames_rgb host, outputs %s: %.1f ms  %.2f Gpoints/s  (%.1f GB/s out, %.1f GB/s in)"
-          % (label, dt_s * 1e3, n / dt_s / 1e9, n * 16 / dt_s / 1e9, n * 4 / dt_s / 1e9))
-ctx.close()
 
 # apply-T through the host pipeline: 12 B/point each way, full duplex
 ctx = r3d.Context(0)
