@@ -224,10 +224,17 @@ int r3d_comm_allgather(r3d_comm* comm, const void* d_send, const int64_t* h_coun
     R3D_HIP(hipMemcpyAsync(recv + off[me], d_send, (size_t)h_counts[me], hipMemcpyDeviceToDevice, st));
   if (W == 1) return R3D_OK;
   R3D_NCCL(api, api->GroupStart());
-  for (int step = 1; step < W; ++step) {
+  ncclResult_t bad = ncclSuccess;  // a failed enqueue must still close the group, or every later RCCL call of this thread queues into it
+  for (int step = 1; step < W && bad == ncclSuccess; ++step) {
     const int to = (me + step) % W, from = (me - step + W) % W;  // staggered peers: no two ranks start on the same target
-    if (h_counts[me] > 0) R3D_NCCL(api, api->Send(d_send, (size_t)h_counts[me], ncclUint8, to, comm->comm, st));
-    if (h_counts[from] > 0) R3D_NCCL(api, api->Recv(recv + off[from], (size_t)h_counts[from], ncclUint8, from, comm->comm, st));
+    if (h_counts[me] > 0) bad = api->Send(d_send, (size_t)h_counts[me], ncclUint8, to, comm->comm, st);
+    if (bad == ncclSuccess && h_counts[from] > 0)
+      bad = api->Recv(recv + off[from], (size_t)h_counts[from], ncclUint8, from, comm->comm, st);
+  }
+  if (bad != ncclSuccess) {
+    (void)api->GroupEnd();
+    r3d_set_error("RCCL error %d (%s) while queueing the direct exchange", (int)bad, api->GetErrorString(bad));
+    return R3D_ERR_HIP;
   }
   R3D_NCCL(api, api->GroupEnd());
   return R3D_OK;

@@ -305,7 +305,8 @@ def _step_size(T, extent):
 
 
 def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=None, ctx=None, culled=True, init="auto",
-                   check_every=4, dead_zone=None, max_coarse=40, coarse_tol=2e-4, trim=None, coarse_trim=None):
+                   check_every=4, dead_zone=None, max_coarse=40, coarse_tol=2e-4, trim=None, coarse_trim=None,
+                   profile=False):
     """Similarity (s, R, t) that maps `src` onto `tgt`: the T_data.txt of transfer_T_icp.py:99-108.
     Returns (T 4x4, info dict).  Three stages, all on device-resident clouds:
 
@@ -327,11 +328,22 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
           and the coarse stage by construction listens to the FAR pairs).  None = use all.  The coarse stage trims more
           gently, at coarse_trim (default 1 - (1 - trim)/4): there the far pairs ARE the signal.  Reliable on structured
           scenes (surfaces); on a featureless uniform volume outliers and extent mismatch look alike and coarse_trim has
-          to match the outlier share."""
+          to match the outlier share.
+    profile: info["timings_ms"] = wall time per stage (upload + index build, init, spacing probe, coarse, fine), with a
+          device sync at every stage boundary (off by default: the syncs cost a little)."""
+    import time
+    marks = [("start", time.perf_counter())]
+
+    def mark(name):
+        if profile:
+            dev.ctx.sync()
+            marks.append((name, time.perf_counter()))
+
     dev = IcpDevice(src, tgt, ctx, culled)
     info = {"init": init if isinstance(init, str) else "matrix", "coarse_iterations": 0, "coarse_history": []}
     T_total = np.eye(4)
     try:
+        mark("upload_index")
         if dev.n < 3:
             raise ValueError("need at least 3 source points")
         mode = init if isinstance(init, str) else "matrix"
@@ -348,11 +360,13 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                 T_total = np.eye(4)
                 T_total[:3, 3] = mom_t[1:4] / mom_t[0] - mom_s[1:4] / mom_s[0]
             dev.move_source(T_total)
+        mark("init")
         if mode == "auto" and dev.index is not None:
             mu = mom_t[1:4] / mom_t[0]
             extent = float(np.sqrt(max(mom_t[16] / mom_t[0] - mu @ mu, 0.0)))
             d0 = float(dead_zone) if dead_zone is not None else 2.0 * dev.target_spacing()
             info["dead_zone"] = d0
+            mark("spacing_probe")
             if d0 > 0 and extent > 0:
                 dev.back_begin()
                 T_since = np.eye(4)
@@ -378,6 +392,7 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                     if _step_size(T, extent) <= coarse_tol:
                         break
                 dev.back_end()
+            mark("coarse")
         # fine stage
         dev.state_reset()
         max_d2 = -1.0 if trim_d2 is None else float(trim_d2)
@@ -401,6 +416,9 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
         if st["degenerate"]:
             raise ValueError("ICP step undefined: fewer than 3 matched pairs (or no spread) after gating")
         T_total = st["T_total"] @ T_total
+        mark("fine")
+        if profile:
+            info["timings_ms"] = {b[0]: (b[1] - a[1]) * 1e3 for a, b in zip(marks, marks[1:])}
         info.update({"iterations": st["iterations"], "rms_history": st["rms_history"], "degenerate": st["degenerate"],
                      "converged_at": stop_at})
     finally:

@@ -46,6 +46,8 @@ for check_every in (4, 1):
           "probe; |T - T_true|max = %.2e, final rms %.3e, dead zone %.3f"
           % (check_every, info["coarse_iterations"], info["iterations"], dt * 1e3, np.abs(T - T_true).max(),
              info["rms_history"][-1], info["dead_zone"]))
+T, info = icp.icp_similarity(src, tgt, ctx=ctx, profile=True)
+print("stages (ms, synced):", {k: round(v, 2) for k, v in info["timings_ms"].items()})
 # the fine loop alone, from a near-aligned start, fused+device-solve vs stepped from the host, culled vs brute force
 near = (src.astype(np.float64) @ (T_true[:3, :3] * 1.003).T + T_true[:3, 3] + 0.01).astype(np.float32)
 for culled in (True, False):
