@@ -3,6 +3,9 @@ scale (monodepth2/trainer.py:150-160) and calls as `self.backproject_depth[s](de
 (trainer.py:387-388).  The layer itself lives in upstream monodepth2's layers.py, which the reference does not vendor; its
 definition is restated in csrc/r3d_backproject.hip.  Same constructor, same call, same [B, 4, H*W] fp32 result; the
 backward pass (with respect to depth -- inv_K is data in that trainer) is a second HIP kernel.
+`Project3D`, its partner in the same lines (trainer.py:158-159, 389-390: `self.project_3d[s](cam_points, K, T)`), maps the
+points to grid_sample coordinates [B, H, W, 2]; its backward yields the gradients of the points AND of K and T (the pose
+network trains through T): the per-pixel part and the twelve per-image sums are HIP, the 4x4 product K @ T is torch's.
 
 torch only lends tensors and the current stream; the arithmetic is the library's.  CUDA/ROCm tensors only: there is no
 CPU fallback.
@@ -70,3 +73,50 @@ class BackprojectDepth(torch.nn.Module):
 
     def forward(self, depth, inv_K):
         return _BackprojectFn.apply(depth, inv_K, self.batch_size, self.height, self.width)
+
+
+class _Project3DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fn, points, P, batch, height, width, eps):
+        if points.device.type != "cuda":
+            raise RuntimeError("Project3D runs on an MI355X (got a tensor on %s); there is no CPU fallback" % points.device)
+        if points.dtype != torch.float32 or P.dtype != torch.float32:
+            raise TypeError("Project3D is fp32 like the upstream layer")
+        if tuple(points.shape) != (batch, 4, height * width):
+            raise ValueError("points must be [%d, 4, %d]" % (batch, height * width))
+        if tuple(P.shape) != (batch, 3, 4):
+            raise ValueError("K @ T must be [%d, 4, 4]" % batch)
+        x, m = points.contiguous(), P.contiguous()
+        pix = torch.empty((batch, height, width, 2), dtype=torch.float32, device=points.device)
+        ctx = _ctx_for(points.device)
+        L.check(ctx.lib.r3d_project3d_f32(ctx.handle, x.data_ptr(), m.data_ptr(), batch, height, width, eps, pix.data_ptr()))
+        fn.save_for_backward(x, m)
+        fn.geom = (batch, height, width, eps)
+        return pix
+
+    @staticmethod
+    def backward(fn, grad_pix):
+        x, m = fn.saved_tensors
+        batch, height, width, eps = fn.geom
+        g = grad_pix.contiguous()
+        want_x, want_P = fn.needs_input_grad[0], fn.needs_input_grad[1]
+        grad_x = torch.empty_like(x) if want_x else None
+        grad_P = torch.empty_like(m) if want_P else None
+        ctx = _ctx_for(g.device)
+        L.check(ctx.lib.r3d_project3d_grad_f32(ctx.handle, g.data_ptr(), x.data_ptr(), m.data_ptr(), batch, height, width, eps,
+                                               grad_x.data_ptr() if want_x else None,
+                                               grad_P.data_ptr() if want_P else None))
+        return grad_x, grad_P, None, None, None, None
+
+
+class Project3D(torch.nn.Module):
+    """Layer which projects 3D points into a camera with intrinsics K and at position T (upstream monodepth2
+    layers.Project3D): [B, 4, H*W] points -> [B, H, W, 2] sampling coordinates in [-1, 1]."""
+
+    def __init__(self, batch_size, height, width, eps=1e-7):
+        super().__init__()
+        self.batch_size, self.height, self.width, self.eps = int(batch_size), int(height), int(width), float(eps)
+
+    def forward(self, points, K, T):
+        P = torch.matmul(K, T)[:, :3, :]
+        return _Project3DFn.apply(points, P, self.batch_size, self.height, self.width, self.eps)

@@ -147,6 +147,17 @@ int r3d_backproject_depth_f32(r3d_ctx* ctx, const float* d_depth, const float* d
 int r3d_backproject_depth_grad_f32(r3d_ctx* ctx, const float* d_grad_cam_points, const float* d_inv_K, int batch, int height,
                                    int width, float* d_grad_depth);
 
+/* Its partner in the same trainer lines, Project3D (trainer.py:150-160, 389-390; upstream layers.py):
+ *     c = P[b] . points[b][:, p]   (P = (K @ T)[:, :3, :], [B][3][4] row-major, formed by the caller: sixteen numbers per image)
+ *     pix[b][p] = ( (c0 / (c2 + eps) / (W-1) - 0.5) * 2,  (c1 / (c2 + eps) / (H-1) - 0.5) * 2 )        grid_sample coordinates
+ * d_points [B][4][H*W] (the BackprojectDepth layout), d_pix [B][H][W][2], fp32; upstream eps = 1e-7.
+ * The _grad entry point is the backward pass: d_grad_points [B][4][H*W] and/or d_grad_P [B][3][4] (either may be NULL);
+ * d_grad_P is a two-stage fixed-order reduction (bitwise repeatable). */
+int r3d_project3d_f32(r3d_ctx* ctx, const float* d_points, const float* d_P, int batch, int height, int width, float eps,
+                      float* d_pix);
+int r3d_project3d_grad_f32(r3d_ctx* ctx, const float* d_grad_pix, const float* d_points, const float* d_P, int batch,
+                           int height, int width, float eps, float* d_grad_points, float* d_grad_P);
+
 /* ---- a4 on an existing cloud: p_world = Rinv . (p_cam - t), the evaluation order of point_camera()
  * (camera_to_world.py:57-59) and of the fused kernel, so fuse_frames(depth) == se3_apply(unproject(depth))
  * bit for bit.  h_pose is ALWAYS a host pointer: 12 doubles [Rinv row-major (9), t (3)].  In-place allowed. */
