@@ -5,9 +5,16 @@
     comm.allgather(d_send_ptr, byte_counts, d_recv_ptr)      # unequal shards, rank order, async on ctx's stream
 
 One process per GPU (RCCL refuses two ranks on one device).
+
+Launched by `python -m torch.distributed.run --nproc-per-node N script.py` (or any launcher that sets RANK, WORLD_SIZE,
+LOCAL_RANK and, for several jobs on one node, MASTER_PORT), `Comm.from_env(ctx)` does the id exchange itself over an
+abstract Unix socket -- one node, no torch, no files left behind.
 """
 import atexit
 import ctypes as C
+import os
+import socket
+import time
 import weakref
 
 import numpy as np
@@ -16,6 +23,91 @@ from . import _lib as L
 
 ID_BYTES = 128
 GATHER_AUTO, GATHER_NCCL, GATHER_DIRECT = 0, 1, 2
+
+
+def env_rank_world():
+    """(rank, world) from the launcher's environment; (0, 1) when there is none."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if not 0 <= rank < world:
+        raise ValueError("RANK=%d outside WORLD_SIZE=%d" % (rank, world))
+    return rank, world
+
+
+def env_local_device():
+    """GPU index for this rank: LOCAL_RANK (one process per GPU).  R3D_SHARE_GPU=1 folds the ranks onto the visible GPUs
+    (rehearsals on a one-GPU box against a stand-in transport; RCCL itself refuses two ranks on one device)."""
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if os.environ.get("R3D_SHARE_GPU", "0") not in ("", "0"):
+        n = C.c_int(0)
+        L.check(L.load().r3d_device_count(C.byref(n)))
+        return local % max(n.value, 1)
+    return local
+
+
+def _rendezvous_name():
+    # abstract-namespace Unix socket: lives only as long as rank 0 holds it, nothing to clean up or to go stale.
+    # Concurrent jobs on one node already need distinct MASTER_PORTs for their launcher.
+    tag = os.environ.get("R3D_RENDEZVOUS", "%s_%s" % (os.environ.get("MASTER_PORT", "29500"),
+                                                      os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+    return b"\0r3d_comm_" + tag.encode()
+
+
+def exchange_unique_id(rank, world, timeout=120.0):
+    """The 128-byte communicator id on every rank of a ONE-NODE job: rank 0 creates it and serves it to the other
+    world-1 ranks over an abstract Unix socket; they connect (retrying until rank 0 is up) and read it."""
+    if world == 1:
+        return Comm.unique_id()
+    name = _rendezvous_name()
+    deadline = time.monotonic() + timeout
+    if rank == 0:
+        uid = Comm.unique_id()
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            srv.bind(name)              # EADDRINUSE = another job with the same MASTER_PORT / R3D_RENDEZVOUS: fail loudly
+            srv.listen(world)
+            served = set()
+            while len(served) < world - 1:
+                srv.settimeout(max(deadline - time.monotonic(), 0.01))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError("rendezvous: %d of %d ranks asked for the communicator id within %.0f s"
+                                       % (len(served), world - 1, timeout))
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        who = int.from_bytes(conn.recv(4), "little")
+                        conn.sendall(uid)
+                        if conn.recv(1) == b"k":          # the rank holds all 128 bytes
+                            served.add(who)
+                    except OSError:
+                        pass                 # that rank will retry
+        finally:
+            srv.close()
+        return uid
+    while True:
+        c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            c.settimeout(10.0)
+            c.connect(name)
+            c.sendall(int(rank).to_bytes(4, "little"))
+            uid = b""
+            while len(uid) < ID_BYTES:
+                part = c.recv(ID_BYTES - len(uid))
+                if not part:
+                    break
+                uid += part
+            if len(uid) == ID_BYTES:
+                c.sendall(b"k")
+                return uid
+        except OSError:
+            pass
+        finally:
+            c.close()
+        if time.monotonic() > deadline:
+            raise TimeoutError("rendezvous: rank 0 did not serve the communicator id within %.0f s" % timeout)
+        time.sleep(0.05)
 
 
 class Comm:
@@ -39,6 +131,12 @@ class Comm:
         buf = C.create_string_buffer(ID_BYTES)
         L.check(L.load().r3d_comm_unique_id(buf))
         return buf.raw
+
+    @classmethod
+    def from_env(cls, ctx, timeout=120.0):
+        """Communicator for the rank the launcher made this process (RANK / WORLD_SIZE), on `ctx`'s GPU."""
+        rank, world = env_rank_world()
+        return cls(ctx, exchange_unique_id(rank, world, timeout=timeout), rank, world)
 
     def rccl_origin(self):
         s = C.c_char_p()
@@ -70,6 +168,15 @@ class Comm:
 
     def allreduce_sum_f64(self, d_buf, n):
         L.check(self.ctx.lib.r3d_comm_allreduce_sum_f64(self.handle, d_buf, int(n)))
+
+    def barrier(self):
+        """Every rank has reached this point (a one-number all-reduce, then a stream sync)."""
+        buf = self.ctx.alloc(8).upload(np.zeros(1))
+        try:
+            self.allreduce_sum_f64(buf.ptr, 1)
+            self.ctx.sync()
+        finally:
+            buf.free()
 
     def close(self):
         if self.handle:

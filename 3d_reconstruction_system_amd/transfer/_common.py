@@ -6,6 +6,7 @@ Environment (all optional; the defaults are the reference's hard-coded values):
   R3D_FX R3D_FY R3D_CX R3D_CY   pinhole intrinsics        (p2c:25-28, c2w:68-71)
   R3D_DEVICE                    GPU index                 (default 0)
   R3D_SKIP_INTERMEDIATE=1       do not write ./point/<stem>.txt and ./point_world/*.txt
+  WORLD_SIZE RANK LOCAL_RANK    set by a one-process-per-GPU launcher (torch.distributed.run ...): frames are sharded
 """
 import importlib
 import os
@@ -44,3 +45,24 @@ def context():
 
 def skip_intermediate():
     return os.environ.get("R3D_SKIP_INTERMEDIATE", "0") not in ("", "0")
+
+
+def module(name):
+    return importlib.import_module(package().__name__ + "." + name)
+
+
+def world_size():
+    return int(os.environ.get("WORLD_SIZE", "1"))
+
+
+_sharded = None
+
+
+def sharded_context():
+    """(Context on this rank's GPU, Comm over all ranks) for a launcher-started job; created once."""
+    global _sharded
+    if _sharded is None:
+        CM = module("comm")
+        ctx = package().default_context(CM.env_local_device())
+        _sharded = (ctx, CM.Comm.from_env(ctx))
+    return _sharded

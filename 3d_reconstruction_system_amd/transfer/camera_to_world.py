@@ -9,6 +9,12 @@ frame by ONE fused HIP launch (fp64 registers, reference evaluation order) inste
 loops per frame with a text file between them.  The text/PLY files are produced from the GPU's
 fp64 result by the library's native formatter, byte-compatible with Python's repr()/"%.4f".
 
+Several GPUs: start it under a one-process-per-GPU launcher, e.g.
+    python -m torch.distributed.run --nproc-per-node 8 camera_to_world.py
+and the pose file's frames are cut into contiguous blocks, one per rank; each rank decodes and fuses its block, one
+RCCL all-gather (through the library's C ABI, no torch in this process) assembles the world cloud, every rank writes
+the ./point/<stem>.txt files of ITS frames, rank 0 writes the world txt and the PLY.  Same bytes as one GPU.
+
 Deliberate differences from the reference (all documented in DESIGN.md):
   * str_tofloat uses float() (np.float no longer exists);
   * a missing depth image raises FileNotFoundError naming the file (reference: TypeError on None);
@@ -118,7 +124,37 @@ def fuse_pose_file(qt_path, depth_dir='./depth/', out_dtype=np.float64):
     return names, depths, world
 
 
+def _get_file_name_sharded(qt_path):
+    """get_file_name when a launcher started one process per GPU (WORLD_SIZE > 1): BASELINE config 4."""
+    D = _common.module("dist")
+    ctx, comm = _common.sharded_context()
+    if comm.rank == 0:
+        print('data start transfer')
+    t1 = time.time()
+    names, lo, hi, depths, world = D.fuse_pose_file_sharded(qt_path, './depth/', _common.intrinsics(), np.float64, ctx, comm)
+    n_frames = len(names)
+    if n_frames and not _common.skip_intermediate():
+        if hi > lo:
+            per = depths.shape[1] * depths.shape[2]
+            cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=ctx)
+            for k in range(hi - lo):          # this rank's frames only
+                r3d.cloud_io.write_xyz_txt('./point/' + names[lo + k][0:-4] + '.txt', cam[k * per:(k + 1) * per],
+                                           z_raw=depths[k] if depths.dtype in (np.uint8, np.uint16) else None)
+        if comm.rank == 0:
+            per = world.shape[0] // n_frames
+            r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
+    t2 = time.time()
+    if comm.rank == 0:
+        print('##################')
+        print("%d frames cost ." % n_frames, t2 - t1)
+        genply(world, './ply/small_035_p8.ply', world.shape[0])
+    comm.barrier()                             # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
+    comm.close()
+
+
 def get_file_name(qt_path):
+    if _common.world_size() > 1:
+        return _get_file_name_sharded(qt_path)
     print('data start transfer')
     t1 = time.time()
     names, depths, world = fuse_pose_file(qt_path)

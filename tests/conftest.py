@@ -27,3 +27,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def mock_rccl(tmp_path_factory):
+    """tests/c/mock_rccl.cpp: the ten nccl* symbols r3d_comm.hip binds, moving bytes between processes through /dev/shm
+    (RCCL refuses two ranks on one device; the test box has one GPU).  Test infrastructure, bound via R3D_RCCL_PATH."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("mock") / "libmockrccl.so")
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared",
+                            os.path.join(root, "tests", "c", "mock_rccl.cpp"), "-o", so], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    return so

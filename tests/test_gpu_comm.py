@@ -96,16 +96,6 @@ def test_plain_c_multi_rank_consumer(tmp_path):
 
 
 # ---- N > 1 on the one-GPU box: the C ABI's exchange logic against a stand-in transport ----------------------------------
-@pytest.fixture(scope="module")
-def mock_rccl(tmp_path_factory):
-    """tests/c/mock_rccl.cpp: the ten nccl* symbols r3d_comm.hip binds, moving bytes between processes through /dev/shm."""
-    so = str(tmp_path_factory.mktemp("mock") / "libmockrccl.so")
-    build = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "c", "mock_rccl.cpp"),
-                            "-o", so], capture_output=True, text=True)
-    assert build.returncode == 0, build.stderr[-2000:]
-    return so
-
-
 @pytest.mark.parametrize("world,n_frames,algo", [(2, 5, 0), (2, 6, 1), (3, 7, 2), (4, 9, 0), (4, 8, 1), (3, 2, 0)])
 def test_plain_c_consumer_multi_rank_over_mock_transport(tmp_path, mock_rccl, world, n_frames, algo):
     """world ranks share the GPU; ragged blocks (and an EMPTY last block: 3 ranks, 2 frames), both assemblies, the

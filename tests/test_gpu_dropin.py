@@ -173,3 +173,32 @@ def test_camera_to_world_script_c1_scene_digests(tmp_path, golden_dir):
     for k, row in g["world_last_frame_rows"].items():
         np.testing.assert_allclose(world[int(k)], row, rtol=0, atol=1e-11)
     np.testing.assert_allclose(world.sum(0), g["world_last_frame_sum"], rtol=1e-11)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_camera_to_world_script_frame_sharded_over_ranks(tmp_path, golden_dir, mock_rccl, world):
+    """BASELINE config 4's shape through the drop-in: `torch.distributed.run --nproc-per-node N camera_to_world.py`.
+    scene3 has 3 frames: 2 ranks = ragged blocks (2 + 1), 3 ranks = one each, 4 ranks = an EMPTY last block.  The ranks share
+    the box's one GPU against the stand-in transport (R3D_RCCL_PATH; RCCL refuses two ranks per device); the worker
+    processes never import torch.  Every file must equal what the reference wrote for the same inputs."""
+    scene = os.path.join(golden_dir, "scene3")
+    for d in ("depth", "camera_pose"):
+        shutil.copytree(os.path.join(scene, d), tmp_path / d)
+    for d in ("point", "point_world", "ply"):
+        os.makedirs(tmp_path / d)
+    port = 29650 + (os.getpid() + 11 * world) % 120
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(SCRIPTS, "transfer", "camera_to_world.py")]
+    r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", R3D_RCCL_PATH=mock_rccl,
+                                R3D_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("Write into .ply file Done.") == 1                  # rank 0 only
+    for name in ("000", "007", "frame_b"):
+        assert (tmp_path / "point" / (name + ".txt")).read_bytes() == \
+            open(os.path.join(scene, "point", name + ".txt"), "rb").read()
+    assert (tmp_path / "ply" / "small_035_p8.ply").read_bytes() == \
+        open(os.path.join(scene, "ply", "small_035_p8.ply"), "rb").read()
+    got = O.read_xyz_txt(str(tmp_path / "point_world" / "small_worldpoint_5_23_5.txt"))
+    want = O.read_xyz_txt(os.path.join(scene, "point_world", "small_worldpoint_5_23_5.txt"))
+    assert got.shape == want.shape and (np.abs(got - want) / (1 + np.linalg.norm(want, axis=1, keepdims=True))).max() <= 1e-12
