@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 H, W, FRAMES_PER_GPU = 384, 1280, 100
 BYTES_PER_POINT = 13          # 1 B u8 depth read + 12 B f32 xyz written
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# N>1 assembly survey: seconds without progress before the pre-measured shards-stay-resident line goes out instead
+WATCHDOG_S = int(os.environ.get("R3D_BENCH_WATCHDOG_S", "240"))
 XGMI_LINK_GBS = 153.0         # one xGMI link, per direction (7 links per GPU, full mesh of 8)
 OVERLAP_CHUNKS = 4            # slices of the pipelined 'inputs' assembly
 
@@ -444,68 +446,10 @@ def main():
     kernel_ms, kernel_mean_ms, kernel_n = kernel_duration_ms(torch, stream, fuse)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
-    # N > 1: every assembly strategy, timed briefly BEFORE the headline region (all of them go on the line); the
-    # headline step is --assemble, by default the fastest strategy that leaves the whole cloud on every rank
-    assemble = {}
-    mode = "none"
-    if use_dist:
-        modes = ["none", "outputs", "inputs"]
-        if isinstance(transport, D.R3dTransport):
-            modes += ["outputs_direct", "inputs_direct"]
-        if side_transport is not None:
-            modes.append("inputs_overlap")
-        for m in modes:
-            try:   # a side measurement must never cost the headline line
-                st = make_step(m)
-                for _ in range(3):
-                    st()
-                fence()
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    st()
-                fence()
-                sec = max_over_ranks((time.perf_counter() - t1) / 10)
-                fabric_in = 0 if m == "none" else (world - 1) * (n_local * xyz_bytes if m.startswith("outputs")
-                                                                 else F * (H * W + 96))
-                if m == "inputs_overlap":    # same bits as 'inputs': checked here once, cheaply, on a strided sample
-                    probe = full[::997].clone()
-                    make_step("inputs")()
-                    if not torch.equal(probe, full[::997]):
-                        raise RuntimeError("pipelined assembly differs from the plain one")
-                entry = {"ms_per_step": round(sec * 1e3, 4), "Mpoints_s": round(world * n_local / sec / 1e6, 1),
-                         "fabric_bytes_in_per_gpu": fabric_in}
-                if fabric_in and world > 1:
-                    gbs = fabric_in / sec / 1e9          # whole step time, compute included: a lower bound on the links
-                    entry["xgmi_GBps_in_per_gpu"] = round(gbs, 1)
-                    entry["xgmi_GBps_per_link"] = round(gbs / (world - 1), 1)
-                    entry["frac_of_link_peak"] = round(gbs / (world - 1) / XGMI_LINK_GBS, 4)
-                assemble[m] = entry
-            except Exception as e:  # pragma: no cover
-                assemble[m] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:100])}
-        ok = {m: v["ms_per_step"] for m, v in assemble.items() if "ms_per_step" in v and m != "none"}
-        if a.assemble == "auto":
-            mode = min(ok, key=ok.get) if ok else "none"
-        else:
-            mode = a.assemble if (a.assemble in ok or a.assemble == "none") else "none"
-    step = make_step(mode)
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(a.steps):
-        step()
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    gpu_ms_per_step = ev0.elapsed_time(ev1) / max(a.steps, 1)       # this rank's stream, first step's start to last step's end
-    elapsed = max_over_ranks(elapsed)
-
     # which kernel the library dispatched for this launch (r3d_fuse.hip picks by output type)
     kernel_label = "fuse_lane_kernel<u8,f32,pose>" if a.out_dtype == "float32" else "fuse_pair_kernel<u8,f64,pose>"
-    if rank == 0:
+
+    def make_line(mode, elapsed, gpu_ms_per_step):
         total_pts = world * n_local * a.steps
         line = {
             "metric": "Mpoints/s fused (1280x384 depth, N frames)",
@@ -554,6 +498,101 @@ def main():
                                     "makes each GPU write world x %.0f MB into its own HBM, so its whole-job rate cannot "
                                     "exceed one GPU's kernel rate; 'none' (shards stay resident for the voxel / ICP "
                                     "stages) is the rate that scales" % (F, n_local * xyz_bytes / 1e6))
+        return line
+
+    def headline(step):
+        """--warmup untimed steps, then EXACTLY --steps timed ones between two fences; seconds = max over ranks."""
+        for _ in range(a.warmup):
+            step()
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(a.steps):
+            step()
+        ev1.record(stream)
+        fence()
+        sec = time.perf_counter() - t0
+        return max_over_ranks(sec), ev0.elapsed_time(ev1) / max(a.steps, 1)   # this rank's stream: first start to last end
+
+    # N > 1: every assembly strategy, timed briefly BEFORE the headline region (all of them go on the line); the
+    # headline step is --assemble, by default the fastest strategy that leaves the whole cloud on every rank.
+    # The exchange code has only ever met RCCL with one rank (no multi-GPU node was available to the build), so the
+    # survey runs under a watchdog: the shards-stay-resident job is measured FIRST by the full contract, and if a
+    # strategy then stalls for WATCHDOG_S seconds every rank prints nothing more / rank 0 prints THAT line, flagged.
+    assemble = {}
+    mode = "none"
+    fallback = {}
+    beat = {"t": time.monotonic(), "what": "start", "armed": False}
+
+    def watchdog():
+        while beat["armed"]:
+            time.sleep(1.0)
+            if beat["armed"] and time.monotonic() - beat["t"] > WATCHDOG_S:
+                if rank == 0 and fallback:
+                    line = make_line("none", fallback["elapsed"], fallback["gpu"])
+                    line["watchdog"] = "assembly strategy '%s' made no progress for %d s; this line is the " \
+                                       "shards-stay-resident job measured before the survey" % (beat["what"], WATCHDOG_S)
+                    print(json.dumps(line), flush=True)
+                os._exit(0 if fallback else 3)
+
+    if use_dist:
+        elapsed_none, gpu_none = headline(make_step("none"))
+        fallback["elapsed"], fallback["gpu"] = elapsed_none, gpu_none
+        modes = ["outputs", "inputs"]
+        if isinstance(transport, D.R3dTransport):
+            modes += ["outputs_direct", "inputs_direct"]
+        if side_transport is not None:
+            modes.append("inputs_overlap")
+        assemble["none"] = {"ms_per_step": round(elapsed_none / a.steps * 1e3, 4),
+                            "Mpoints_s": round(world * n_local * a.steps / elapsed_none / 1e6, 1), "fabric_bytes_in_per_gpu": 0}
+        import threading
+        beat.update(t=time.monotonic(), armed=True)
+        threading.Thread(target=watchdog, daemon=True).start()
+        for m in modes:
+            beat.update(t=time.monotonic(), what=m)
+            try:   # a side measurement must never cost the headline line
+                st = make_step(m)
+                for _ in range(3):
+                    st()
+                fence()
+                beat["t"] = time.monotonic()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    st()
+                fence()
+                sec = max_over_ranks((time.perf_counter() - t1) / 10)
+                beat["t"] = time.monotonic()
+                fabric_in = (world - 1) * (n_local * xyz_bytes if m.startswith("outputs") else F * (H * W + 96))
+                if m == "inputs_overlap":    # same bits as 'inputs': checked here once, cheaply, on a strided sample
+                    probe = full[::997].clone()
+                    make_step("inputs")()
+                    if not torch.equal(probe, full[::997]):
+                        raise RuntimeError("pipelined assembly differs from the plain one")
+                entry = {"ms_per_step": round(sec * 1e3, 4), "Mpoints_s": round(world * n_local / sec / 1e6, 1),
+                         "fabric_bytes_in_per_gpu": fabric_in}
+                if fabric_in and world > 1:
+                    gbs = fabric_in / sec / 1e9          # whole step time, compute included: a lower bound on the links
+                    entry["xgmi_GBps_in_per_gpu"] = round(gbs, 1)
+                    entry["xgmi_GBps_per_link"] = round(gbs / (world - 1), 1)
+                    entry["frac_of_link_peak"] = round(gbs / (world - 1) / XGMI_LINK_GBS, 4)
+                assemble[m] = entry
+            except Exception as e:  # pragma: no cover
+                assemble[m] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:100])}
+        ok = {m: v["ms_per_step"] for m, v in assemble.items() if "ms_per_step" in v and m != "none"}
+        if a.assemble == "auto":
+            mode = min(ok, key=ok.get) if ok else "none"
+        else:
+            mode = a.assemble if (a.assemble in ok or a.assemble == "none") else "none"
+        beat.update(t=time.monotonic(), what="headline (%s)" % mode)
+    if use_dist and mode == "none":
+        elapsed, gpu_ms_per_step = elapsed_none, gpu_none        # already measured by the full contract
+    else:
+        elapsed, gpu_ms_per_step = headline(make_step(mode))
+    beat["armed"] = False
+
+    if rank == 0:
+        line = make_line(mode, elapsed, gpu_ms_per_step)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line), flush=True)

@@ -152,7 +152,18 @@ ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int peer, ncclC
   return flush(c);
 }
 
+// MOCK_RCCL_STALL_RANK=r MOCK_RCCL_STALL_AFTER=k: rank r never returns from its k-th all-gather -- how a wedged fabric
+// looks to the host (bench.py's watchdog test)
+static void maybe_stall(ncclComm_t c) {
+  static int calls = 0;
+  const char* r = getenv("MOCK_RCCL_STALL_RANK");
+  const char* k = getenv("MOCK_RCCL_STALL_AFTER");
+  if (r && k && atoi(r) == c->rank && ++calls > atoi(k))
+    for (;;) sleep(1);
+}
+
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
+  maybe_stall(c);
   const size_t bytes = count * dtype_size(t);
   char* r = static_cast<char*>(recv);
   if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;

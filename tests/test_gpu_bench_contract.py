@@ -61,14 +61,11 @@ def test_secondary_workloads_print_a_roofline():
         assert d["roofline"]["bound"] == bound and 0.3 < d["roofline"]["frac"] < 1.0, d
 
 
-def test_two_rank_bench_over_the_c_abi_transport(tmp_path):
+def test_two_rank_bench_over_the_c_abi_transport(mock_rccl):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run), two ranks sharing the one GPU: torch's own
     process group on gloo, the exchange step through r3d_comm_* bound to the mock transport (tests/c/mock_rccl.cpp).
     Every assembly strategy must run, agree (the pipelined one checks itself against the plain one) and be reported."""
-    so = str(tmp_path / "libmockrccl.so")
-    build = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "c", "mock_rccl.cpp"),
-                            "-o", so], capture_output=True, text=True)
-    assert build.returncode == 0, build.stderr[-2000:]
+    so = mock_rccl
     port = 29950 + os.getpid() % 40
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8"]
@@ -85,3 +82,24 @@ def test_two_rank_bench_over_the_c_abi_transport(tmp_path):
         if m != "none":
             assert d["assemble"][m]["fabric_bytes_in_per_gpu"] > 0 and "xgmi_GBps_per_link" in d["assemble"][m]
     assert d["config"]["points_per_step"] == 2 * 8 * 384 * 1280 and d["config"]["assemble"] != "none"
+
+
+def test_watchdog_prints_the_pre_measured_line_when_an_exchange_wedges(mock_rccl):
+    """No multi-GPU node was available to the build, so the N>1 survey runs under a watchdog: if a strategy stalls (here:
+    rank 1 never returns from its 3rd all-gather) rank 0 still prints ONE valid line -- the shards-stay-resident job that was
+    measured by the full contract BEFORE the survey -- flagged with what hung, and every rank exits."""
+    port = 29900 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", R3D_DIST_BACKEND="gloo", R3D_BENCH_TRANSPORT="r3d",
+                                R3D_RCCL_PATH=mock_rccl, OMP_NUM_THREADS="1", R3D_BENCH_WATCHDOG_S="8",
+                                MOCK_RCCL_STALL_RANK="1", MOCK_RCCL_STALL_AFTER="2"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["assemble"] == "none"
+    assert "made no progress" in d["watchdog"] and "ms_per_step" in d["assemble"]["none"]
+    assert abs(d["value"] - 2 * 8 * 384 * 1280 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
