@@ -134,6 +134,8 @@ void r3d_shard_offsets(const int64_t* counts, int world, int64_t* offsets_out /*
 
 }  // namespace
 
+r3d_ctx* r3d_comm_context(const r3d_comm* comm) { return comm ? comm->ctx : nullptr; }
+
 extern "C" {
 
 int r3d_comm_unique_id(void* id_out) {

@@ -165,7 +165,7 @@ using r3d_icp::pair_weight;
 // NN kernel, whose winners the exact fallback wrote after the main kernel's fused sums were taken).
 // only_if != nullptr: the whole launch is a no-op when *only_if == 0 (partials are zeroed).
 __global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __restrict__ src, int64_t n_src,
-                                                              const float* __restrict__ tgt,
+                                                              const float* __restrict__ tgt, int64_t n_tgt,
                                                               const uint32_t* __restrict__ idx,
                                                               const float* __restrict__ d2, float max_d2, float dead_zone,
                                                               const unsigned char* __restrict__ flag,
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __res
       if (flag != nullptr && flag[i] == 0) continue;
       if (max_d2 >= 0.f && !(d2[i] <= max_d2)) continue;
       const int64_t j = idx ? (int64_t)idx[i] : i;  // no index array: pair k with k (per-cloud moments)
+      if (j >= n_tgt) continue;                      // a caller's index array is data: never read past the target cloud
       const double p[3] = {(double)src[i * 3 + 0], (double)src[i * 3 + 1], (double)src[i * 3 + 2]};
       const double q[3] = {(double)tgt[j * 3 + 0], (double)tgt[j * 3 + 1], (double)tgt[j * 3 + 2]};
       pair_accumulate(acc, d2 ? pair_weight(d2[i], dead_zone) : 1.0, p, q);
@@ -384,11 +385,10 @@ static int accumulate_impl(r3d_ctx* ctx, const float* d_src, int64_t n_src, cons
   void* d_part_v = nullptr;
   if ((rc = r3d_scratch(ctx, 4, ((size_t)blocks + 1) * kSums * sizeof(double), &d_part_v))) return rc;
   double* d_part = static_cast<double*>(d_part_v);
-  hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, d_idx,
+  hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, n_tgt, d_idx,
                      (gated || dead_zone > 0.f) ? d_d2 : nullptr, gated ? max_d2 : -1.f, dead_zone,
                      (const unsigned char*)nullptr, (const unsigned*)nullptr, d_part);
   R3D_HIP(hipGetLastError());
-  (void)n_tgt;
   return r3d_icp_sums_finish(ctx, d_src, n_src, d_tgt, d_idx, d_d2, -1.f, 0.f, nullptr, nullptr, d_part, blocks, d_sums_out,
                              with_scale, d_state);
 }

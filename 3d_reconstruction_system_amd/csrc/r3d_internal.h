@@ -67,6 +67,10 @@ int r3d_fail_hip(hipError_t e, const char* what, const char* file, int line);
 
 // make the ctx's device current for the calling thread
 int r3d_ctx_enter(r3d_ctx* ctx);
+// the context a communicator was created on (its collectives run on that context's stream); r3d_comm.hip
+struct r3d_comm;
+r3d_ctx* r3d_comm_context(const r3d_comm* comm);
+
 // grow-only scratch slot (device memory); returns device pointer in *p
 int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p);
 

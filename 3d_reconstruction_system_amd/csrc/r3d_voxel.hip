@@ -528,11 +528,15 @@ int r3d_voxelset_union(r3d_voxelset* vs, r3d_comm* comm) {
   int rank = 0, world = 1;
   int rc = r3d_comm_info(comm, &rank, &world, nullptr);
   if (rc) return rc;
+  // the exchange runs on the communicator's stream, the set's kernels on the set's: one context orders them
+  R3D_REQUIRE(r3d_comm_context(comm) == vs->ctx, "create the communicator on the voxel set's context");
   uint64_t* d_mine = nullptr;
   int64_t n_mine = 0;
-  if ((rc = codes_to_device_list(vs, &d_mine, &n_mine))) return rc;
-  if (world == 1) return R3D_OK;
-  // how many codes every rank brings: an all-gather of one int64 each
+  const int rc_mine = codes_to_device_list(vs, &d_mine, &n_mine);
+  if (world == 1) return rc_mine;
+  // how many codes every rank brings: an all-gather of one int64 each.  A rank whose set cannot be listed (overflow)
+  // still takes part and says -1, so that EVERY rank returns the error instead of waiting for it forever.
+  if (rc_mine) n_mine = -1;
   void* d_cnt = nullptr;
   if ((rc = r3d_scratch(vs->ctx, 3, (size_t)(world + 1) * sizeof(int64_t), &d_cnt))) return rc;
   int64_t* d_counts = static_cast<int64_t*>(d_cnt);
@@ -541,9 +545,13 @@ int r3d_voxelset_union(r3d_voxelset* vs, r3d_comm* comm) {
   if ((rc = r3d_comm_allgather(comm, d_counts + world, eight.data(), d_counts, R3D_GATHER_AUTO))) return rc;
   R3D_HIP(hipMemcpyAsync(counts.data(), d_counts, (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, vs->ctx->stream));
   R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
+  if (rc_mine) return rc_mine;  // this rank's own error message stands
   int64_t total = 0;
   for (int r = 0; r < world; ++r) {
-    R3D_REQUIRE(counts[r] >= 0, "rank %d reports a negative code count", r);
+    if (counts[r] < 0) {
+      r3d_set_error("rank %d could not list its voxel set (overflow): no union was formed", r);
+      return R3D_ERR_NOMEM;
+    }
     bytes[r] = counts[r] * (int64_t)sizeof(uint64_t);
     total += counts[r];
   }

@@ -208,7 +208,8 @@ int r3d_nn_index_sort_cloud(r3d_nn_index* index, float* d_xyz, int64_t n_points,
 /* r3d_icp_accumulate: the 18 fp64 sums Umeyama needs over the matched pairs (p=src[k], q=tgt[idx[k]]),
  * pairs with d2 > max_d2 skipped when max_d2 >= 0 (d_d2 may be NULL when max_d2 < 0):
  *   sums[0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p_a*q_b (a major), [16]=sum |p|^2, [17]=sum |q|^2.
- * Deterministic (fixed two-stage tree, no float atomics).  h_sums is a host pointer; synchronous. */
+ * Deterministic (fixed two-stage tree, no float atomics).  h_sums is a host pointer; synchronous.
+ * Pairs whose idx[k] >= n_tgt are skipped (the index array is data; the kernel never reads past the target cloud). */
 int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                        const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums);
 
@@ -338,7 +339,9 @@ int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, 
 int r3d_voxelset_insert_codes(r3d_voxelset* vs, const uint64_t* d_codes, int64_t n_codes);
 /* Config 5 (frames sharded over the GPUs, ONE map): collective over `comm`.  Every rank has voxelised its own shard of the
  * world cloud into its own set; the ranks all-gather only their DISTINCT codes (8 B/voxel, unequal shards -- the 12 B/point
- * of the clouds never leave their GPU) and fold them in.  Afterwards every rank's set is the union.  Synchronises. */
+ * of the clouds never leave their GPU) and fold them in.  Afterwards every rank's set is the union.  Synchronises.
+ * `comm` must live on the set's context (one stream orders the set's kernels and the exchange).  If ANY rank's set has
+ * overflowed, every rank takes part in the first exchange and then returns R3D_ERR_NOMEM: no rank is left waiting. */
 int r3d_voxelset_union(r3d_voxelset* vs, struct r3d_comm* comm);
 /* In-place ascending sort of 64-bit keys in HBM by their low key_bits bits (stable LSD radix sort, 8-bit digits;
  * asynchronous on the ctx stream).  Building block of r3d_voxelset_codes, exported for tests and reuse. */

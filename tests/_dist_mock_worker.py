@@ -63,6 +63,16 @@ def main():
     ok = ok and np.array_equal(vs.codes(), whole.codes()) and vs.stats()["overflow"] == 0
     vs.close()
     whole.close()
+    # a rank whose set overflowed must not leave the others waiting: EVERY rank gets the error
+    tiny = V.VoxelSet(0.01, 1024, ctx)
+    if rank == 1:
+        tiny.insert(want[:50000])
+    try:
+        tiny.union_across(comm)
+        ok = False
+    except r3d.R3DError:
+        pass
+    tiny.close()
     sums = torch.arange(18, dtype=torch.float64, device=dev) * (rank + 1)
     comm.allreduce_sum_f64(sums.data_ptr(), 18)
     torch.cuda.synchronize()

@@ -180,6 +180,21 @@ def test_known_correspondences_give_the_closed_form_answer(icp, ctx):
     np.testing.assert_allclose(T, T_true, rtol=0, atol=5e-5)
 
 
+def test_accumulate_skips_indices_past_the_target_cloud(icp, ctx):
+    """The index array is caller data: rows pointing past the target must be left out, not read."""
+    src, tgt, _, pick = OI.synthetic_pair(n_tgt=3000, n_src=2000)
+    bad = pick.astype(np.uint32).copy()
+    bad[::7] = np.uint32(0xFFFFFFFF)
+    bad[1::7] = np.uint32(tgt.shape[0])
+    dev = icp.IcpDevice(src, tgt, ctx, culled=False)
+    dev.d_idx.upload(bad)
+    sums = dev.sums()
+    dev.free()
+    keep = bad < tgt.shape[0]
+    np.testing.assert_allclose(sums, OI.pair_sums(src[keep], tgt, bad[keep]), rtol=1e-12, atol=1e-9)
+    assert sums[0] == keep.sum()
+
+
 def test_icp_loop_converges_and_matches_oracle_loop(icp, ctx):
     """A small misalignment (inside ICP's basin: displacement < half the point spacing): the GPU loop must
     land on the true transform and agree with the oracle's loop step for step."""
