@@ -255,6 +255,82 @@ def secondary(a):
     ctx.close()
 
 
+def c5_sharded(a):
+    """BASELINE config 5's shape over the GPUs of a node, torch-free: `torch.distributed.run --nproc-per-node N bench.py
+    --workload c5 --gpus N`.  Every rank owns F frames of 1920x1080 f32 depth + RGB; a step = fuse them with colour (one
+    launch), voxelise the rank's shard into its own HBM hash set, unite the sets through the C ABI (r3d_voxelset_union:
+    all-gather of the DISTINCT codes only, 8 B/voxel; the 16 B/point of the coloured cloud never leave their GPU).
+    Synthetic depth is random, i.e. the worst case of ~1 voxel per point."""
+    r3d = importlib.import_module("3d_reconstruction_system_amd")
+    V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
+    CM = importlib.import_module("3d_reconstruction_system_amd.comm")
+    rank, world = CM.env_rank_world()
+    if world != a.gpus:
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
+    ctx = r3d.Context(CM.env_local_device())
+    comm = CM.Comm.from_env(ctx)
+    F = max(1, min(a.frames, 250)) if a.frames != FRAMES_PER_GPU else 50
+    h5, w5 = 1080, 1920
+    n = F * h5 * w5
+    rng = np.random.default_rng(5 + rank)
+    depth = rng.random((F, h5, w5), dtype=np.float32) * 99.5 + 0.5
+    rgb = rng.integers(0, 256, size=(F, h5, w5, 3), dtype=np.uint8)
+    tab = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
+    d_depth, d_rgb, d_pose = ctx.alloc(depth.nbytes).upload(depth), ctx.alloc(rgb.nbytes).upload(rgb), ctx.alloc(tab.nbytes).upload(tab)
+    del depth, rgb
+    d_xyz, d_rgba = ctx.alloc(n * 12), ctx.alloc(n * 4)
+    cam = ctx.camera(h5, w5, 960.0, 960.0, 959.5, 539.5)
+    vs = V.VoxelSet(0.1, 2 * n * world, ctx)
+    d_t = ctx.alloc(8 * (world + 1))
+
+    def step():
+        r3d.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, np.float32, d_rgba.ptr)
+        vs.clear()
+        vs.insert_device(d_xyz.ptr, n)
+        vs.union_across(comm)
+
+    def max_over_ranks(seconds):
+        mine = np.array([seconds])
+        ctx.lib.r3d_memcpy_h2d(ctx.handle, d_t.ptr + 8 * world, mine.ctypes.data, 8)
+        comm.allgather(d_t.ptr + 8 * world, [8] * world, d_t.ptr)
+        return float(d_t.download(np.float64, world).max())
+
+    steps, warm = max(1, min(a.steps, 50)), max(1, min(a.warmup, 5))
+    for _ in range(warm):
+        step()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    comm.barrier()
+    sec = max_over_ranks(time.perf_counter() - t0)
+    st = vs.stats()
+    ms_fuse = []
+    for _ in range(5):
+        ctx.timer_start()
+        r3d.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, np.float32, d_rgba.ptr)
+        ms_fuse.append(ctx.timer_stop())
+    ms = sorted(ms_fuse)[2]
+    if rank == 0:
+        gbs = n * 23 / ms / 1e6
+        print(json.dumps({
+            "metric": "Mpoints/s fused RGBD + voxel map (1920x1080 f32 depth + RGB, %d frames per GPU, one map)" % F,
+            "value": round(world * n * steps / sec / 1e6, 1), "unit": "Mpoints/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": round(sec / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (random depth: ~1 voxel per point, the worst case for the map)",
+            "config": {"workload": "C5: fuse with colour + voxel insert + union of the ranks' sets", "frames_per_gpu": F,
+                       "points_per_step": world * n, "parallelism": "frames sharded, %d rank(s), one process per GPU, "
+                                                                    "r3d_comm (%s)" % (world, comm.rccl_origin())},
+            "union_voxels": st["voxels"], "union_overflow": st["overflow"],
+            "fabric_bytes_in_per_gpu": 8 * st["voxels"] * (world - 1) // max(world, 1),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "fuse_rgb_kernel<f32,pose>",
+                         "kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": n * 23}}), flush=True)
+    comm.barrier()
+    comm.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,6 +352,8 @@ def main():
                          "one GPU: apply = 4x4 apply on the C2 cloud, icp = C3 (two 500k clouds, SURVEY recipe), voxel = occupancy insert, "
                          "c5 = config 5 geometry (1080p f32 RGBD, colour carried, + voxel insert)")
     a = ap.parse_args()
+    if a.workload == "c5" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return c5_sharded(a)
     if a.workload != "fuse":
         return secondary(a)
 

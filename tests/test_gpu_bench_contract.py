@@ -103,3 +103,23 @@ def test_watchdog_prints_the_pre_measured_line_when_an_exchange_wedges(mock_rccl
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["assemble"] == "none"
     assert "made no progress" in d["watchdog"] and "ms_per_step" in d["assemble"]["none"]
     assert abs(d["value"] - 2 * 8 * 384 * 1280 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
+
+
+def test_config5_shape_over_two_ranks(mock_rccl):
+    """`bench.py --workload c5 --gpus 2` under the launcher: per-rank RGBD fuse + voxel insert + union of the sets through
+    the C ABI (stand-in transport, ranks share the GPU; the workers never import torch)."""
+    port = 29860 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--workload", "c5", "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--frames", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", R3D_RCCL_PATH=mock_rccl, R3D_SHARE_GPU="1", OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    n = 2 * 1080 * 1920
+    assert d["n_gpus"] == 2 and d["config"]["points_per_step"] == 2 * n and d["union_overflow"] == 0
+    assert n < d["union_voxels"] <= 2 * n                 # random depth: nearly one voxel per point, both ranks' shards in ONE map
+    assert d["fabric_bytes_in_per_gpu"] == 8 * d["union_voxels"] // 2
+    assert abs(d["value"] - 2 * n / d["ms_per_step"] / 1e3) / d["value"] < 1e-2 and 0.3 < d["roofline"]["frac"] < 1.0
