@@ -42,7 +42,10 @@ __device__ __forceinline__ double pair_weight(float d2, float dead_zone) {
   return d > (double)dead_zone ? 1.0 - (double)dead_zone / d : 0.0;
 }
 
+// A pair in which p or q carries a NaN / inf coordinate is no pair: it is left out (one such row would turn all 18 sums
+// into NaN).  The six values come from fp32, so their fp64 sum is finite exactly when all of them are.
 __device__ __forceinline__ void pair_accumulate(double acc[kSums], double w, const double p[3], const double q[3]) {
+  if (!isfinite(((p[0] + p[1]) + p[2]) + ((q[0] + q[1]) + q[2]))) return;
   acc[0] += w;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {

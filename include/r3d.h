@@ -183,6 +183,8 @@ int r3d_apply_T_dev(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_
  * computed in fp32 as d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx)) with dx = sx-tx, dy = sy-ty, dz = sz-tz (one rounding
  * for dx*dx, one per fused multiply-add; no other contraction), lowest index wins exact ties.  This expression IS
  * the specification: brute force, culled index, fallback and oracle all evaluate exactly it.
+ * Non-finite input: a pair whose d2 is NaN or +inf never wins; a source with no finite d2 at all (it, or every target,
+ * has a NaN / inf coordinate) gets index 0 and d2 = +inf; the pair sums leave rows with non-finite coordinates out.
  * src/tgt are float32 xyz AoS.  d_idx_out [n_src] uint32, d_d2_out [n_src] float32 (may be NULL). */
 int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                uint32_t* d_idx_out, float* d_d2_out);
@@ -209,7 +211,8 @@ int r3d_nn_index_sort_cloud(r3d_nn_index* index, float* d_xyz, int64_t n_points,
  * pairs with d2 > max_d2 skipped when max_d2 >= 0 (d_d2 may be NULL when max_d2 < 0):
  *   sums[0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p_a*q_b (a major), [16]=sum |p|^2, [17]=sum |q|^2.
  * Deterministic (fixed two-stage tree, no float atomics).  h_sums is a host pointer; synchronous.
- * Pairs whose idx[k] >= n_tgt are skipped (the index array is data; the kernel never reads past the target cloud). */
+ * Pairs whose idx[k] >= n_tgt are skipped (the index array is data; the kernel never reads past the target cloud), and so
+ * are pairs in which p or q has a NaN / inf coordinate (in every sums pass of this library, fused ones included). */
 int r3d_icp_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                        const uint32_t* d_idx, const float* d_d2, float max_d2, double* h_sums);
 

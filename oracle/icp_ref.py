@@ -63,6 +63,8 @@ def pair_sums(src, tgt, idx, d2=None, max_d2=-1.0, dead_zone=0.0):
     if max_d2 >= 0:
         keep = np.asarray(d2) <= np.float32(max_d2)
         p, q, w = p[keep], q[keep], w[keep]
+    finite = np.isfinite(p).all(1) & np.isfinite(q).all(1)         # a row with a NaN / inf coordinate is no pair
+    p, q, w = p[finite], q[finite], w[finite]
     out = np.zeros(18)
     wp = p * w[:, None]
     out[0] = w.sum()

@@ -455,3 +455,42 @@ def test_fuse_rgb_host_pipeline_many_chunks(R, ctx, odtype):
     np.testing.assert_array_equal(rgba, _rgba_words(rgb))
     for f in (0, 39):
         check(xyz[f * H * W:(f + 1) * H * W], O.fuse_frames(d[f:f + 1], q[f:f + 1], t[f:f + 1]), odtype)
+
+
+def test_seeded_random_shape_sweep_every_kernel(R, ctx):
+    """120 seeded random (F, H, W) -- frame sizes around the 1024-pixel tile (1023, 1024, 1025, multiples, primes), 1..7
+    frames -- through every shipped kernel (3 depth types x f32/f64 xyz x pose / no pose x plain / colour) against the oracle.
+    Random shapes find what hand-picked ones do not: tile tails, frames that are not a multiple of the tile, 1-wide rasters."""
+    rng = np.random.default_rng(20260)
+    specials = [1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1021, 1023, 1024, 1025, 2047, 2048, 2049, 3071,
+                3072, 3073, 4095, 4096, 4097, 5003]
+    for case in range(120):
+        if case % 3 == 0:                                  # a frame of exactly / nearly k tiles, factored at random
+            px = int(rng.choice(specials))
+            divs = [d for d in range(1, px + 1) if px % d == 0]
+            h = int(rng.choice(divs))
+            w = px // h
+        else:
+            h, w = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+        f = int(rng.integers(1, 8))
+        ddtype = [np.uint8, np.uint16, np.float32][case % 3 if case % 2 else int(rng.integers(0, 3))]
+        odtype = [np.float32, np.float64][int(rng.integers(0, 2))]
+        d = make_depth(rng, (f, h, w), ddtype)
+        q = rng.normal(size=(f, 4))
+        t = rng.normal(size=(f, 3)) * 10
+        K = (float(rng.uniform(50, 900)), float(rng.uniform(50, 900)), float(rng.uniform(0, w)), float(rng.uniform(0, h)))
+        want = O.fuse_frames(d, q, t, *K)
+        got = R.fuse_frames(d, q, t, intrinsics=K, out_dtype=odtype, ctx=ctx)
+        check(got, want, odtype)
+        got_u = R.unproject(d, intrinsics=K, out_dtype=odtype, ctx=ctx)
+        want_u = np.concatenate([O.unproject(fr, *K) for fr in d])
+        check(got_u, want_u, odtype)
+        if odtype == np.float64:
+            np.testing.assert_array_equal(got_u, want_u, err_msg="case %d %s" % (case, (f, h, w, ddtype)))
+        rgb = rng.integers(0, 256, size=(f, h, w, 3), dtype=np.uint8)
+        xyz, rgba = R.fuse_frames_rgb(d, rgb, q, t, intrinsics=K, out_dtype=odtype, ctx=ctx)
+        np.testing.assert_array_equal(xyz, got, err_msg="case %d %s" % (case, (f, h, w, ddtype)))
+        np.testing.assert_array_equal(rgba, _rgba_words(rgb))
+        cam_xyz, rgba2 = R.fuse_frames_rgb(d, rgb, intrinsics=K, out_dtype=odtype, ctx=ctx)
+        np.testing.assert_array_equal(cam_xyz, got_u)
+        np.testing.assert_array_equal(rgba2, rgba)

@@ -466,3 +466,84 @@ def test_trimmed_estimator_matches_oracle_restatement(icp, ctx):
     T, _ = icp.icp_similarity(src, tgt, ctx=ctx, trim=0.9)
     np.testing.assert_allclose(T, T_ref, rtol=0, atol=2e-4)
     np.testing.assert_allclose(T, T_true, rtol=0, atol=2e-3)
+
+
+def test_seeded_random_cloud_sweep_culled_equals_brute_force(icp, ctx):
+    """60 seeded random (n_src, n_tgt, distribution) cases around the index's granularities (32-target groups, 256-target
+    quarters, 1024-target tiles, 16-tile super-boxes, 256-source blobs): the culled query must equal the brute-force sweep
+    bit for bit (indices AND distances), and the sums fused into the query must equal the separate gather pass.
+    Distributions include the degenerate ones (every point identical, a line, a plane, heavy duplication, far apart)."""
+    rng = np.random.default_rng(31337)
+    sizes = [1, 2, 31, 32, 33, 255, 256, 257, 1023, 1024, 1025, 2047, 2049, 4096, 16383, 16384, 16385, 20000]
+
+    def cloud(kind, n):
+        if kind == "same":
+            return np.tile(rng.normal(size=(1, 3)), (n, 1))
+        if kind == "line":
+            return np.outer(rng.random(n) * 50, rng.normal(size=3))
+        if kind == "plane":
+            p = rng.random((n, 3)) * 20
+            p[:, 2] = 3.0
+            return p
+        if kind == "dups":
+            base = rng.random((max(1, n // 50), 3)) * 10
+            return base[rng.integers(0, base.shape[0], n)]
+        if kind == "far":
+            return rng.random((n, 3)) + 1000.0 * rng.integers(0, 2, size=(n, 1))
+        return rng.random((n, 3)) * 20
+
+    kinds = ["cube", "same", "line", "plane", "dups", "far"]
+    for case in range(60):
+        n, m = int(rng.choice(sizes)), int(rng.choice(sizes))
+        ks, kt = kinds[int(rng.integers(0, 6))], kinds[case % 6]
+        src, tgt = cloud(ks, n).astype(np.float32), cloud(kt, m).astype(np.float32)
+        tag = "case %d: %d %s sources, %d %s targets" % (case, n, ks, m, kt)
+        bi, bd = icp.nearest_neighbours(src, tgt, ctx=ctx, culled=False)
+        ci, cd = icp.nearest_neighbours(src, tgt, ctx=ctx, culled=True)
+        np.testing.assert_array_equal(ci, bi, err_msg=tag)
+        np.testing.assert_array_equal(cd, bd, err_msg=tag)
+        if n >= 3:
+            dev = icp.IcpDevice(src, tgt, ctx, culled=True)
+            fused = dev.nn_sums()
+            sep = dev.sums()                       # same pairs; the two passes add them up in different (fixed) orders
+            np.testing.assert_allclose(fused, sep, rtol=1e-10, atol=1e-9 * (1.0 + np.abs(sep).max()), err_msg=tag)
+            assert fused[0] == n, tag
+            dev.free()
+
+
+def test_non_finite_points_never_win_and_never_enter_the_sums(icp, ctx):
+    """include/r3d.h: a pair with NaN / inf d2 never wins; a source with no finite distance gets index 0, d2 = +inf; rows with
+    a non-finite coordinate stay out of every sums pass.  Brute force, culled index and the fused sums agree."""
+    rng = np.random.default_rng(77)
+    src = (rng.random((5000, 3)) * 20).astype(np.float32)
+    tgt = (rng.random((7000, 3)) * 20).astype(np.float32)
+    bad_s = rng.choice(5000, 40, replace=False)
+    bad_t = rng.choice(np.arange(1, 7000), 60, replace=False)
+    src[bad_s[:20], 1] = np.nan
+    src[bad_s[20:], 0] = np.inf
+    tgt[bad_t[:30], 2] = np.nan
+    tgt[bad_t[30:], 0] = -np.inf
+    clean_t = np.ones(7000, bool)
+    clean_t[bad_t] = False
+    clean_s = np.ones(5000, bool)
+    clean_s[bad_s] = False
+    want_i, want_d = OI.nearest_neighbours(src[clean_s], tgt[clean_t])
+    want_i = np.nonzero(clean_t)[0][want_i]
+    for culled in (False, True):
+        idx, d2 = icp.nearest_neighbours(src, tgt, ctx=ctx, culled=culled)
+        np.testing.assert_array_equal(idx[clean_s], want_i)
+        np.testing.assert_allclose(d2[clean_s], want_d, rtol=2e-7)
+        assert (idx[bad_s] == 0).all() and np.isposinf(d2[bad_s]).all()
+    dev = icp.IcpDevice(src, tgt, ctx)
+    fused = dev.nn_sums()
+    sep = dev.sums()
+    idx, d2 = dev.download()
+    dev.free()
+    want = OI.pair_sums(src[clean_s], tgt, idx[clean_s])
+    assert fused[0] == sep[0] == clean_s.sum()
+    np.testing.assert_allclose(fused, want, rtol=1e-11, atol=1e-8)
+    np.testing.assert_allclose(sep, want, rtol=1e-11, atol=1e-8)
+    mom = icp.IcpDevice(src, tgt, ctx, culled=False)
+    m = mom.moments("src")
+    mom.free()
+    assert m[0] == clean_s.sum() and np.isfinite(m).all()
