@@ -18,18 +18,32 @@ from .device import xyz_code
 
 
 def read_depth_gray(path):
-    """8-bit grey raster with OpenCV's IMREAD_GRAYSCALE meaning: OpenCV if importable, else
-    PIL's 'L' conversion (identical for 8-bit single-channel PNGs, the reference's input)."""
+    """8-bit grey raster with OpenCV's IMREAD_GRAYSCALE meaning (c2w:160): OpenCV itself if importable.  Without it:
+    8-bit single-channel PNGs (the reference's input) are what they are; a 16-bit grey PNG keeps its HIGH byte -- OpenCV
+    reads those through libpng's png_set_strip_16, i.e. v >> 8, where PIL's 'L' conversion would clip at 255; colour files
+    take PIL's 'L' (ITU-R 601 weights like OpenCV's; equal for the R=G=B files depth maps are saved as)."""
     try:
         import cv2
         img = cv2.imread(path, cv2.IMREAD_GRAYSCALE)
     except ImportError:
         img = None
-        try:
-            from PIL import Image
-            img = np.array(Image.open(path).convert("L"))
-        except FileNotFoundError:
-            img = None
+        lib = L.load()
+        h, w, bits = C.c_int(), C.c_int(), C.c_int()
+        if lib.r3d_png_gray_info(os.fsencode(path), C.byref(h), C.byref(w), C.byref(bits)) == L.OK and bits.value == 16:
+            raw = np.empty((h.value, w.value), np.uint16)
+            arr = (C.c_char_p * 1)(os.fsencode(path))
+            if lib.r3d_png_gray_decode_batch(arr, 1, raw.ctypes.data, h.value, w.value, 16) == L.OK:
+                img = (raw >> 8).astype(np.uint8)
+        if img is None:
+            try:
+                from PIL import Image
+                pil = Image.open(path)
+                if pil.mode.startswith("I;16") or pil.mode == "I":
+                    img = (np.array(pil).astype(np.uint32) >> 8).clip(0, 255).astype(np.uint8)
+                else:
+                    img = np.array(pil.convert("L"))
+            except FileNotFoundError:
+                img = None
     if img is None:
         raise FileNotFoundError("cannot read depth image %r" % path)
     return np.ascontiguousarray(img)

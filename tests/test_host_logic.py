@@ -256,3 +256,27 @@ def test_native_rgb_png_batch_matches_pil(R, tmp_path):
         R.cloud_io.read_rgb_batch([str(tmp_path / "missing.png")])
     out = np.empty((5, H, W, 3), np.uint8)
     assert R.cloud_io.read_rgb_batch(paths, out=out) is out
+
+
+def test_16_bit_grey_depth_png_keeps_its_high_byte_like_opencv(R, tmp_path):
+    """cv.imread(path, IMREAD_GRAYSCALE) (c2w:160) reads a 16-bit PNG through libpng's strip_16: v >> 8.  PIL's 'L'
+    conversion would clip at 255 instead -- a different depth map.  (Parity unpinned: OpenCV is absent here; the rule is
+    libpng's documented transformation.)"""
+    from PIL import Image
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV present: its own decode is used")
+    except ImportError:
+        pass
+    rng = np.random.default_rng(3)
+    v = rng.integers(0, 65536, (21, 34), dtype=np.uint16)
+    paths = []
+    for k in range(3):
+        p = tmp_path / ("d%d.png" % k)
+        Image.fromarray((v + k).astype(np.uint16)).save(p)
+        paths.append(str(p))
+    np.testing.assert_array_equal(R.cloud_io.read_depth_gray(paths[0]), (v >> 8).astype(np.uint8))
+    got = R.cloud_io.read_depth_batch(paths)
+    assert got.dtype == np.uint8 and got.shape == (3, 21, 34)
+    for k in range(3):
+        np.testing.assert_array_equal(got[k], ((v + k).astype(np.uint16) >> 8).astype(np.uint8))
