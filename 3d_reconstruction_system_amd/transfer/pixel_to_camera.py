@@ -7,7 +7,8 @@ Same entry point and defaults (`./depth/24.png` -> `./point/24.txt` -> `./ply/24
 shipped, the reference script crashes after writing the txt (it calls genply_RGB with three
 arguments, p2c:136 vs :98), its coloured writer needs an un-imported PIL (p2c:58) and
 gentxtcord is hard-wired to 480x640 (p2c:34-35).  Here the raster size comes from the image, both
-writers work, and main() writes the plain PLY the script was evidently meant to produce.
+writers work, and main() does what its three-argument call (points, ./img/24.png, ply path) spells out: the COLOURED PLY
+when that colour image exists, the plain PLY otherwise.
 """
 import os
 import sys
@@ -67,11 +68,15 @@ def main():
     num = 24
     depth_path = './depth/' + str(num) + '.png'
     point_path = './point/' + str(num) + '.txt'
+    imgpath = './img/' + str(num) + '.png'
     pc_file = './ply/' + str(num) + '.ply'
     gt = r3d.cloud_io.read_depth_unchanged(depth_path)
     gray_img = gt[:, :, 1] if gt.ndim == 3 else gt   # p2c:134 takes channel 1 of a 3-channel PNG
     gt_cord = gentxtcord(point_path, gray_img)
-    genply_RGB(gt_cord, pc_file)
+    if os.path.exists(imgpath):
+        genply_noRGB(gt_cord, imgpath, pc_file)      # p2c:136 passes (gt_cord, imgpath, pc_file): the coloured writer's signature
+    else:
+        genply_RGB(gt_cord, pc_file)
 
 
 if __name__ == '__main__':

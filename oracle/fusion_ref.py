@@ -145,6 +145,19 @@ def format_ply(xyz):
     return PLY_HEAD % xyz.shape[0] + body + PLY_TAIL
 
 
+PLY_HEAD_RGB = ("ply\n    format ascii 1.0\n    element vertex %d\n    property float x\n    property float y\n"
+                "    property float z\n    property uchar red\n    property uchar green\n    property uchar blue\n"
+                "    property uchar alpha\n    end_header\n    ")
+
+
+def format_ply_rgb(xyz, rgb):
+    """p2c:55-91 (genply_noRGB, the coloured writer): rows `x y z R G B 0`, no trailing space, same indentation."""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    rgb = np.asarray(rgb).reshape(-1, 3)
+    body = "".join("%.4f %.4f %.4f %d %d %d 0\n" % (p[0], p[1], p[2], int(c[0]), int(c[1]), int(c[2])) for p, c in zip(xyz, rgb))
+    return PLY_HEAD_RGB % xyz.shape[0] + body + PLY_TAIL
+
+
 def read_ply_vertices(path):
     """Parse a PLY written in the reference layout back to float64 [N,3]."""
     with open(path) as f:

@@ -202,3 +202,20 @@ def test_camera_to_world_script_frame_sharded_over_ranks(tmp_path, golden_dir, m
     got = O.read_xyz_txt(str(tmp_path / "point_world" / "small_worldpoint_5_23_5.txt"))
     want = O.read_xyz_txt(os.path.join(scene, "point_world", "small_worldpoint_5_23_5.txt"))
     assert got.shape == want.shape and (np.abs(got - want) / (1 + np.linalg.norm(want, axis=1, keepdims=True))).max() <= 1e-12
+
+
+def test_pixel_to_camera_script_writes_the_coloured_ply_when_the_image_exists(tmp_path):
+    """p2c:136 calls its writer with (points, ./img/24.png, ply path) -- the coloured writer's signature.  With ./img/24.png
+    present the drop-in's main() writes `x y z R G B 0` rows under the uchar header of p2c:71-87; the oracle's formatter
+    (pinned by the reference-generated coloured fixture in tests/test_oracle_golden.py) gives the expected bytes."""
+    from PIL import Image
+    for d in ("depth", "point", "ply", "img"):
+        os.makedirs(tmp_path / d)
+    rng = np.random.default_rng(4)
+    depth = rng.integers(1, 256, (48, 64), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    Image.fromarray(np.stack([depth // 2, depth, depth // 3], 2).astype(np.uint8), "RGB").save(tmp_path / "depth" / "24.png")
+    Image.fromarray(rgb, "RGB").save(tmp_path / "img" / "24.png")
+    out = run_script("transfer/pixel_to_camera.py", str(tmp_path))
+    assert "Write into .ply file Done." in out
+    assert (tmp_path / "ply" / "24.ply").read_bytes() == O.format_ply_rgb(O.unproject(depth), rgb.reshape(-1, 3)).encode()

@@ -127,6 +127,10 @@ def test_p2c_480x640_digest(golden_dir, tmp_path):
         assert tuple(vec[int(k)]) == (x, y, float(z))
     assert g["short_raster_error"] == "IndexError"  # p2c hard-codes 480x640 (p2c:34-35)
     assert O.format_ply(vec[:7]) == open(os.path.join(golden_dir, "p2c_first7.ply")).read()
+    # the coloured writer (genply_noRGB, p2c:55-91) on the reference's own image
+    from PIL import Image
+    rgb = np.array(Image.open(os.path.join(golden_dir, "p2c_rgb_2x3.png")).convert("RGB")).reshape(-1, 3)
+    assert O.format_ply_rgb(vec[:6], rgb) == open(os.path.join(golden_dir, "p2c_first6_rgb.ply")).read()
 
 
 def test_c1_192x640_digest(golden_dir, tmp_path):
