@@ -211,23 +211,36 @@ def write_ply_rgb(path, xyz, rgb):
                                   xyz.shape[0]))
 
 
+def _parse_rows_native(buf, offset, separator):
+    """[N,3] float64 from the text in `buf[offset:]` by the library's threaded parser, or None when a line is not plain
+    'x<sep>y<sep>z[...]' in the subset std::from_chars shares with float() -- the caller then parses it Python's way."""
+    lib = L.load()
+    n, bad = C.c_int64(), C.c_int64()
+    if len(buf) - offset <= 0:
+        return np.empty((0, 3))
+    raw = (C.c_char * len(buf)).from_buffer(buf)          # buf: bytearray (no copy)
+    ptr = C.addressof(raw) + offset
+    nbytes = len(buf) - offset
+    if lib.r3d_parse_xyz_text(ptr, nbytes, ord(separator), None, 0, C.byref(n), None) != L.OK:
+        return None
+    out = np.empty((n.value, 3), dtype=np.float64)
+    rc = lib.r3d_parse_xyz_text(ptr, nbytes, ord(separator), out.ctypes.data, n.value, C.byref(n), C.byref(bad))
+    return out if rc == L.OK else None
+
+
 def read_xyz_txt(path):
     """[N,3] float64 from `X,Y,Z\n` lines: the first three comma-separated fields of every non-empty line, like the
     reference's data_p[0:3] (c2w:97-98, icp:76-80) -- extra fields (e.g. x,y,z,r,g,b) are ignored, a missing final
-    newline is fine, a malformed line raises ValueError naming it."""
-    with open(path, 'r') as f:
-        text = f.read()
-    lines = text.split('\n')
+    newline is fine, a malformed line raises ValueError naming it.  Parsed by the library's host threads
+    (r3d_parse_xyz_text, correctly rounded like float()); a file it declines is parsed line by line here."""
+    with open(path, 'rb') as f:
+        data = bytearray(f.read())
+    got = _parse_rows_native(data, 0, ',')
+    if got is not None:
+        return got
+    lines = data.decode('utf-8', errors='replace').split('\n')
     if lines and lines[-1] == '':
         lines.pop()
-    if not lines:
-        return np.empty((0, 3))
-    if text.count(',') == 2 * len(lines) and '' not in lines:
-        # the common case, exactly three fields on every line: one vectorised parse
-        try:
-            return np.array(','.join(lines).split(','), dtype=np.float64).reshape(-1, 3)
-        except ValueError:
-            pass                                   # fall through to the line-by-line parse for a precise message
     out = np.empty((len(lines), 3))
     n = 0
     for no, line in enumerate(lines, 1):
@@ -245,18 +258,26 @@ def read_xyz_txt(path):
 
 
 def read_ply(path):
-    """Vertices of an ASCII PLY in the reference layout -> [N,3] float64."""
-    with open(path, 'r') as f:
-        lines = f.read().split('\n')
-    n, start = None, None
-    for i, s in enumerate(lines):
-        s = s.strip()
-        if s.startswith('element vertex'):
+    """Vertices of an ASCII PLY in the reference layout -> [N,3] float64 (the first three blank-separated numbers of each
+    of the `element vertex` rows; colour columns are ignored)."""
+    with open(path, 'rb') as f:
+        data = bytearray(f.read())
+    n, start, pos = None, None, 0
+    while pos < len(data):
+        e = data.find(b'\n', pos)
+        e = len(data) if e < 0 else e
+        s = bytes(data[pos:e]).strip()
+        if s.startswith(b'element vertex'):
             n = int(s.split()[-1])
-        if s == 'end_header':
-            start = i + 1
+        pos = e + 1
+        if s == b'end_header':
+            start = pos
             break
     if n is None or start is None:
         raise ValueError("%s: not a PLY with an 'element vertex' header" % path)
-    rows = [s.split()[:3] for s in lines[start:start + n]]
+    got = _parse_rows_native(data, min(start, len(data)), ' ') if start < len(data) else np.empty((0, 3))
+    if got is not None and got.shape[0] == n:
+        return got                                   # the whole body is the vertex list (the reference's layout)
+    lines = data[start:].decode('utf-8', errors='replace').split('\n')
+    rows = [s.split()[:3] for s in lines[:n]]
     return np.array(rows, dtype=np.float64).reshape(-1, 3)

@@ -492,4 +492,163 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
   return R3D_OK;
 }
 
+// ---- the way back: "x,y,z[,...]\n" lines (camera / world txt; read by get_pointdata c2w:92-98 and local_world
+// icp:74-80 as the first three comma-separated fields) or "x y z [...]\n" rows (a PLY body) -> [n][3] fp64.
+// Threads split the text at line boundaries, count their rows, then parse with std::from_chars (correctly rounded,
+// = Python's float()).  Anything from_chars does not take the way float() does (underscores, "Infinity", hex ...)
+// reports its line so that the Python host can re-parse the file its own way: semantics stay Python's, speed is native.
+namespace {
+
+struct ParseSpan {
+  const char* lo;
+  const char* hi;
+  int64_t rows = 0;        // non-blank lines
+  int64_t first_line = 0;  // 1-based number of the span's first line
+  int64_t lines = 0;       // newline-terminated (or final) lines, blank ones included
+};
+
+inline bool blank_line(const char* a, const char* b) {
+  for (; a < b; ++a)
+    if (*a != ' ' && *a != '\t' && *a != '\r') return false;
+  return true;
+}
+
+// one field [a, b) -> double like float(): surrounding blanks allowed, optional '+', nan / inf in any case
+inline bool parse_field(const char* a, const char* b, double* out) {
+  while (a < b && (*a == ' ' || *a == '\t' || *a == '\r')) ++a;
+  while (b > a && (b[-1] == ' ' || b[-1] == '\t' || b[-1] == '\r')) --b;
+  if (a < b && *a == '+') {
+    ++a;
+    if (a < b && (*a == '-' || *a == '+')) return false;
+  }
+  if (a >= b) return false;
+  const std::from_chars_result r = std::from_chars(a, b, *out, std::chars_format::general);
+  if (r.ec == std::errc::result_out_of_range) {  // float() gives +-inf on overflow and +-0.0 (or a subnormal) on underflow
+    char tmp[64];
+    const size_t n = (size_t)(b - a);
+    if (n >= sizeof(tmp)) return false;
+    memcpy(tmp, a, n);
+    tmp[n] = 0;
+    char* end = nullptr;
+    *out = strtod(tmp, &end);
+    return end == tmp + n;
+  }
+  return r.ec == std::errc() && r.ptr == b;
+}
+
+// rows of one span into out; returns 0 or the 1-based line number that did not parse
+int64_t parse_span(const ParseSpan& sp, char sep, double* out) {
+  const char* p = sp.lo;
+  int64_t line = sp.first_line;
+  while (p < sp.hi) {
+    const char* e = static_cast<const char*>(memchr(p, '\n', (size_t)(sp.hi - p)));
+    if (!e) e = sp.hi;
+    if (!blank_line(p, e)) {
+      const char* f = p;
+      for (int k = 0; k < 3; ++k) {
+        const char* g;
+        if (sep == ',') {
+          g = static_cast<const char*>(memchr(f, ',', (size_t)(e - f)));
+          if (!g) g = e;
+          if (k < 2 && g == e) return line;  // fewer than three fields
+        } else {                             // any run of blanks separates
+          while (f < e && (*f == ' ' || *f == '\t' || *f == '\r')) ++f;
+          g = f;
+          while (g < e && *g != ' ' && *g != '\t' && *g != '\r') ++g;
+          if (f == g) return line;
+        }
+        if (!parse_field(f, g, out + k)) return line;
+        f = g < e ? g + 1 : e;
+      }
+      out += 3;
+    }
+    p = e < sp.hi ? e + 1 : sp.hi;
+    ++line;
+  }
+  return 0;
+}
+
+}  // namespace
+
+int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double* h_xyz_out, int64_t cap_points,
+                       int64_t* n_points_out, int64_t* bad_line_out) {
+  if ((n_bytes > 0 && !h_text) || !n_points_out || (separator != ',' && separator != ' ') || cap_points < 0) {
+    r3d_set_error("r3d_parse_xyz_text: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  *n_points_out = 0;
+  if (bad_line_out) *bad_line_out = 0;
+  if (n_bytes == 0) return R3D_OK;
+  try {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned n_threads = std::max(1u, std::min(hw == 0 ? 1u : hw, 16u));
+    if (n_bytes < ((size_t)1 << 20)) n_threads = 1;
+    // spans end just after a newline
+    std::vector<ParseSpan> spans;
+    const char* end = h_text + n_bytes;
+    const char* lo = h_text;
+    for (unsigned t = 0; t < n_threads && lo < end; ++t) {
+      const char* hi = t + 1 == n_threads ? end : h_text + (n_bytes / n_threads) * (t + 1);
+      if (hi < lo) hi = lo;
+      if (hi < end) {
+        const char* nl = static_cast<const char*>(memchr(hi, '\n', (size_t)(end - hi)));
+        hi = nl ? nl + 1 : end;
+      }
+      ParseSpan sp;
+      sp.lo = lo;
+      sp.hi = hi;
+      spans.push_back(sp);
+      lo = hi;
+    }
+    auto count = [](ParseSpan* sp) {
+      const char* p = sp->lo;
+      while (p < sp->hi) {
+        const char* e = static_cast<const char*>(memchr(p, '\n', (size_t)(sp->hi - p)));
+        if (!e) e = sp->hi;
+        if (!blank_line(p, e)) ++sp->rows;
+        ++sp->lines;
+        p = e < sp->hi ? e + 1 : sp->hi;
+      }
+    };
+    {
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < spans.size(); ++t) pool.emplace_back(count, &spans[t]);
+      count(&spans[0]);
+      for (auto& th : pool) th.join();
+    }
+    int64_t total = 0, line = 1;
+    std::vector<int64_t> row0(spans.size());
+    for (size_t t = 0; t < spans.size(); ++t) {
+      row0[t] = total;
+      total += spans[t].rows;
+      spans[t].first_line = line;
+      line += spans[t].lines;
+    }
+    *n_points_out = total;
+    if (!h_xyz_out) return R3D_OK;  // count only
+    if (cap_points < total) {
+      r3d_set_error("r3d_parse_xyz_text: buffer holds %lld points, text has %lld", (long long)cap_points, (long long)total);
+      return R3D_ERR_NOMEM;
+    }
+    std::vector<int64_t> bad(spans.size(), 0);
+    {
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < spans.size(); ++t)
+        pool.emplace_back([&, t]() { bad[t] = parse_span(spans[t], (char)separator, h_xyz_out + 3 * row0[t]); });
+      bad[0] = parse_span(spans[0], (char)separator, h_xyz_out);
+      for (auto& th : pool) th.join();
+    }
+    for (size_t t = 0; t < spans.size(); ++t)
+      if (bad[t]) {
+        if (bad_line_out) *bad_line_out = bad[t];
+        r3d_set_error("r3d_parse_xyz_text: line %lld is not 'x%cy%cz[...]'", (long long)bad[t], (char)separator, (char)separator);
+        return R3D_ERR_INVALID;
+      }
+    return R3D_OK;
+  } catch (const std::exception&) {
+    r3d_set_error("r3d_parse_xyz_text: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
+}
+
 }  // extern "C"

@@ -304,6 +304,13 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
 /* The same text into a caller buffer; two-call protocol like r3d_format_ply. */
 int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
                        char* h_buf, size_t buf_cap, size_t* n_bytes_out);
+/* The way back (f1: "a fast X,Y,Z parser"): rows of text -> [n][3] fp64 on host threads.  separator ',' reads the txt
+ * lines above the way get_pointdata / local_world do (camera_to_world.py:92-98, transfer_T_icp.py:74-80): the first three
+ * comma-separated fields of every non-blank line, extra fields ignored; separator ' ' reads blank-separated rows (the
+ * body of the PLY layout).  Numbers are parsed correctly rounded (= Python float()).  h_xyz_out == NULL only counts.
+ * A line that does not parse returns R3D_ERR_INVALID with its 1-based number in *bad_line_out (may be NULL). */
+int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double* h_xyz_out, int64_t cap_points,
+                       int64_t* n_points_out, int64_t* bad_line_out);
 
 /* ---- f3 ingestion: the depth rasters of camera_to_world.py:160 (`cv.imread(path, IMREAD_GRAYSCALE)`) decoded by host
  * threads.  Native path: non-interlaced greyscale PNG, 8 bits (-> uint8, same bytes as OpenCV) or 16 bits (-> uint16);

@@ -56,6 +56,31 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> zraw((size_t)n);
   for (auto& z : zraw) z = (uint16_t)rng();
   if (r3d_write_xyz_txt("/tmp/r3d_fuzz.txt", vf.data(), R3D_F32, n, zraw.data(), R3D_DEPTH_U16, 0) != R3D_OK) return 1;
+  // the text parser: round trip of the txt just formatted (bit for bit), then random byte damage and truncation
+  {
+    int64_t np_ = 0, bad_line = 0;
+    if (r3d_parse_xyz_text(buf.data(), nb, ',', nullptr, 0, &np_, nullptr) != R3D_OK || np_ != n) return 20;
+    std::vector<double> back((size_t)n * 3);
+    if (r3d_parse_xyz_text(buf.data(), nb, ',', back.data(), n, &np_, &bad_line) != R3D_OK) return 21;
+    for (size_t i = 0; i < v.size(); ++i)
+      if (memcmp(&back[i], &v[i], 8) != 0 && !(std::isnan(back[i]) && std::isnan(v[i]))) return 22;
+    if (r3d_parse_xyz_text(buf.data(), nb, ',', back.data(), n - 1, &np_, nullptr) != R3D_ERR_NOMEM) return 23;
+    std::vector<char> dmg;
+    for (int trial = 0; trial < 300; ++trial) {
+      const size_t len = 1 + rng() % 20000, off = rng() % (nb - len);
+      dmg.assign(buf.begin() + off, buf.begin() + off + len);       // exactly len bytes, no terminator: overreads show up
+      const int flips = (int)(rng() % 6);
+      const char junk[] = ",\n\r +-eE.x_09\0";
+      for (int j = 0; j < flips; ++j) dmg[rng() % dmg.size()] = junk[rng() % (sizeof(junk) - 1)];
+      for (int sep : {(int)',', (int)' '}) {
+        int64_t cnt = 0;
+        if (r3d_parse_xyz_text(dmg.data(), dmg.size(), sep, nullptr, 0, &cnt, nullptr) != R3D_OK) return 24;
+        std::vector<double> o((size_t)cnt * 3 + 3);
+        const int rc = r3d_parse_xyz_text(dmg.data(), dmg.size(), sep, o.data(), cnt, &cnt, &bad_line);
+        if (rc != R3D_OK && rc != R3D_ERR_INVALID) return 25;
+      }
+    }
+  }
   // PNG decoder on a valid file (argv[1]) and on corrupted copies of it
   if (argc > 1) {
     FILE* f = fopen(argv[1], "rb");

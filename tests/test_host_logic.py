@@ -280,3 +280,46 @@ def test_16_bit_grey_depth_png_keeps_its_high_byte_like_opencv(R, tmp_path):
     assert got.dtype == np.uint8 and got.shape == (3, 21, 34)
     for k in range(3):
         np.testing.assert_array_equal(got[k], ((v + k).astype(np.uint16) >> 8).astype(np.uint8))
+
+
+def test_native_txt_and_ply_parsers_agree_with_python_float(R, tmp_path):
+    """f1's 'fast X,Y,Z parser' (r3d_parse_xyz_text): correctly rounded like float() on every spelling repr() and '%.4f'
+    produce plus the ones people type (exponents, '+', blanks, CRLF, nan/inf, overflow, subnormals); anything outside the
+    subset it shares with float() (underscores ...) is handed to the Python parser, so results never differ."""
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([rng.normal(size=3000) * 10.0 ** rng.integers(-30, 30, 3000),
+                           rng.integers(-10**6, 10**6, 300).astype(np.float64),
+                           np.array([0.0, -0.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf, -np.inf, np.nan,
+                                     0.1, 1 / 3, 1e22, 1e23, 123456789012345678.0, 2 ** 53 + 2.0, 9007199254740993.0])])
+    vals = np.resize(vals, (vals.size // 3) * 3).reshape(-1, 3)
+    p = tmp_path / "v.txt"
+    R.cloud_io.write_xyz_txt(str(p), vals)                              # repr() spellings
+    got = R.cloud_io.read_xyz_txt(str(p))
+    np.testing.assert_array_equal(got.view(np.uint64), vals.view(np.uint64))        # bit for bit, NaN and -0.0 included
+    want = [[float(v) for v in line.split(',')[:3]] for line in p.read_text().split('\n') if line.strip()]
+    np.testing.assert_array_equal(got.view(np.uint64), np.array(want).view(np.uint64))
+    odd = ("1e3,+2.5E-2, 3 \r\n  -4,5.,.5,9,9\n\n 1e400,-1e400,1e-400\nNaN,iNf,-infinity\n"
+           "0.1000000000000000055511151231257827,0.30000000000000004,9007199254740993\n7,8,9")
+    p.write_text(odd)
+    want = np.array([[float(v) for v in line.split(',')[:3]] for line in odd.split('\n') if line.strip()])
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)).view(np.uint64), want.view(np.uint64))
+    p.write_text("1_000,2,3\n4,5,6\n")                                  # float() takes underscores, from_chars does not
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)), [[1000, 2, 3], [4, 5, 6]])
+    for bad in ("1,2\n", "1,,3\n", "1,2,x\n", "1,2,3\n4;5;6\n", "+-1,2,3\n"):
+        p.write_text(bad)
+        with pytest.raises(ValueError):
+            R.cloud_io.read_xyz_txt(str(p))
+    # big file: several parser threads, line boundaries in odd places
+    big = rng.normal(size=(200001, 3)) * 100
+    R.cloud_io.write_xyz_txt(str(p), big)
+    np.testing.assert_array_equal(R.cloud_io.read_xyz_txt(str(p)), big)
+    q = tmp_path / "v.ply"
+    R.cloud_io.write_ply(str(q), big)
+    back = R.cloud_io.read_ply(str(q))
+    assert back.shape == big.shape and np.abs(back - big).max() <= 0.5001e-4
+    np.testing.assert_array_equal(back[:100], np.array([[float("%.4f" % v) for v in row] for row in big[:100]]))
+    rgb = rng.integers(0, 256, (1000, 3), dtype=np.uint8)
+    R.cloud_io.write_ply_rgb(str(q), big[:1000], rgb)                   # colour columns are ignored
+    np.testing.assert_array_equal(R.cloud_io.read_ply(str(q)), back[:1000])
+    q.write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nelement face 1\nend_header\n1 2 3\n4 5 6\n3 0 1 1\n")
+    np.testing.assert_array_equal(R.cloud_io.read_ply(str(q)), [[1, 2, 3], [4, 5, 6]])      # rows after the vertices are not vertices
