@@ -513,6 +513,91 @@ inline bool blank_line(const char* a, const char* b) {
   return true;
 }
 
+// Fast path for [-]digits[.digits][e[+-]digits] with at most 19 significant digits and a decimal exponent within +-27:
+// the digits are an exact 64-bit integer w, 10^|q| is exact in x87 extended precision (5^27 < 2^63), so w * 10^q or
+// w / 10^q is ONE correctly rounded operation to a 64-bit significand.  Rounding that once more to double is wrong only
+// if the 64-bit result sits exactly on a midpoint between two doubles (low 11 bits == 0x400) while the true value does
+// not; those (and their neighbours, for good measure) go to the exact path.  Result range 1e-27 .. 1.9e46: always normal.
+inline bool fast_double(const char* a, const char* b, double* out) {
+#if defined(__x86_64__) && __LDBL_MANT_DIG__ == 64
+  static const long double p10[28] = {1e0L,  1e1L,  1e2L,  1e3L,  1e4L,  1e5L,  1e6L,  1e7L,  1e8L,  1e9L,
+                                      1e10L, 1e11L, 1e12L, 1e13L, 1e14L, 1e15L, 1e16L, 1e17L, 1e18L, 1e19L,
+                                      1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+  const char* p = a;
+  bool neg = false;
+  if (p < b && *p == '-') {
+    neg = true;
+    ++p;
+  }
+  uint64_t w = 0;
+  int nd = 0;
+  int64_t q = 0;
+  bool any = false;
+  while (p < b && (unsigned)(*p - '0') < 10u) {
+    any = true;
+    const unsigned d = (unsigned)(*p - '0');
+    if (nd || d) {
+      if (nd == 19) return false;
+      w = w * 10 + d;
+      ++nd;
+    }
+    ++p;
+  }
+  if (p < b && *p == '.') {
+    ++p;
+    while (p < b && (unsigned)(*p - '0') < 10u) {
+      any = true;
+      const unsigned d = (unsigned)(*p - '0');
+      if (nd || d) {
+        if (nd == 19) return false;
+        w = w * 10 + d;
+        ++nd;
+      }
+      --q;
+      ++p;
+    }
+  }
+  if (!any) return false;
+  if (p < b && (*p == 'e' || *p == 'E')) {
+    ++p;
+    bool eneg = false;
+    if (p < b && (*p == '-' || *p == '+')) {
+      eneg = *p == '-';
+      ++p;
+    }
+    if (p >= b) return false;
+    int64_t e = 0;
+    int digits = 0;
+    while (p < b && (unsigned)(*p - '0') < 10u) {
+      if (++digits > 5) return false;
+      e = e * 10 + (*p - '0');
+      ++p;
+    }
+    q += eneg ? -e : e;
+  }
+  if (p != b) return false;
+  if (w == 0) {
+    *out = neg ? -0.0 : 0.0;
+    return true;
+  }
+  if (q < -27 || q > 27) return false;
+  long double r = (long double)w;
+  r = q >= 0 ? r * p10[q] : r / p10[-q];
+  uint64_t mant;
+  memcpy(&mant, &r, sizeof(mant));  // x87 extended, little endian: the 64-bit significand comes first
+  const unsigned low = (unsigned)(mant & 0x7ffu);
+  if (low >= 0x3ffu && low <= 0x401u) return false;
+  const double d = (double)r;
+  *out = neg ? -d : d;
+  return true;
+#else
+  (void)a;
+  (void)b;
+  (void)out;
+  return false;
+#endif
+}
+
 // one field [a, b) -> double like float(): surrounding blanks allowed, optional '+', nan / inf in any case
 inline bool parse_field(const char* a, const char* b, double* out) {
   while (a < b && (*a == ' ' || *a == '\t' || *a == '\r')) ++a;
@@ -522,6 +607,7 @@ inline bool parse_field(const char* a, const char* b, double* out) {
     if (a < b && (*a == '-' || *a == '+')) return false;
   }
   if (a >= b) return false;
+  if (fast_double(a, b, out)) return true;
   const std::from_chars_result r = std::from_chars(a, b, *out, std::chars_format::general);
   if (r.ec == std::errc::result_out_of_range) {  // float() gives +-inf on overflow and +-0.0 (or a subnormal) on underflow
     char tmp[64];

@@ -323,3 +323,26 @@ def test_native_txt_and_ply_parsers_agree_with_python_float(R, tmp_path):
     np.testing.assert_array_equal(R.cloud_io.read_ply(str(q)), back[:1000])
     q.write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nelement face 1\nend_header\n1 2 3\n4 5 6\n3 0 1 1\n")
     np.testing.assert_array_equal(R.cloud_io.read_ply(str(q)), [[1, 2, 3], [4, 5, 6]])      # rows after the vertices are not vertices
+
+
+def test_native_parser_fast_path_is_correctly_rounded_on_a_million_numbers(R, tmp_path):
+    """The parser's fast path (64-bit digits x exact power of ten in extended precision, midpoints sent to the exact path)
+    against float() on the spellings that take it: repr() of ordinary magnitudes, '%.4f', '%.17g', '%.19g' (19 digits),
+    short decimals, and the classic double-rounding traps."""
+    rng = np.random.default_rng(99)
+    x = rng.normal(size=250000) * 10.0 ** rng.integers(-8, 9, 250000)
+    toks = [repr(float(v)) for v in x[:90000]] + ["%.4f" % v for v in x[90000:150000]] + ["%.17g" % v for v in x[150000:200000]] \
+        + ["%.19g" % v for v in x[200000:230000]] + ["%.3e" % v for v in x[230000:250000]]
+    toks += ["9007199254740993", "9007199254740992.5", "9007199254740993.0000001", "0.500000000000000166533453693773481063544750213623046875",
+             "1.00000000000000011102230246251565404236316680908203125", "1.00000000000000011102230246251565404236316680908203124",
+             "4503599627370496.5", "4503599627370497.5", "0.1", "123456789012345678", "1234567890123456789", "12345678901234567890",
+             "1e27", "1e-27", "9999999999999999999e27", "1e28", "0.000", "-0.0", "000012.500", "1.e2", ".5e1", "5E-1"]
+    toks += ["%d.%04d5" % (a, b) for a, b in zip(rng.integers(0, 5000, 30000), rng.integers(0, 10000, 30000))]     # ...5 ties at 1e-5
+    while len(toks) % 3:
+        toks.append("1")
+    p = tmp_path / "m.txt"
+    p.write_text("".join("%s,%s,%s\n" % tuple(toks[i:i + 3]) for i in range(0, len(toks), 3)))
+    got = R.cloud_io.read_xyz_txt(str(p)).reshape(-1)
+    want = np.array([float(t) for t in toks])
+    bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+    assert bad.size == 0, [(toks[k], got[k], want[k]) for k in bad[:5]]
