@@ -6,32 +6,34 @@ other_tools/transfer_T_icp.py:33-43 (get_T).
 """
 import numpy as np
 
-try:  # the reference's own dependency; gives bit-identical matrices when present
-    from scipy.spatial.transform import Rotation as _Rotation
-except Exception:  # pragma: no cover - scipy is optional
-    _Rotation = None
+import math
 
 
 def _rotation_matrix_xyzw(q):
-    q = np.asarray(q, dtype=np.float64).reshape(4)
-    n = np.sqrt(np.dot(q, q))
+    """Rotation matrix of a scalar-last quaternion, normalised first: SciPy's Rotation.from_quat(q).as_matrix() restated
+    operation for operation (sequential 4-term dot, one sqrt, four divisions, then the ten products) -- bit-identical to
+    SciPy 1.15 on 50,000 random quaternions (tests/test_host_logic.py) and to the reference-generated fixture, without
+    paying ~0.2-0.4 s to import scipy.spatial in every drop-in run."""
+    x, y, z, w = [float(v) for v in np.asarray(q, dtype=np.float64).reshape(4)]
+    n = math.sqrt(x * x + y * y + z * z + w * w)
     if not n > 0.0:
         raise ValueError("quaternion has zero norm")
-    x, y, z, w = q / n
+    x /= n
+    y /= n
+    z /= n
+    w /= n
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    xy, zw, xz, yw, yz, xw = x * y, z * w, x * z, y * w, y * z, x * w
     return np.array([
-        [x * x - y * y - z * z + w * w, 2 * (x * y - z * w), 2 * (x * z + y * w)],
-        [2 * (x * y + z * w), -x * x + y * y - z * z + w * w, 2 * (y * z - x * w)],
-        [2 * (x * z - y * w), 2 * (y * z + x * w), -x * x - y * y + z * z + w * w]])
+        [x2 - y2 - z2 + w2, 2 * (xy - zw), 2 * (xz + yw)],
+        [2 * (xy + zw), -x2 + y2 - z2 + w2, 2 * (yz - xw)],
+        [2 * (xz - yw), 2 * (yz + xw), -x2 - y2 + z2 + w2]])
 
 
 def scipy_transfer(quat):
     """Inverse rotation of a scalar-LAST quaternion (normalised first), as an np.matrix
     like the reference returns (c2w:53-55: `np.matrix(R.from_quat(q).as_matrix()).I`)."""
-    if _Rotation is not None:
-        r = _Rotation.from_quat(np.asarray(quat, dtype=np.float64)).as_matrix()
-    else:
-        r = _rotation_matrix_xyzw(quat)
-    return np.matrix(np.linalg.inv(r))
+    return np.matrix(np.linalg.inv(_rotation_matrix_xyzw(quat)))
 
 
 def get_r(q):

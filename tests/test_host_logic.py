@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import PKG
+from helpers import PKG, ROOT
 from oracle import fusion_ref as O
 
 
@@ -21,12 +21,26 @@ def test_scipy_transfer_and_get_r_match_golden(R, golden_dir):
     for q, want in zip(g["quats_xyzw"], g["scipy_transfer"]):
         got = R.scipy_transfer(q)
         assert isinstance(got, np.matrix)
-        np.testing.assert_array_equal(np.asarray(got), np.array(want))      # same scipy + same inverse: bit equal
+        np.testing.assert_array_equal(np.asarray(got), np.array(want))      # SciPy's arithmetic restated + same inverse: bit equal
         np.testing.assert_allclose(np.asarray(got), O.quat_to_rinv(q), atol=2e-15)
     for q, want in zip(g["get_r_wxyz_input"], g["get_r"]):
         np.testing.assert_allclose(np.asarray(R.get_r(q)), np.array(want), atol=2e-15)
     with pytest.raises(ValueError):
         R.scipy_transfer([0, 0, 0, 0])
+
+
+def test_rotation_restatement_is_bitwise_scipy_and_the_package_does_not_import_scipy(R):
+    """poses._rotation_matrix_xyzw restates SciPy's from_quat().as_matrix() operation for operation, so the drop-ins do
+    not pay for importing scipy.spatial; when SciPy is importable here the two must agree bit for bit."""
+    import subprocess, sys
+    code = "import importlib, sys; importlib.import_module(%r); sys.exit(1 if 'scipy' in sys.modules else 0)" % PKG
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT).returncode == 0
+    Rotation = pytest.importorskip("scipy.spatial.transform").Rotation
+    P = importlib.import_module(PKG + ".poses")
+    rng = np.random.default_rng(0)
+    for _ in range(5000):
+        q = rng.normal(size=4) * 10.0 ** rng.uniform(-3, 3)
+        np.testing.assert_array_equal(P._rotation_matrix_xyzw(q), Rotation.from_quat(q).as_matrix())
 
 
 def test_pose_table_layout(R):

@@ -38,3 +38,34 @@ for label, env in (("fused PLY only (R3D_SKIP_INTERMEDIATE=1)", {"R3D_SKIP_INTER
           % (label, dt, F, F * H * W / 1e6, ply / 1e9, F * H * W / dt / 1e6))
 import shutil
 shutil.rmtree(td)
+
+# transfer_T_icp.py --estimate at BASELINE config 3: two 500k-point camera txts -> T_data.txt (GPU ICP from no guess) ->
+# merged world txt + PLY.  File parsing and formatting are the library's host code.
+r3d = importlib.import_module("3d_reconstruction_system_amd")
+td = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+for d in ("point", "point_world", os.path.join("ply", "icp")):
+    os.makedirs(os.path.join(td, d))
+n = int(os.environ.get("ICP_POINTS", "500000"))
+tgt = rng.random((n, 3)) * 20.0
+ax = rng.normal(size=3)
+ax /= np.linalg.norm(ax)
+a = np.deg2rad(10.0)
+K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+Rm = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+tv = rng.normal(size=3)
+tv *= 0.5 / np.linalg.norm(tv)
+src = (tgt[rng.permutation(n)] - tv) @ np.linalg.inv(1.7 * Rm).T
+r3d.cloud_io.write_xyz_txt(os.path.join(td, "point", "0.txt"), (tgt + rng.normal(size=tgt.shape) * 0.01).astype(np.float32))
+r3d.cloud_io.write_xyz_txt(os.path.join(td, "point", "24.txt"), src.astype(np.float32))
+script = os.path.join(ROOT, "3d_reconstruction_system_amd", "other_tools", "transfer_T_icp.py")
+t0 = time.perf_counter()
+r = subprocess.run([sys.executable, script, "--estimate"], cwd=td, capture_output=True, text=True)
+dt = time.perf_counter() - t0
+assert r.returncode == 0, r.stderr[-2000:]
+T = r3d.get_T(os.path.join(td, "T_data.txt"))
+T_true = np.eye(4)
+T_true[:3, :3], T_true[:3, 3] = 1.7 * Rm, tv
+print("transfer_T_icp.py --estimate, two %d-point txt clouds (s=1.7, 10 deg, |t|=0.5): %.2f s wall incl. interpreter start; "
+      "|T - T_true|max = %.1e; merged PLY %.0f MB" % (n, dt, np.abs(T - T_true).max(),
+                                                      os.path.getsize(os.path.join(td, "ply", "icp", "024.ply")) / 1e6))
+shutil.rmtree(td)
