@@ -45,7 +45,7 @@ def test_headline_line_is_complete_and_self_consistent():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Mpoints/s" and cb["value"] > 0 and cb["cpu_model"]
 
 
-def test_multi_rank_code_path_rehearsed_with_one_rccl_rank():
+def test_multi_rank_code_path_rehearsed_with_one_rccl_rank(real_rccl):
     d = run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], env={"R3D_BENCH_FORCE_COLLECTIVES": "1"})
     assert "r3d_comm over RCCL" in d["transport"], d["transport"]
     modes = d["assemble"]

@@ -21,7 +21,7 @@ def R():
     return _r3d()
 
 
-def test_comm_single_rank_allgather_allreduce(R):
+def test_comm_single_rank_allgather_allreduce(R, real_rccl):
     CM = importlib.import_module(PKG + ".comm")
     ctx = R.Context(0)
     comm = CM.Comm(ctx, CM.Comm.unique_id(), 0, 1)
@@ -47,7 +47,7 @@ def test_comm_single_rank_allgather_allreduce(R):
     ctx.close()
 
 
-def test_sharded_engine_over_r3d_transport_single_rank(R):
+def test_sharded_engine_over_r3d_transport_single_rank(R, real_rccl):
     import torch
     CM = importlib.import_module(PKG + ".comm")
     D = importlib.import_module(PKG + ".dist")
@@ -82,16 +82,16 @@ def test_sharded_engine_over_r3d_transport_single_rank(R):
     ctx.close()
 
 
-def test_plain_c_multi_rank_consumer(tmp_path):
+def test_plain_c_multi_rank_consumer(tmp_path, real_rccl):
     exe = str(tmp_path / "comm_2rank")
     libdir = os.path.join(ROOT, PKG)
     build = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                             os.path.join(ROOT, "tests", "c", "comm_2rank.c"), "-o", exe, "-L", libdir, "-lr3d_hip", "-lm",
                             "-Wl,-rpath," + libdir], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr
-    one = subprocess.run([exe, "1", "5"], capture_output=True, text=True, timeout=300)        # a world of one rank
+    one = subprocess.run([exe, "1", "5"], capture_output=True, text=True, timeout=120)        # a world of one rank
     assert one.returncode == 0 and "identical to the single-GPU cloud" in one.stdout, one.stdout + one.stderr
-    two = subprocess.run([exe, "2", "5"], capture_output=True, text=True, timeout=300)        # runs only with >= 2 GPUs
+    two = subprocess.run([exe, "2", "5"], capture_output=True, text=True, timeout=120)        # runs only with >= 2 GPUs
     assert two.returncode in (0, 77), two.stdout + two.stderr
 
 

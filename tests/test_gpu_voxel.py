@@ -147,7 +147,7 @@ def test_radix_sort_u64(ctx, n, bits):
     buf.free()
 
 
-def test_insert_codes_and_single_rank_union(V, ctx):
+def test_insert_codes_and_single_rank_union(V, ctx, real_rccl):
     """Codes of one set folded into another == the set built from both clouds; codes beyond 48 bits are ignored; a world
     of one rank leaves the set as it is."""
     CM = importlib.import_module(PKG + ".comm")
