@@ -8,8 +8,6 @@ device these functions raise.
 Reference arithmetic: transfer/pixel_to_camera.py:24-44, transfer/camera_to_world.py:53-105,
 other_tools/transfer_T_icp.py:10-12,71-97.
 """
-import ctypes as C
-
 import numpy as np
 
 from . import _lib as L

@@ -8,8 +8,6 @@ per-point `tree.updateNode(data, True)` loop becomes one bulk insert on the GPU.
 import os
 import sys
 
-import numpy as np
-
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transfer"))
     import _common  # type: ignore

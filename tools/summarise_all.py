@@ -14,7 +14,6 @@ import json
 import os
 import shutil
 import statistics
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
