@@ -58,6 +58,58 @@ def moments_init(mom_src, mom_tgt):
     return T
 
 
+def _cloud_stats(m):
+    """(centroid, RMS radius, covariance) of a cloud from its 18 self-paired sums."""
+    m = np.asarray(m, dtype=np.float64)
+    n = m[0]
+    mu = m[1:4] / n
+    cov = m[7:16].reshape(3, 3) / n - np.outer(mu, mu)
+    return mu, np.sqrt(max(m[16] / n - mu @ mu, 0.0)), 0.5 * (cov + cov.T)
+
+
+def init_candidates(mom_src, mom_tgt, with_scale=True):
+    """Starting transforms for init="auto": [("moments", T0), ("pca", T1) ... ("pca", T4)].  T0 = moments_init (no rotation).
+    T1..T4 additionally turn the source's principal axes onto the target's -- the four proper rotations V_q S V_p^T,
+    S = diag(+-1, +-1, +-1) (eigenvectors are defined up to sign; mirror images excluded) -- which lets the estimator
+    start from ANY relative orientation when the scene is anisotropic (a room, a street), e.g. a camera-frame cloud
+    against COLMAP's arbitrary world gauge.  On a near-isotropic cloud the axes mean nothing; the cost test in
+    icp_similarity then keeps T0."""
+    mu_p, r_p, cov_p = _cloud_stats(mom_src)
+    mu_q, r_q, cov_q = _cloud_stats(mom_tgt)
+    s = (r_q / r_p if r_p > 0 and r_q > 0 else 1.0) if with_scale else 1.0
+
+    def make(Rm):
+        T = np.eye(4)
+        T[:3, :3] = s * Rm
+        T[:3, 3] = mu_q - s * (Rm @ mu_p)
+        return T
+
+    out = [("moments", make(np.eye(3)))]
+    wp, Vp = np.linalg.eigh(cov_p)
+    wq, Vq = np.linalg.eigh(cov_q)
+    if not (np.all(np.isfinite(wp)) and np.all(np.isfinite(wq))) or wp[2] <= 0 or wq[2] <= 0:
+        return out
+    for sx in (1.0, -1.0):
+        for sy in (1.0, -1.0):
+            S = np.diag([sx, sy, 1.0])
+            Rm = Vq @ S @ Vp.T
+            if np.linalg.det(Rm) < 0:
+                Rm = Vq @ np.diag([sx, sy, -1.0]) @ Vp.T
+            out.append(("pca", make(Rm)))
+    return out
+
+
+def trimmed_mean(d2, keep=0.8):
+    """Mean of the lowest `keep` share of the finite values (fp64); +inf when there are none."""
+    d2 = np.asarray(d2, dtype=np.float64)
+    d2 = np.sort(d2[np.isfinite(d2)])
+    k = int(np.ceil(keep * d2.size))
+    return float(d2[:k].mean()) if k > 0 else float("inf")
+
+
+INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 32768, 0.8, 1.05
+
+
 class NNIndex:
     """Spatially culled exact nearest-neighbour index over a device-resident target cloud (r3d_nn_index)."""
 
@@ -106,6 +158,7 @@ class IcpDevice:
             raise ValueError("target cloud is empty")
         self.n, self.m = src.shape[0], tgt.shape[0]
         self._tgt_host = tgt             # the target never moves: target_spacing() samples it without a D2H
+        self._src_host = src             # the source as handed over (original order and frame): init_costs() samples it
         c = self.ctx
         self.d_src = c.alloc(max(src.nbytes, 16)).upload(src)
         self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
@@ -181,6 +234,36 @@ class IcpDevice:
                 b.free()
         d2 = d2[np.isfinite(d2)]
         return float(np.sqrt(np.median(d2))) if d2.size else 0.0
+
+    def init_costs(self, transforms):
+        """Symmetric, robust misfit of each candidate start (call BEFORE the source is moved): a strided sample of the
+        source moved by T against the target index, plus a strided sample of the target moved by T^-1 against an index of
+        the source (distances brought to target units); each side the mean of the lowest INIT_KEEP share of d2."""
+        c = self.ctx
+        ss = self._src_host[::max(1, self.n // INIT_SAMPLES)]
+        st = self._tgt_host[::max(1, self.m // INIT_SAMPLES)]
+        cap = max(ss.shape[0], st.shape[0])
+        d_ss, d_st = c.alloc(ss.nbytes).upload(ss), c.alloc(st.nbytes).upload(st)
+        d_mv, d_i, d_d = c.alloc(cap * 12), c.alloc(cap * 4), c.alloc(cap * 4)
+        ix_src = NNIndex(c, self.d_src.ptr, self.n)
+        costs = []
+        try:
+            for T in transforms:
+                T = np.ascontiguousarray(T, dtype=np.float64)
+                T_inv = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float64)
+                s2 = float(np.cbrt(abs(np.linalg.det(T[:3, :3])))) ** 2
+                L.check(c.lib.r3d_apply_T(c.handle, d_ss.ptr, L.F32, ss.shape[0], T.ctypes.data, d_mv.ptr, L.F32))
+                self.index.query(d_mv.ptr, ss.shape[0], d_i.ptr, d_d.ptr)
+                fwd = trimmed_mean(d_d.download(np.float32, ss.shape[0]), INIT_KEEP)
+                L.check(c.lib.r3d_apply_T(c.handle, d_st.ptr, L.F32, st.shape[0], T_inv.ctypes.data, d_mv.ptr, L.F32))
+                ix_src.query(d_mv.ptr, st.shape[0], d_i.ptr, d_d.ptr)
+                back = trimmed_mean(d_d.download(np.float32, st.shape[0]), INIT_KEEP) * s2
+                costs.append(fwd + back)
+        finally:
+            ix_src.close()
+            for b in (d_ss, d_st, d_mv, d_i, d_d):
+                b.free()
+        return costs
 
     # ---- reverse direction (symmetric coarse phase): every TARGET point's nearest point of a source snapshot ----
     def back_begin(self):
@@ -311,7 +394,9 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
     Returns (T 4x4, info dict).  Three stages, all on device-resident clouds:
 
       init   "identity": none.  "moments": centroid onto centroid and RMS radius onto RMS radius (closes a scale gap
-             such as monocular depth vs COLMAP units).  "auto" (default): moments, then the symmetric dead-zone stage.
+             such as monocular depth vs COLMAP units).  "auto" (default): the better of the moments start and the four
+             principal-axis alignments (init_candidates: any relative orientation on an anisotropic scene), judged by a
+             symmetric trimmed misfit on samples, then the symmetric dead-zone stage.
              A 4x4 array: that transform.
       coarse (init="auto") SYMMETRIC ICP under the cost max(0, d - dead_zone)^2: source -> target and target ->
              source matches together, each weighted w = max(0, 1 - dead_zone/d).  Matches closer than the target's
@@ -359,6 +444,17 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
             if not with_scale:
                 T_total = np.eye(4)
                 T_total[:3, 3] = mom_t[1:4] / mom_t[0] - mom_s[1:4] / mom_s[0]
+            if mode == "auto" and dev.index is not None and min(dev.n, dev.m) >= 16:
+                # multi-start: the moments transform and the four principal-axis alignments, judged by a symmetric
+                # trimmed misfit on samples; the plain moments start keeps the job unless an axis alignment is clearly better
+                cands = init_candidates(mom_s, mom_t, with_scale)
+                costs = dev.init_costs([T for _n, T in cands])
+                best = int(np.argmin(costs))
+                if costs[0] <= INIT_PREFER_MOMENTS * costs[best]:
+                    best = 0
+                info["init_candidates"] = [(cands[k][0], float(costs[k])) for k in range(len(cands))]
+                info["init_choice"] = best
+                T_total = cands[best][1]
             dev.move_source(T_total)
         mark("init")
         if mode == "auto" and dev.index is not None:

@@ -156,6 +156,56 @@ def target_spacing(tgt, max_queries=32768):
     return float(np.sqrt(np.median(d2)))
 
 
+INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 32768, 0.8, 1.05
+
+
+def init_candidates(P, Q, with_scale=True):
+    """icp.init_candidates restated from the points: the moments start and the four proper principal-axis alignments."""
+    mu_p, mu_q = P.mean(0), Q.mean(0)
+    cov_p, cov_q = (P - mu_p).T @ (P - mu_p) / P.shape[0], (Q - mu_q).T @ (Q - mu_q) / Q.shape[0]
+    r_p, r_q = np.sqrt(np.trace(cov_p)), np.sqrt(np.trace(cov_q))
+    s = (r_q / r_p if r_p > 0 and r_q > 0 else 1.0) if with_scale else 1.0
+
+    def make(Rm):
+        T = np.eye(4)
+        T[:3, :3] = s * Rm
+        T[:3, 3] = mu_q - s * (Rm @ mu_p)
+        return T
+
+    out = [make(np.eye(3))]
+    wp, Vp = np.linalg.eigh(0.5 * (cov_p + cov_p.T))
+    wq, Vq = np.linalg.eigh(0.5 * (cov_q + cov_q.T))
+    if wp[2] <= 0 or wq[2] <= 0:
+        return out
+    for sx in (1.0, -1.0):
+        for sy in (1.0, -1.0):
+            Rm = Vq @ np.diag([sx, sy, 1.0]) @ Vp.T
+            if np.linalg.det(Rm) < 0:
+                Rm = Vq @ np.diag([sx, sy, -1.0]) @ Vp.T
+            out.append(make(Rm))
+    return out
+
+
+def trimmed_mean(d2, keep=0.8):
+    d2 = np.asarray(d2, dtype=np.float64)
+    d2 = np.sort(d2[np.isfinite(d2)])
+    k = int(np.ceil(keep * d2.size))
+    return float(d2[:k].mean()) if k > 0 else float("inf")
+
+
+def init_costs(src, tgt, transforms):
+    """icp.IcpDevice.init_costs restated: symmetric trimmed misfit of each start on strided samples."""
+    ss = src[::max(1, src.shape[0] // INIT_SAMPLES)]
+    st = tgt[::max(1, tgt.shape[0] // INIT_SAMPLES)]
+    costs = []
+    for T in transforms:
+        s2 = float(np.cbrt(abs(np.linalg.det(T[:3, :3])))) ** 2
+        fwd = trimmed_mean(nearest_neighbours(apply_T32(ss, T), tgt)[1], INIT_KEEP)
+        back = trimmed_mean(nearest_neighbours(apply_T32(st, np.linalg.inv(T)), src)[1], INIT_KEEP) * s2
+        costs.append(fwd + back)
+    return costs
+
+
 def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_zone=None, max_coarse=40,
                         coarse_tol=2e-4, trim=None, check_every=4):
     """The build's full estimator restated: moments init -> symmetric dead-zone ICP -> plain ICP
@@ -169,6 +219,14 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
     s0 = r_q / r_p if with_scale else 1.0
     T_total[:3, :3] *= s0
     T_total[:3, 3] = mu_q - s0 * mu_p
+    choice = 0
+    if min(src.shape[0], tgt.shape[0]) >= 16:
+        cands = init_candidates(P, Q, with_scale)
+        costs = init_costs(src, tgt, cands)
+        choice = int(np.argmin(costs))
+        if costs[0] <= INIT_PREFER_MOMENTS * costs[choice]:
+            choice = 0
+        T_total = cands[choice]
     cur = apply_T32(src, T_total)
     d0 = float(dead_zone) if dead_zone is not None else 2.0 * target_spacing(tgt)
     snap = cur.copy()
@@ -210,7 +268,7 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
         if prev is not None and abs(prev - rms) <= tol * max(prev, 1e-30):
             break
         prev = rms
-    return T_total, {"coarse_iterations": coarse, "iterations": fine, "dead_zone": d0}
+    return T_total, {"coarse_iterations": coarse, "iterations": fine, "dead_zone": d0, "init_choice": choice}
 
 
 def synthetic_pair(n_tgt=4000, n_src=3000, seed=7, s=1.7, angle_deg=10.0, t_norm=0.5, noise=0.0, extent=20.0):

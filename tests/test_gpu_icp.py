@@ -346,21 +346,43 @@ def test_device_side_iterations_equal_host_stepped_loop(icp, ctx):
         b.free()
 
 
-def test_full_estimator_matches_oracle_restatement(icp, ctx):
-    """moments -> symmetric dead-zone stage -> plain ICP on the GPU against oracle/icp_ref.icp_similarity_auto, on a
-    cloud dense enough (relative to the 10 degree / 1.7x misalignment) that the coarse stage has work to do."""
+def _cube_surface(rng, n, a):
+    """n points on the six faces of an a-sided cube: a SURFACE (what depth fusion produces) with no preferred axes."""
+    p = rng.random((n, 3)) * a
+    face = rng.integers(0, 6, n)
+    p[np.arange(n), face % 3] = np.where(face < 3, 0.0, a)
+    return p
+
+
+@pytest.mark.parametrize("scene", ["same points", "independent samples of a cube"])
+def test_full_estimator_matches_oracle_restatement(icp, ctx, scene):
+    """multi-start init -> symmetric dead-zone stage -> plain ICP on the GPU against oracle/icp_ref.icp_similarity_auto.
+    "same points": the source is a moved copy of the target's points -- their principal axes agree exactly, an axis alignment
+    is the better start in BOTH implementations and leaves the coarse stage idle.  "independent samples of a cube": two
+    different samplings of a cube's SURFACE -- axes mean nothing, the moments start is kept and the coarse stage has to
+    close 10 degrees / 1.7x; truth is met to the sampling noise, the oracle to 1e-4.  (A FILLED volume sampled twice is a
+    different matter: plain ICP with a free scale is biased there, ~5 % -- clouds from depth fusion are surfaces.)"""
     rng = np.random.default_rng(11)
-    tgt = (rng.random((12000, 3)) * np.array([6.0, 4.0, 3.0])).astype(np.float32)
     _s, _t, T_true, _ = OI.synthetic_pair(n_tgt=8, n_src=4, s=1.7, angle_deg=10.0, t_norm=0.5, seed=7)
     Ti = np.linalg.inv(T_true)
-    src = OI.apply_T32(tgt[rng.permutation(12000)], Ti)
+    if scene == "same points":
+        tgt = (rng.random((8000, 3)) * np.array([6.0, 4.0, 3.0])).astype(np.float32)
+        src = OI.apply_T32(tgt[rng.permutation(8000)], Ti)
+    else:
+        tgt = _cube_surface(rng, 5000, 5.0).astype(np.float32)
+        src = OI.apply_T32(_cube_surface(rng, 5000, 5.0).astype(np.float32), Ti)
     T_ref, info_ref = OI.icp_similarity_auto(src, tgt)
     T, info = icp.icp_similarity(src, tgt, ctx=ctx)
-    assert info["coarse_iterations"] >= 1 and info_ref["coarse_iterations"] >= 1
-    np.testing.assert_allclose(T_ref, T_true, rtol=0, atol=1e-4)
-    np.testing.assert_allclose(T, T_true, rtol=0, atol=1e-4)
+    assert info["init_choice"] == info_ref["init_choice"], (info["init_candidates"], info_ref)
+    assert info["coarse_iterations"] == info_ref["coarse_iterations"]
     np.testing.assert_allclose(T, T_ref, rtol=0, atol=1e-4)
     np.testing.assert_allclose(info["dead_zone"], info_ref["dead_zone"], rtol=1e-5)
+    if scene == "same points":
+        assert info["init_choice"] != 0
+        np.testing.assert_allclose(T, T_true, rtol=0, atol=1e-4)
+    else:
+        assert info["init_choice"] == 0 and info["coarse_iterations"] >= 1, info
+        np.testing.assert_allclose(T, T_true, rtol=0, atol=5e-2)
 
 
 def test_c3_full_size_recipe_recovered_from_identity(icp, ctx):
@@ -369,7 +391,13 @@ def test_c3_full_size_recipe_recovered_from_identity(icp, ctx):
     src, tgt, T_true, _ = c3_clouds(500000)
     T, info = icp.icp_similarity(src, tgt, ctx=ctx)
     assert np.abs(T - T_true).max() <= 1e-3, (np.abs(T - T_true).max(), info)
-    assert info["coarse_iterations"] >= 2 and info["rms_history"][-1] < 0.03
+    assert info["rms_history"][-1] < 0.03
+    # the recipe's source is a moved copy of the target's own points: their principal axes agree even on a cube, so the
+    # multi-start may hand the fine stage an almost exact start (the coarse stage then has nothing to do); pin that the
+    # moments start alone still closes the gap through the coarse stage
+    T2, info2 = icp.icp_similarity(src, tgt, ctx=ctx, init="moments")
+    assert info2["coarse_iterations"] == 0              # "moments" = no coarse stage by definition
+    assert np.abs(T2 - T_true).max() > 1e-2             # ... and plain ICP from it does not get there: the stages matter
     # plain ICP from identity cannot close the 1.7x scale gap
     T_plain, _ = icp.icp_similarity(src, tgt, ctx=ctx, init="identity", max_iter=20)
     assert np.abs(T_plain - T_true).max() > 0.1
@@ -547,3 +575,36 @@ def test_non_finite_points_never_win_and_never_enter_the_sums(icp, ctx):
     m = mom.moments("src")
     mom.free()
     assert m[0] == clean_s.sum() and np.isfinite(m).all()
+
+
+@pytest.mark.parametrize("angle", [60.0, 90.0, 135.0, 180.0])
+def test_any_relative_orientation_on_an_anisotropic_scene(icp, ctx, angle):
+    """init="auto" is a multi-start: the moments transform plus the four proper principal-axis alignments, judged by a
+    symmetric trimmed misfit on samples.  On a room-like scene (8 x 6 x 3 m) the plain moments start has a basin of about
+    60 degrees (measured); with the axis alignments s=1.7 / |t|=0.5 come back at ANY rotation -- a camera-frame cloud against
+    COLMAP's arbitrary world gauge.  No initial guess."""
+    n = 120000
+    tg = _room_cloud(n)
+    rng = np.random.default_rng(int(angle))
+    tgt = (tg + rng.normal(size=tg.shape) * 0.005).astype(np.float32)
+    for seed in (1, 2):
+        _s, _t, T_true, _ = OI.synthetic_pair(n_tgt=8, n_src=4, s=1.7, angle_deg=angle, t_norm=0.5, seed=seed)
+        q = tg[rng.permutation(n)]
+        src = ((q - T_true[:3, 3]) @ np.linalg.inv(T_true[:3, :3]).T).astype(np.float32)
+        T, info = icp.icp_similarity(src, tgt, ctx=ctx)
+        assert np.abs(T - T_true).max() <= 1e-3, (angle, seed, np.abs(T - T_true).max(), info["init_candidates"], info["init_choice"])
+        if angle >= 90.0:
+            assert info["init_choice"] != 0, info["init_candidates"]          # an axis alignment was needed
+
+
+def test_multi_start_keeps_the_moments_start_on_an_isotropic_cloud(icp, ctx):
+    """Two INDEPENDENT samplings of a cube have no principal axes in common: the four axis candidates are arbitrary
+    rotations, their misfit is worse, the moments start keeps the job.  (When the source is a moved copy of the target's own
+    points -- SURVEY's C3 recipe -- the axes agree exactly even on a cube, and an axis start is legitimately chosen.)"""
+    rng = np.random.default_rng(3)
+    _s, _t, T_true, _ = OI.synthetic_pair(n_tgt=8, n_src=4, s=1.7, angle_deg=10.0, t_norm=0.5, seed=3)
+    tgt = _cube_surface(rng, 60000, 20.0).astype(np.float32)
+    src = OI.apply_T32(_cube_surface(rng, 60000, 20.0).astype(np.float32), np.linalg.inv(T_true))
+    T, info = icp.icp_similarity(src, tgt, ctx=ctx)
+    assert info["init_choice"] == 0 and len(info["init_candidates"]) == 5, info["init_candidates"]
+    assert np.abs(T - T_true).max() <= 5e-2, np.abs(T - T_true).max()
