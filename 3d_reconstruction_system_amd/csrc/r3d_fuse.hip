@@ -40,6 +40,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPx = 4;                      // pixels per lane (f32 kernels)
 constexpr int kTile = kThreads * kPx;       // pixels per workgroup tile (all kernels)
+constexpr int kStageAutoMB = 64;            // auto: stage a launch's inputs in the Infinity Cache when they exceed this
+constexpr int kStageChunkMB = 96;           // ... in steps of this many input MB (sweep: profiles/r02_cold_inputs.log)
 
 struct FuseDims {
   double scale;
@@ -53,6 +55,7 @@ struct FuseDims {
   uint32_t t_shift;
   uint32_t total_tiles;     // tiles_per_frame * n_frames (< 2^31)
   uint32_t rgb_vec_ok;      // colour plane: tile bases are 16-byte aligned (hw % 16 == 0 and aligned base pointer)
+  uint32_t depth_vec_ok;    // raster: every whole tile starts 4-byte aligned (hw * sizeof(element) % 4 == 0, aligned base)
 };
 
 __device__ __forceinline__ uint32_t magic_div(uint32_t x, uint32_t magic, uint32_t shift) {
@@ -129,11 +132,43 @@ __device__ __forceinline__ void load_tile(const DT* __restrict__ depth, const Fu
   }
 }
 
-template <typename DT, bool POSE>
+// ---- vector loads + in-wave redistribution (the WAVE-CONTIGUOUS mapping; byte-raster unprojection only) ---------
+// Every wave owns 256 CONSECUTIVE pixels of the tile (lane l, round r -> pixel 256*wave + 64*r + l), brings them in as
+// ONE coalesced dword load per lane (256 B per wave instead of four 64-B crumbs) and each lane fetches its bytes from
+// the lane that holds them with ds_bpermute_b32 -- no LDS allocation, no barrier; stores keep THE shape (one contiguous
+// 768-B run per wave instruction).  Whole, 4-byte-aligned tiles; ragged / unaligned ones take clamped byte loads in the
+// same mapping.  A/B over every kernel, raster in cache and not (profiles/r02_cold_inputs.log): it wins where the
+// arithmetic is lightest -- the pose-less u8 -> f32 unprojection, 7.35 vs 7.09 TB/s -- and loses or ties elsewhere
+// (u8 fused 6.8 vs 7.1, u8 -> f64 5.5 vs 6.6, u16 equal), so only that kernel uses it.
+template <int ROUNDS>
+__device__ __forceinline__ void load_tile_wave(const uint8_t* __restrict__ depth, const FuseDims& dm, uint64_t fbase, uint32_t tf,
+                                               uint32_t tid, uint8_t raw[ROUNDS]) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const bool whole = dm.depth_vec_ok && (tf + 1) * kTile <= dm.hw;  // workgroup-uniform
+  if (whole) {
+    const uint32_t dw = reinterpret_cast<const uint32_t*>(depth + fbase + (uint64_t)tf * kTile)[tid];  // pixels 4*tid ..
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      // pixel 64*r + lane of the wave's 256 sits in the dword of lane 16*r + lane/4, byte lane%4
+      const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + (lane >> 2)) << 2), (int)dw);
+      raw[r] = (uint8_t)(got >> (8u * (lane & 3u)));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const uint32_t p = tf * kTile + 256u * wave + 64u * r + lane;
+      raw[r] = depth[fbase + min(p, dm.hw - 1)];
+    }
+  }
+}
+
+template <typename DT, bool POSE, bool WAVE>
 __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restrict__ depth, float* __restrict__ out,
                                                              const double* __restrict__ u, const double* __restrict__ v,
                                                              const double* __restrict__ pose, const FuseDims dm) {
   const uint32_t tid = threadIdx.x;
+  const uint32_t first = WAVE ? 256u * (tid >> 6) + (tid & 63u) : tid;  // this lane's pixel of round 0 within the tile
+  constexpr uint32_t kRound = WAVE ? 64u : (uint32_t)kThreads;           // pixel step between its rounds
   for (uint32_t tile = blockIdx.x; tile < dm.total_tiles; tile += gridDim.x) {
     const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
     const uint32_t tf = tile - frame * dm.tiles_per_frame;
@@ -141,10 +176,13 @@ __global__ __launch_bounds__(kThreads) void fuse_lane_kernel(const DT* __restric
     load_pose<POSE>(pose, frame, P);
     const uint64_t fbase = (uint64_t)frame * dm.hw;
     DT raw[kPx];
-    load_tile<DT, kPx, 0, (POSE || sizeof(DT) > 1)>(depth, dm, tile, tid, raw);  // measured per variant, see load_tile
+    if constexpr (WAVE)
+      load_tile_wave<kPx>(depth, dm, fbase, tf, tid, raw);
+    else
+      load_tile<DT, kPx, 0, (POSE || sizeof(DT) > 1)>(depth, dm, tile, tid, raw);  // measured per variant, see load_tile
 #pragma unroll
     for (int r = 0; r < kPx; ++r) {
-      const uint32_t p = tf * kTile + r * kThreads + tid;
+      const uint32_t p = tf * kTile + r * kRound + first;
       if (p < dm.hw) {
         const uint32_t j = magic_div(p, dm.w_magic, dm.w_shift);
         const uint32_t i = p - j * dm.width;
@@ -301,6 +339,34 @@ __global__ __launch_bounds__(kThreads) void rgb_expand_kernel(const uint8_t* __r
   }
 }
 
+// ---- staging the inputs in the Infinity Cache -------------------------------------------------------------------
+// Measured (tools/cold_inputs.hip, tools/mall_effect.py): when the raster is NOT already in the 256 MiB Infinity Cache,
+// its reads -- 8 % of the bytes -- arrive at the HBM controllers sprinkled among twelve times as many writes and the
+// fused kernel drops from 7.0 to 4.0-4.4 TB/s (prefetching tiles ahead inside the kernel, vector loads, other launch
+// geometries: no help -- it is not latency, it is read/write mixing at the DRAM).  A read-only sweep of the inputs
+// FIRST (5.6 TB/s: 9 us for C2's 49 MB) leaves them in the Infinity Cache, the fused kernel that follows reads them
+// from there and sends a pure write stream to HBM: 6.2 TB/s for the pair, cold.  Big batches go chunk by chunk.
+__global__ __launch_bounds__(kThreads) void cache_touch_kernel(const uint4* __restrict__ src, uint64_t n16,
+                                                               uint32_t* __restrict__ sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * kThreads) {
+    const uint4 q = src[i];
+    acc ^= q.x ^ q.y ^ q.z ^ q.w;
+  }
+  if (acc == 0x9e3779b9u && n16 == ~(uint64_t)0) *sink = acc;  // never true: keeps the loads, writes nothing
+}
+
+// whole 16-byte pieces inside [p, p + bytes): the ragged ends share their cache lines with the pieces next to them
+void cache_touch(r3d_ctx* ctx, const void* p, uint64_t bytes) {
+  const uintptr_t lo = ((uintptr_t)p + 15) & ~(uintptr_t)15, hi = ((uintptr_t)p + bytes) & ~(uintptr_t)15;
+  if (hi <= lo) return;
+  const uint64_t n16 = (hi - lo) / 16;
+  uint64_t blocks = (n16 + kThreads - 1) / kThreads;
+  if (blocks > (uint64_t)ctx->num_cus * 8) blocks = (uint64_t)ctx->num_cus * 8;
+  hipLaunchKernelGGL(cache_touch_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream,
+                     reinterpret_cast<const uint4*>(lo), n16, static_cast<uint32_t*>(nullptr));
+}
+
 struct FusePtrs {
   const void* depth;
   void* out;
@@ -312,25 +378,33 @@ struct FusePtrs {
 };
 
 template <typename DT, bool POSE>
-void launch_typed(const FusePtrs& p, const FuseDims& dm, int out_dtype, int blocks, hipStream_t s) {
+void launch_typed(const FusePtrs& p, const FuseDims& dm, int out_dtype, int blocks, bool wave, hipStream_t s) {
   const DT* d = static_cast<const DT*>(p.depth);
-  if (out_dtype == R3D_F64)
+  if (out_dtype == R3D_F64) {
     hipLaunchKernelGGL((fuse_pair_kernel<DT, POSE>), dim3(blocks), dim3(kThreads), 0, s, d, static_cast<double*>(p.out), p.u,
                        p.v, p.pose, dm);
-  else if (p.rgb)
+  } else if (p.rgb) {
     hipLaunchKernelGGL((fuse_rgb_kernel<DT, POSE>), dim3(blocks), dim3(kThreads), 0, s, d, p.rgb, static_cast<float*>(p.out),
                        p.rgba, p.u, p.v, p.pose, dm);
-  else
-    hipLaunchKernelGGL((fuse_lane_kernel<DT, POSE>), dim3(blocks), dim3(kThreads), 0, s, d, static_cast<float*>(p.out), p.u,
-                       p.v, p.pose, dm);
+  } else {
+    if constexpr (std::is_same<DT, uint8_t>::value && !POSE) {
+      if (wave) {
+        hipLaunchKernelGGL((fuse_lane_kernel<DT, POSE, true>), dim3(blocks), dim3(kThreads), 0, s, d, static_cast<float*>(p.out),
+                           p.u, p.v, p.pose, dm);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((fuse_lane_kernel<DT, POSE, false>), dim3(blocks), dim3(kThreads), 0, s, d, static_cast<float*>(p.out),
+                       p.u, p.v, p.pose, dm);
+  }
 }
 
 template <bool POSE>
-void launch_depth(const FusePtrs& p, const FuseDims& dm, int depth_dtype, int out_dtype, int blocks, hipStream_t s) {
+void launch_depth(const FusePtrs& p, const FuseDims& dm, int depth_dtype, int out_dtype, int blocks, bool wave, hipStream_t s) {
   switch (depth_dtype) {
-    case R3D_DEPTH_U8: launch_typed<uint8_t, POSE>(p, dm, out_dtype, blocks, s); break;
-    case R3D_DEPTH_U16: launch_typed<uint16_t, POSE>(p, dm, out_dtype, blocks, s); break;
-    default: launch_typed<float, POSE>(p, dm, out_dtype, blocks, s); break;
+    case R3D_DEPTH_U8: launch_typed<uint8_t, POSE>(p, dm, out_dtype, blocks, wave, s); break;
+    case R3D_DEPTH_U16: launch_typed<uint16_t, POSE>(p, dm, out_dtype, blocks, wave, s); break;
+    default: launch_typed<float, POSE>(p, dm, out_dtype, blocks, wave, s); break;
   }
 }
 
@@ -359,31 +433,64 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   R3D_REQUIRE(d_depth && d_out, "NULL device pointer");
   R3D_REQUIRE(!with_pose || d_pose, "pose table is NULL");
   const uint64_t hw = (uint64_t)cam->height * cam->width;
-  FusePtrs p{d_depth, d_out, cam->d_u, cam->d_v, with_pose ? d_pose : nullptr, d_rgb, d_rgba};
-  FuseDims dm;
-  dm.scale = depth_scale;
-  dm.hw = (uint32_t)hw;
-  dm.width = (uint32_t)cam->width;
-  dm.tiles_per_frame = (uint32_t)((hw + kTile - 1) / kTile);
-  dm.n_frames = (uint32_t)n_frames;
-  make_magic(dm.width, &dm.w_magic, &dm.w_shift);
-  make_magic(dm.tiles_per_frame, &dm.t_magic, &dm.t_shift);
-  const uint64_t total_tiles = (uint64_t)dm.tiles_per_frame * n_frames;
-  R3D_REQUIRE(total_tiles < ((uint64_t)1 << 31), "batch too large for one launch (%llu tiles); split the frames",
-              (unsigned long long)total_tiles);
-  dm.total_tiles = (uint32_t)total_tiles;
-  dm.rgb_vec_ok = d_rgb && ((uintptr_t)d_rgb % 16 == 0) && (hw % 16 == 0);
+  const uint64_t dsz = r3d_depth_size(depth_dtype), osz = 3 * (uint64_t)r3d_xyz_size(out_dtype);
+  {
+    const uint64_t all_tiles = ((hw + kTile - 1) / kTile) * (uint64_t)n_frames;
+    R3D_REQUIRE(all_tiles < ((uint64_t)1 << 31), "batch too large for one launch (%llu tiles); split the frames",
+                (unsigned long long)all_tiles);
+  }
   const bool colour_after = d_rgb && out_dtype == R3D_F64;  // f64 xyz: colour goes through its own pass
-  if (colour_after) p.rgb = nullptr;
-  // measured (profiles/r02_c5_probe.log, r02_ab_kernels.log, r02_all_kernels.json): one tile per workgroup for every kernel
-  // but the pose-less byte-raster f32 one (unproject only: 89 us with 8 striding workgroups per CU, 100 us at one tile each)
-  const bool stride8 = !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
-  uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : stride8 ? (uint64_t)ctx->num_cus * 8 : total_tiles;
-  if (blocks > total_tiles) blocks = total_tiles;
-  if (with_pose)
-    launch_depth<true>(p, dm, depth_dtype, out_dtype, (int)blocks, ctx->stream);
-  else
-    launch_depth<false>(p, dm, depth_dtype, out_dtype, (int)blocks, ctx->stream);
+  // byte-raster unprojection: dword loads + in-wave redistribution (load_tile_wave); knob 1 = element loads (A/B)
+  const bool wave = ctx->fuse_loads != 1 && !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !(d_rgb && !colour_after);
+  // inputs staged through the Infinity Cache chunk by chunk (cache_touch_kernel): auto = when one launch's inputs are more
+  // than a cache that also has the write stream passing through will have kept from an earlier pass anyway
+  const uint64_t in_per_frame = hw * (dsz + ((d_rgb && !colour_after) ? 3 : 0));
+  const uint64_t in_bytes = in_per_frame * (uint64_t)n_frames;
+  const uint64_t chunk_bytes = (uint64_t)(ctx->fuse_chunk_mb > 0 ? ctx->fuse_chunk_mb : kStageChunkMB) << 20;
+  // ... AND the inputs are a small share of the traffic: the sweep is an extra pass over them (measured at 1000 frames,
+  // profiles/r02_cold_inputs.log: u8 4.3 -> 6.4 TB/s, u8 + colour 3.8 -> 5.5, u16 4.8 -> 6.3, f32 depth -> f64 xyz 4.4 -> 5.6,
+  // but f32 depth + colour (7 of 23 B/point are inputs) 5.7 -> 5.0: that one stays as it is)
+  const bool small_inputs = dsz <= 2 || (out_dtype == R3D_F64 && !(d_rgb && !colour_after));
+  const bool stage = ctx->fuse_prefetch == 2 ||
+                     (ctx->fuse_prefetch == 0 && small_inputs && in_bytes > ((uint64_t)kStageAutoMB << 20));
+  int frames_per_step = n_frames;
+  if (stage) {
+    const uint64_t f = chunk_bytes / (in_per_frame ? in_per_frame : 1);
+    frames_per_step = (int)(f < 1 ? 1 : (f > (uint64_t)n_frames ? (uint64_t)n_frames : f));
+  }
+  for (int f0 = 0; f0 < n_frames; f0 += frames_per_step) {
+    const int nf = n_frames - f0 < frames_per_step ? n_frames - f0 : frames_per_step;
+    const uint64_t px0 = hw * (uint64_t)f0;
+    const char* dd = static_cast<const char*>(d_depth) + px0 * dsz;
+    const uint8_t* rr = d_rgb ? d_rgb + px0 * 3 : nullptr;
+    FusePtrs p{dd, static_cast<char*>(d_out) + px0 * osz, cam->d_u, cam->d_v, with_pose ? d_pose + (uint64_t)f0 * 12 : nullptr,
+               colour_after ? nullptr : rr, d_rgba ? d_rgba + px0 : nullptr};
+    FuseDims dm;
+    dm.scale = depth_scale;
+    dm.hw = (uint32_t)hw;
+    dm.width = (uint32_t)cam->width;
+    dm.tiles_per_frame = (uint32_t)((hw + kTile - 1) / kTile);
+    dm.n_frames = (uint32_t)nf;
+    make_magic(dm.width, &dm.w_magic, &dm.w_shift);
+    make_magic(dm.tiles_per_frame, &dm.t_magic, &dm.t_shift);
+    const uint64_t total_tiles = (uint64_t)dm.tiles_per_frame * nf;
+    dm.total_tiles = (uint32_t)total_tiles;
+    dm.rgb_vec_ok = rr && ((uintptr_t)rr % 16 == 0) && (hw % 16 == 0);
+    dm.depth_vec_ok = ((uintptr_t)dd % 4 == 0) && ((hw * dsz) % 4 == 0);
+    if (stage) {
+      cache_touch(ctx, dd, hw * dsz * (uint64_t)nf);
+      if (p.rgb) cache_touch(ctx, rr, hw * 3 * (uint64_t)nf);
+    }
+    // measured (profiles/r02_c5_probe.log, r02_ab_kernels.log, r02_all_kernels.json): one tile per workgroup for every kernel
+    // (the element-load form of the byte-raster unprojection, kept for A/B, likes 8 striding workgroups per CU)
+    const bool stride8 = !wave && !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
+    uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : stride8 ? (uint64_t)ctx->num_cus * 8 : total_tiles;
+    if (blocks > total_tiles) blocks = total_tiles;
+    if (with_pose)
+      launch_depth<true>(p, dm, depth_dtype, out_dtype, (int)blocks, wave, ctx->stream);
+    else
+      launch_depth<false>(p, dm, depth_dtype, out_dtype, (int)blocks, wave, ctx->stream);
+  }
   if (colour_after) {
     const uint64_t n = hw * (uint64_t)n_frames;
     uint64_t b = (n + kTile - 1) / kTile;

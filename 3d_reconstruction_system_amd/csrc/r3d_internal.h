@@ -19,6 +19,9 @@ struct r3d_ctx {
   int num_cus = 256;
   // tuning knobs (r3d_ctx_set_tuning)
   int fuse_blocks = 0;   // 0 auto
+  int fuse_loads = 0;    // 0 auto (vector loads + in-wave redistribution where the raster allows), 1 element loads (A/B)
+  int fuse_prefetch = 0; // 0 auto, 1 off, 2 on: stage the inputs of a launch in the Infinity Cache with a read-only sweep first
+  int fuse_chunk_mb = 0; // 0 auto: input bytes staged (and fused) per step when the prefetch is on
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;

@@ -524,6 +524,34 @@ def main():
     kernel_ms, kernel_mean_ms, kernel_n = kernel_duration_ms(torch, stream, fuse)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
+    # The same launch when the raster is NOT already in the 256 MiB Infinity Cache (the timed loop re-reads one 49 MB
+    # raster every step, so after the first step it is): every launch takes a different copy, 16 copies = 786 MB.  Plain,
+    # and with the library's input staging forced on (fuse_prefetch=2; auto turns it on above 64 MB of inputs per launch).
+    cold = None
+    if world == 1 and a.out_dtype == "float32":
+        try:
+            copies = [depth] + [depth.clone() for _ in range(15)]
+            state = {"i": 0}
+
+            def fuse_rotating():
+                d = copies[state["i"] % len(copies)]
+                state["i"] += 1
+                r3d.fuse_frames_device(ctx, cam, d.data_ptr(), np.uint8, F, table.data_ptr(), shard.data_ptr(), out_np)
+            cold = {"raster_copies": len(copies)}
+            for key, knob in (("plain", 1), ("staged", 2)):
+                ctx.set_tuning("fuse_prefetch", knob)
+                ms, _mean, _n = kernel_duration_ms(torch, stream, fuse_rotating, min_launches=300, min_ms=30.0, warm=32)
+                cold[key + "_ms"] = round(ms, 5)
+                cold[key + "_frac"] = round(bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            cold["note"] = ("each launch reads a different copy of the raster (first touch of fresh frames); 'staged' = a read-only "
+                            "sweep puts the launch's inputs into the Infinity Cache first (library default above 64 MB of inputs "
+                            "per launch; this C2 launch reads 49 MB)")
+            del copies
+        except Exception as e:  # pragma: no cover
+            cold = {"failed": "%s: %s" % (type(e).__name__, str(e)[:100])}
+        finally:
+            ctx.set_tuning("fuse_prefetch", 0)
+
     # which kernel the library dispatched for this launch (r3d_fuse.hip picks by output type)
     kernel_label = "fuse_lane_kernel<u8,f32,pose>" if a.out_dtype == "float32" else "fuse_pair_kernel<u8,f64,pose>"
 
@@ -565,7 +593,10 @@ def main():
                                    "after 50 untimed launches, before the timed region" % kernel_n,
                          # a K-launch burst after a fence starts on an empty Infinity Cache write buffer (~256 MB =
                          # ~40 us head start), so a short timed region can undercut the sustained median by ~1 %
-                         "kernel_ms_over_ms_per_step": round(kernel_ms / (elapsed / a.steps * 1e3), 4)},
+                         "kernel_ms_over_ms_per_step": round(kernel_ms / (elapsed / a.steps * 1e3), 4),
+                         "inputs": "the step re-reads ONE 49 MB raster, which therefore sits in the 256 MiB Infinity Cache from "
+                                   "the second launch on; see cold_inputs",
+                         "cold_inputs": cold},
             "gpu_ms_per_step": round(gpu_ms_per_step, 5),
             "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),
         }

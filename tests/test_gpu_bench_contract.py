@@ -41,6 +41,10 @@ def test_headline_line_is_complete_and_self_consistent():
     assert abs(d["value"] - 100 * 384 * 1280 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
     assert 0.5 < rf["frac"] < 1.0
     assert rf["traffic"] is None or 0.99 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.02
+    # the line also says what the same launch does when its raster is NOT in the Infinity Cache, plain and with input staging
+    cold = rf["cold_inputs"]
+    assert cold["raster_copies"] * 49152000 > 2 * 256 * 2 ** 20
+    assert 0.3 < cold["plain_frac"] < cold["staged_frac"] <= rf["frac"] + 0.02, cold
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Mpoints/s" and cb["value"] > 0 and cb["cpu_model"]
 

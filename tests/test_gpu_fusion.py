@@ -494,3 +494,44 @@ def test_seeded_random_shape_sweep_every_kernel(R, ctx):
         cam_xyz, rgba2 = R.fuse_frames_rgb(d, rgb, intrinsics=K, out_dtype=odtype, ctx=ctx)
         np.testing.assert_array_equal(cam_xyz, got_u)
         np.testing.assert_array_equal(rgba2, rgba)
+
+
+@pytest.mark.parametrize("ddtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("odtype", [np.float32, np.float64])
+def test_input_staging_in_chunks_never_changes_a_bit(R, ctx, ddtype, odtype):
+    """Big batches have their inputs swept into the Infinity Cache chunk by chunk before each chunk is fused (fuse_prefetch /
+    fuse_chunk_mb; auto above 64 MB of inputs).  Forced on with 1 MB chunks here: several chunks, a ragged last one, frame
+    offsets into every array (raster, pose table, xyz, colour, rgba) -- the results must equal the single launch bit for bit."""
+    rng = np.random.default_rng(5)
+    F, H, W = 37, 96, 130                                       # 12,480 pixels per frame: not a multiple of the 1024-pixel tile
+    d = make_depth(rng, (F, H, W), ddtype)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10
+    try:
+        ctx.set_tuning("fuse_prefetch", 1)
+        want = R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx)
+        want_u = R.unproject(d, out_dtype=odtype, ctx=ctx)
+        want_c = R.fuse_frames_rgb(d, rgb, q, t, out_dtype=odtype, ctx=ctx)
+        ctx.set_tuning("fuse_prefetch", 2)
+        ctx.set_tuning("fuse_chunk_mb", 1)
+        np.testing.assert_array_equal(R.fuse_frames(d, q, t, out_dtype=odtype, ctx=ctx), want)
+        np.testing.assert_array_equal(R.unproject(d, out_dtype=odtype, ctx=ctx), want_u)
+        got_c = R.fuse_frames_rgb(d, rgb, q, t, out_dtype=odtype, ctx=ctx)
+        np.testing.assert_array_equal(got_c[0], want_c[0])
+        np.testing.assert_array_equal(got_c[1], want_c[1])
+        # the device entry points with everything resident (the host ones above go through the 32 MiB pipeline chunks)
+        cam = ctx.camera(H, W, *R.REF_INTRINSICS)
+        tab = R.pose_table(q, t)
+        d_depth, d_pose = ctx.alloc(d.nbytes).upload(d), ctx.alloc(tab.nbytes).upload(tab)
+        d_rgb, d_rgba = ctx.alloc(rgb.nbytes).upload(rgb), ctx.alloc(F * H * W * 4)
+        d_out = ctx.alloc(F * H * W * 3 * np.dtype(odtype).itemsize)
+        R.fuse_frames_device(ctx, cam, d_depth.ptr, ddtype, F, d_pose.ptr, d_out.ptr, odtype)
+        np.testing.assert_array_equal(d_out.download(odtype, F * H * W * 3).reshape(-1, 3), want)
+        R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, ddtype, F, d_pose.ptr, d_rgb.ptr, d_out.ptr, odtype, d_rgba.ptr)
+        np.testing.assert_array_equal(d_out.download(odtype, F * H * W * 3).reshape(-1, 3), want_c[0])
+        np.testing.assert_array_equal(d_rgba.download(np.uint32, F * H * W), want_c[1])
+        for b in (d_depth, d_pose, d_rgb, d_rgba, d_out):
+            b.free()
+    finally:
+        ctx.set_tuning("fuse_prefetch", 0)
+        ctx.set_tuning("fuse_chunk_mb", 0)

@@ -1,0 +1,224 @@
+// A/B for the headline kernel (u8 depth -> f32 xyz, pose) when the raster does NOT sit in the 256 MiB Infinity Cache:
+// every launch reads a different copy of the C2 raster (K copies, K x 49 MB >> the cache), as a first touch of fresh
+// frames does.  Variants: the library; persistent workgroups that prefetch the raster D tiles ahead (element loads or
+// one dword per lane + ds_bpermute); one tile per workgroup with the loads of TWO tiles' worth in flight.
+// Build: make -C tools cold_inputs   Run: tools/cold_inputs [K copies=16] [frames=100]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <vector>
+
+#include "r3d.h"
+
+#define CK(x)                                                                                  \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess) {                                                                    \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+      exit(1);                                                                                 \
+    }                                                                                          \
+  } while (0)
+#define RK(x)                                                                                  \
+  do {                                                                                         \
+    int rc_ = (x);                                                                             \
+    if (rc_ != R3D_OK) {                                                                       \
+      fprintf(stderr, "r3d error %d: %s at %s:%d\n", rc_, r3d_last_error(), __FILE__, __LINE__); \
+      exit(1);                                                                                 \
+    }                                                                                          \
+  } while (0)
+
+constexpr int kThreads = 256, kPx = 4, kTile = kThreads * kPx;
+struct Pose { double r[9], t[3]; };
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ void load_pose(const double* __restrict__ pose, uint32_t frame, Pose& P) {
+  const double* pp = pose + (uint64_t)frame * 12;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P.r[k] = pp[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P.t[k] = pp[9 + k];
+}
+__device__ __forceinline__ void point(double z, double u, double v, const Pose& p, double o[3]) {
+  const double x = u * z, y = v * z;
+  const double dx = x - p.t[0], dy = y - p.t[1], dz = z - p.t[2];
+  o[0] = fma(p.r[2], dz, fma(p.r[1], dy, p.r[0] * dx));
+  o[1] = fma(p.r[5], dz, fma(p.r[4], dy, p.r[3] * dx));
+  o[2] = fma(p.r[8], dz, fma(p.r[7], dy, p.r[6] * dx));
+}
+
+// hw must be a multiple of 1024 here (C2: 491520 = 480 tiles per frame); the tool checks.
+// D = prefetch distance in tiles (0: load, then use); VEC: one dword per lane + bpermute, wave-contiguous mapping.
+template <int D, bool VEC>
+__global__ __launch_bounds__(kThreads) void fuse_pf(const uint8_t* __restrict__ depth, float* __restrict__ out,
+                                                    const double* __restrict__ u, const double* __restrict__ v,
+                                                    const double* __restrict__ pose, uint32_t hw, uint32_t width,
+                                                    uint32_t tiles_per_frame, uint32_t total_tiles) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t first = VEC ? 256u * wave + lane : tid, step = VEC ? 64u : 256u;
+  auto load = [&](uint32_t tile) -> uint32_t {
+    const uint8_t* base = depth + (uint64_t)tile * kTile;  // tiles are contiguous across frames when hw % 1024 == 0
+    if (VEC) return reinterpret_cast<const uint32_t*>(base)[tid];
+    return (uint32_t)base[tid] | ((uint32_t)base[tid + 256] << 8) | ((uint32_t)base[tid + 512] << 16) | ((uint32_t)base[tid + 768] << 24);
+  };
+  constexpr int kQ = D > 0 ? D : 1;
+  uint32_t pend[kQ];
+  const uint32_t G = gridDim.x;
+  if (D > 0) {
+#pragma unroll
+    for (int d = 0; d < kQ; ++d) pend[d] = (blockIdx.x + d * G < total_tiles) ? load(blockIdx.x + d * G) : 0u;
+  }
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += G) {
+    uint32_t cur;
+    if (D > 0) {
+      cur = pend[0];
+#pragma unroll
+      for (int d = 0; d + 1 < kQ; ++d) pend[d] = pend[d + 1];
+      const uint32_t nxt = tile + (uint32_t)D * G;
+      pend[kQ - 1] = nxt < total_tiles ? load(nxt) : 0u;
+    } else {
+      cur = load(tile);
+    }
+    const uint32_t frame = tile / tiles_per_frame, tf = tile - frame * tiles_per_frame;
+    Pose P;
+    load_pose(pose, frame, P);
+    const uint64_t fbase = (uint64_t)frame * hw;
+#pragma unroll
+    for (int r = 0; r < kPx; ++r) {
+      uint32_t z8;
+      if (VEC) {
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * r + (lane >> 2)) << 2), (int)cur);
+        z8 = (got >> (8 * (lane & 3u))) & 0xffu;
+      } else {
+        z8 = (cur >> (8 * r)) & 0xffu;
+      }
+      const uint32_t p = tf * kTile + r * step + first;
+      const uint32_t j = p / width, i = p - j * width;
+      double w[3];
+      point((double)z8, u[i], v[j], P, w);
+      asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + (fbase + p) * 3), "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]})
+                   : "memory");
+    }
+  }
+}
+
+// read-only sweep that pulls a buffer into the Infinity Cache (16 B per lane, grid-stride); the sum keeps the loads alive
+__global__ __launch_bounds__(kThreads) void touch_kernel(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * kThreads) {
+    const uint4 q = src[i];
+    acc ^= q.x ^ q.y ^ q.z ^ q.w;
+  }
+  if (acc == 0x9e3779b9u) *sink = acc;  // practically never: no store traffic
+}
+
+template <typename F>
+float time_ms(hipStream_t st, F&& launch, int iters) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 64; ++i) launch(i);
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  for (int i = 0; i < iters; ++i) launch(i);
+  CK(hipEventRecord(b, st));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+int main(int argc, char** argv) {
+  const int K = argc > 1 ? atoi(argv[1]) : 16, F = argc > 2 ? atoi(argv[2]) : 100;
+  const int H = 384, W = 1280;
+  const uint64_t hw = (uint64_t)H * W, n = hw * F;
+  if (hw % kTile) return 2;
+  r3d_ctx* ctx = nullptr;
+  RK(r3d_ctx_create(0, nullptr, 0, &ctx));
+  void* stv = nullptr;
+  RK(r3d_ctx_stream(ctx, &stv));
+  hipStream_t st = (hipStream_t)stv;
+  r3d_camera* cam = nullptr;
+  RK(r3d_camera_create(ctx, H, W, 600.391, 600.079, 320, 240, &cam));
+  std::mt19937 rng(1234);
+  std::vector<uint8_t> depth(n);
+  for (auto& d : depth) d = (uint8_t)(1 + rng() % 255);
+  std::vector<double> pose((size_t)F * 12), u(W), v(H);
+  std::normal_distribution<double> nd;
+  for (int f = 0; f < F; ++f) {
+    double q[4], nn = 0;
+    for (auto& x : q) { x = nd(rng); nn += x * x; }
+    nn = sqrt(nn);
+    const double x = q[0] / nn, y = q[1] / nn, z = q[2] / nn, w = q[3] / nn;
+    double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                   2 * (y * z - x * w),     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    for (int k = 0; k < 9; ++k) pose[f * 12 + k] = R[(k % 3) * 3 + k / 3];
+    for (int k = 0; k < 3; ++k) pose[f * 12 + 9 + k] = nd(rng) * 10;
+  }
+  for (int i = 0; i < W; ++i) u[i] = ((double)i - 320) / 600.391;
+  for (int j = 0; j < H; ++j) v[j] = ((double)j - 240) / 600.079;
+  std::vector<uint8_t*> d_in(K);
+  for (auto& p : d_in) {
+    CK(hipMalloc(&p, n));
+    CK(hipMemcpy(p, depth.data(), n, hipMemcpyHostToDevice));
+  }
+  double *d_pose, *d_u, *d_v;
+  float *d_ref, *d_out;
+  CK(hipMalloc(&d_pose, pose.size() * 8));
+  CK(hipMalloc(&d_u, W * 8));
+  CK(hipMalloc(&d_v, H * 8));
+  CK(hipMalloc(&d_ref, n * 12));
+  CK(hipMalloc(&d_out, n * 12));
+  CK(hipMemcpy(d_pose, pose.data(), pose.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_u, u.data(), W * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_v, v.data(), H * 8, hipMemcpyHostToDevice));
+  const uint32_t tpf = (uint32_t)(hw / kTile), total = tpf * F;
+  RK(r3d_fuse_frames(ctx, cam, d_in[0], R3D_DEPTH_U8, F, 1.0, d_pose, d_ref, R3D_F32));
+  CK(hipStreamSynchronize(st));
+  struct Cand { const char* name; std::function<void(int)> fn; };
+  auto K_ = [&](auto kern, int grid) {
+    return [=, &d_in](int i) {
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, st, d_in[i % d_in.size()], d_out, d_u, d_v, d_pose, (uint32_t)hw, (uint32_t)W, tpf, total);
+    };
+  };
+  const int cus = 256;
+  std::vector<Cand> cands = {
+      {"library (1 tile/WG)", [&](int i) { RK(r3d_fuse_frames(ctx, cam, d_in[i % K], R3D_DEPTH_U8, F, 1.0, d_pose, d_out, R3D_F32)); }},
+      {"no prefetch, 1 tile/WG", K_(fuse_pf<0, false>, (int)total)},
+      {"no prefetch, 8 WG/CU", K_(fuse_pf<0, false>, cus * 8)},
+      {"prefetch 2, 8 WG/CU", K_(fuse_pf<2, false>, cus * 8)},
+      {"dword prefetch 2, 32 WG/CU", K_(fuse_pf<2, true>, cus * 32)},
+      {"dword no prefetch, 1 tile/WG", K_(fuse_pf<0, true>, (int)total)},
+  };
+  uint32_t* d_sink;
+  CK(hipMalloc(&d_sink, 4));
+  for (int wg : {1, 2, 4, 8})
+    cands.push_back({wg == 1 ? "touch (1 WG/CU) + library" : wg == 2 ? "touch (2 WG/CU) + library" : wg == 4 ? "touch (4 WG/CU) + library" : "touch (8 WG/CU) + library",
+                     [&, wg](int i) {
+                       hipLaunchKernelGGL(touch_kernel, dim3(cus * wg), dim3(kThreads), 0, st, reinterpret_cast<const uint4*>(d_in[i % K]), n / 16, d_sink);
+                       RK(r3d_fuse_frames(ctx, cam, d_in[i % K], R3D_DEPTH_U8, F, 1.0, d_pose, d_out, R3D_F32));
+                     }});
+  cands.push_back({"touch only (8 WG/CU)", [&](int i) { hipLaunchKernelGGL(touch_kernel, dim3(cus * 8), dim3(kThreads), 0, st, reinterpret_cast<const uint4*>(d_in[i % K]), n / 16, d_sink); }});
+  std::vector<char> ha(n * 12), hb(n * 12);
+  CK(hipMemcpy(ha.data(), d_ref, n * 12, hipMemcpyDeviceToHost));
+  for (auto& c : cands) {
+    CK(hipMemsetAsync(d_out, 0xff, n * 12, st));
+    c.fn(0);
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(hb.data(), d_out, n * 12, hipMemcpyDeviceToHost));
+    printf("  %-30s %s\n", c.name, memcmp(ha.data(), hb.data(), n * 12) == 0 ? "bit-identical" : "MISMATCH");
+  }
+  for (int mode = 0; mode < 2; ++mode) {
+    printf("== %s inputs (%d cop%s of the %.0f MB raster)\n", mode ? "COLD" : "HOT", mode ? K : 1, mode && K > 1 ? "ies" : "y", n / 1e6);
+    for (int round = 0; round < 2; ++round)
+      for (auto& c : cands) {
+        const float ms = time_ms(st, [&](int i) { c.fn(mode ? i : 0); }, 320);
+        printf("  round %d  %-30s %.4f ms  %.2f TB/s\n", round, c.name, ms, n * 13 / ms / 1e9);
+      }
+  }
+  return 0;
+}
