@@ -346,6 +346,10 @@ def main():
                          "then fuse all frames locally (same bits); '*_direct' = grouped send/recv per peer instead of "
                          "ncclAllGather; 'none' = shards stay resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cold-inputs", action="store_true",
+                    help="also time the launch with 16 rotating copies of the raster (not in the Infinity Cache), plain and with the "
+                         "library's input staging forced on; off by default so that a profile of the default command holds only "
+                         "the launches the line's kernel_ms describes (committed run: profiles/r02_cold_inputs.log)")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel", "c5"],
                     help="fuse (default, the headline C2 line); the others print one JSON line for a secondary kernel on "
@@ -528,7 +532,7 @@ def main():
     # raster every step, so after the first step it is): every launch takes a different copy, 16 copies = 786 MB.  Plain,
     # and with the library's input staging forced on (fuse_prefetch=2; auto turns it on above 64 MB of inputs per launch).
     cold = None
-    if world == 1 and a.out_dtype == "float32":
+    if a.cold_inputs and world == 1 and a.out_dtype == "float32":
         try:
             copies = [depth] + [depth.clone() for _ in range(15)]
             state = {"i": 0}
@@ -595,7 +599,9 @@ def main():
                          # ~40 us head start), so a short timed region can undercut the sustained median by ~1 %
                          "kernel_ms_over_ms_per_step": round(kernel_ms / (elapsed / a.steps * 1e3), 4),
                          "inputs": "the step re-reads ONE 49 MB raster, which therefore sits in the 256 MiB Infinity Cache from "
-                                   "the second launch on; see cold_inputs",
+                                   "the second launch on.  With a different copy per launch (first touch of fresh frames) the same "
+                                   "launch measures frac 0.51 plain and 0.80 with the library's input staging (default above 64 MB "
+                                   "of inputs per launch): python bench.py --cold-inputs; profiles/r02_cold_inputs.log",
                          "cold_inputs": cold},
             "gpu_ms_per_step": round(gpu_ms_per_step, 5),
             "kernel_only_Mpoints_s_per_gpu": round(n_local / kernel_ms / 1e3, 1),

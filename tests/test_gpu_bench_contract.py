@@ -25,7 +25,7 @@ def run_bench(args, env=None):
 
 
 def test_headline_line_is_complete_and_self_consistent():
-    d = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    d = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--cold-inputs"])
     for k in REQUIRED + ["cpu_baseline"]:
         assert k in d, k
     assert d["metric"].startswith("Mpoints/s fused (1280x384 depth") and d["unit"] == "Mpoints/s"

@@ -39,6 +39,7 @@ def timed(ctx, fn, iters):
 
 def main():
     short = "--short" in sys.argv          # PMC passes: few launches per kernel, no brute-force NN
+    extra = "--extra" in sys.argv          # also the big-batch / staged launches (NOT under rocprofv3: same kernel names, other sizes)
     ctx = r3d.Context(0)
     rng = np.random.default_rng(1234)
     out = {}
@@ -58,13 +59,38 @@ def main():
     d_xyz64 = ctx.alloc(n * 24)
     ms = timed(ctx, lambda: r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz64.ptr, np.float64), 50)
     out["fuse_u8_f64"] = {"ms": ms, "GBps": n * 25 / ms / 1e6, "Gpts": n / ms / 1e6, "bound": "hbm", "bytes_per_point": 25}
+    if extra:
+        # C4 on ONE GPU: 1000 frames (491.5 M points, 6.4 GB of traffic) -- far beyond the Infinity Cache, inputs staged (default)
+        F4 = 1000
+        n4 = F4 * H * W
+        d_depth4, d_xyz4 = ctx.alloc(n4), ctx.alloc(n4 * 12)
+        L.check(ctx.lib.r3d_memset(ctx.handle, d_depth4.ptr, 0x41, n4))
+        tab4 = r3d.pose_table(rng.normal(size=(F4, 4)), rng.normal(size=(F4, 3)) * 10)
+        d_pose4 = ctx.alloc(tab4.nbytes).upload(tab4)
+        for knob, key in ((0, "fuse_u8_f32_1000_frames"), (1, "fuse_u8_f32_1000_frames_unstaged")):
+            ctx.set_tuning("fuse_prefetch", knob)
+            ms = timed(ctx, lambda: r3d.fuse_frames_device(ctx, cam, d_depth4.ptr, np.uint8, F4, d_pose4.ptr, d_xyz4.ptr, np.float32), 20)
+            out[key] = {"ms": ms, "GBps": n4 * 13 / ms / 1e6, "Gpts": n4 / ms / 1e6, "bound": "hbm", "bytes_per_point": 13}
+        ctx.set_tuning("fuse_prefetch", 0)
+        for b in (d_depth4, d_xyz4, d_pose4):
+            b.free()
     d_xyz64.free()
     # colour carried through the fused launch (+7 B/point)
     rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
     d_rgb, d_rgba = ctx.alloc(rgb.nbytes).upload(rgb), ctx.alloc(n * 4)
+    # this loop re-reads the same 196 MB of inputs: with the staging sweep off they are served by the Infinity Cache (the
+    # round-1/2 figure); the library's default stages inputs of that size (they would not be cached in a real pass)
+    ctx.set_tuning("fuse_prefetch", 1)
     ms = timed(ctx, lambda: r3d.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr,
                                                        np.float32, d_rgba.ptr), 20 if short else 100)
-    out["fuse_rgb_u8_f32"] = {"ms": ms, "GBps": n * 20 / ms / 1e6, "Gpts": n / ms / 1e6, "bound": "hbm", "bytes_per_point": 20}
+    out["fuse_rgb_u8_f32"] = {"ms": ms, "GBps": n * 20 / ms / 1e6, "Gpts": n / ms / 1e6, "bound": "hbm", "bytes_per_point": 20,
+                              "inputs": "cached (same buffers every launch), staging off"}
+    ctx.set_tuning("fuse_prefetch", 0)
+    if extra:
+        ms = timed(ctx, lambda: r3d.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr,
+                                                           np.float32, d_rgba.ptr), 20 if short else 100)
+        out["fuse_rgb_u8_f32_default"] = {"ms": ms, "GBps": n * 20 / ms / 1e6, "Gpts": n / ms / 1e6, "bound": "hbm", "bytes_per_point": 20,
+                                      "inputs": "library default: 196 MB of inputs per launch are staged through the Infinity Cache"}
     d_rgb.free()
     d_rgba.free()
     r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)

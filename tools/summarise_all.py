@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # algorithmic bytes per launch of tools/profile_all.py's launches (C2: 49,152,000 points; C3: 500k x 500k)
 N_C2 = 100 * 384 * 1280
 ALGO = {
-    "fuse_lane_kernel<unsigned char, true>": ("fused unproject+SE(3), u8 -> f32 xyz", N_C2 * 13),
-    "fuse_lane_kernel<unsigned char, false>": ("unproject only, u8 -> f32 xyz", N_C2 * 13),
+    "fuse_lane_kernel<unsigned char, true, false>": ("fused unproject+SE(3), u8 -> f32 xyz", N_C2 * 13),
+    "fuse_lane_kernel<unsigned char, false, true>": ("unproject only, u8 -> f32 xyz (dword loads + ds_bpermute)", N_C2 * 13),
     "fuse_pair_kernel<unsigned char, true>": ("fused, u8 -> f64 xyz (lane pairs)", N_C2 * 25),
     "fuse_rgb_kernel<unsigned char, true>": ("fused + colour, u8 depth + rgb -> f32 xyz + rgba", N_C2 * 20),
     "apply_lane_kernel<float, false>": ("apply-T 4x4, f32 -> f32", N_C2 * 24),
