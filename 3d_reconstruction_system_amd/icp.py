@@ -238,27 +238,31 @@ class IcpDevice:
     def init_costs(self, transforms):
         """Symmetric, robust misfit of each candidate start (call BEFORE the source is moved): a strided sample of the
         source moved by T against the target index, plus a strided sample of the target moved by T^-1 against an index of
-        the source (distances brought to target units); each side the mean of the lowest INIT_KEEP share of d2."""
+        the source (distances brought to target units); each side the mean of the lowest INIT_KEEP share of d2.
+        All candidates share ONE query per direction (their moved samples are laid end to end): two queries, not ten."""
         c = self.ctx
         ss = self._src_host[::max(1, self.n // INIT_SAMPLES)]
         st = self._tgt_host[::max(1, self.m // INIT_SAMPLES)]
-        cap = max(ss.shape[0], st.shape[0])
+        k, ns, nt = len(transforms), ss.shape[0], st.shape[0]
+        cap = k * max(ns, nt)
         d_ss, d_st = c.alloc(ss.nbytes).upload(ss), c.alloc(st.nbytes).upload(st)
         d_mv, d_i, d_d = c.alloc(cap * 12), c.alloc(cap * 4), c.alloc(cap * 4)
         ix_src = NNIndex(c, self.d_src.ptr, self.n)
-        costs = []
         try:
-            for T in transforms:
-                T = np.ascontiguousarray(T, dtype=np.float64)
-                T_inv = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float64)
+            Ts = [np.ascontiguousarray(T, dtype=np.float64) for T in transforms]
+            for j, T in enumerate(Ts):
+                L.check(c.lib.r3d_apply_T(c.handle, d_ss.ptr, L.F32, ns, T.ctypes.data, d_mv.ptr + j * ns * 12, L.F32))
+            self.index.query(d_mv.ptr, k * ns, d_i.ptr, d_d.ptr)
+            fwd = d_d.download(np.float32, k * ns).reshape(k, ns)
+            invs = [np.ascontiguousarray(np.linalg.inv(T), dtype=np.float64) for T in Ts]
+            for j, Ti in enumerate(invs):
+                L.check(c.lib.r3d_apply_T(c.handle, d_st.ptr, L.F32, nt, Ti.ctypes.data, d_mv.ptr + j * nt * 12, L.F32))
+            ix_src.query(d_mv.ptr, k * nt, d_i.ptr, d_d.ptr)
+            back = d_d.download(np.float32, k * nt).reshape(k, nt)
+            costs = []
+            for j, T in enumerate(Ts):
                 s2 = float(np.cbrt(abs(np.linalg.det(T[:3, :3])))) ** 2
-                L.check(c.lib.r3d_apply_T(c.handle, d_ss.ptr, L.F32, ss.shape[0], T.ctypes.data, d_mv.ptr, L.F32))
-                self.index.query(d_mv.ptr, ss.shape[0], d_i.ptr, d_d.ptr)
-                fwd = trimmed_mean(d_d.download(np.float32, ss.shape[0]), INIT_KEEP)
-                L.check(c.lib.r3d_apply_T(c.handle, d_st.ptr, L.F32, st.shape[0], T_inv.ctypes.data, d_mv.ptr, L.F32))
-                ix_src.query(d_mv.ptr, st.shape[0], d_i.ptr, d_d.ptr)
-                back = trimmed_mean(d_d.download(np.float32, st.shape[0]), INIT_KEEP) * s2
-                costs.append(fwd + back)
+                costs.append(trimmed_mean(fwd[j], INIT_KEEP) + trimmed_mean(back[j], INIT_KEEP) * s2)
         finally:
             ix_src.close()
             for b in (d_ss, d_st, d_mv, d_i, d_d):
