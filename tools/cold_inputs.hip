@@ -53,7 +53,7 @@ __device__ __forceinline__ void point(double z, double u, double v, const Pose& 
 
 // hw must be a multiple of 1024 here (C2: 491520 = 480 tiles per frame); the tool checks.
 // D = prefetch distance in tiles (0: load, then use); VEC: one dword per lane + bpermute, wave-contiguous mapping.
-template <int D, bool VEC>
+template <int D, bool VEC, int POL = 0>
 __global__ __launch_bounds__(kThreads) void fuse_pf(const uint8_t* __restrict__ depth, float* __restrict__ out,
                                                     const double* __restrict__ u, const double* __restrict__ v,
                                                     const double* __restrict__ pose, uint32_t hw, uint32_t width,
@@ -62,7 +62,17 @@ __global__ __launch_bounds__(kThreads) void fuse_pf(const uint8_t* __restrict__ 
   const uint32_t first = VEC ? 256u * wave + lane : tid, step = VEC ? 64u : 256u;
   auto load = [&](uint32_t tile) -> uint32_t {
     const uint8_t* base = depth + (uint64_t)tile * kTile;  // tiles are contiguous across frames when hw % 1024 == 0
-    if (VEC) return reinterpret_cast<const uint32_t*>(base)[tid];
+    if (VEC) {
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(base) + tid;
+      uint32_t v;
+      if (POL == 0) return *a;
+      if (POL == 1) asm volatile("global_load_dword %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+      if (POL == 2) asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+      if (POL == 3) asm volatile("global_load_dword %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+      if (POL == 4) asm volatile("global_load_dword %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+      if (POL == 5) asm volatile("global_load_dword %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+      return v;
+    }
     return (uint32_t)base[tid] | ((uint32_t)base[tid + 256] << 8) | ((uint32_t)base[tid + 512] << 16) | ((uint32_t)base[tid + 768] << 24);
   };
   constexpr int kQ = D > 0 ? D : 1;
@@ -193,6 +203,11 @@ int main(int argc, char** argv) {
       {"prefetch 2, 8 WG/CU", K_(fuse_pf<2, false>, cus * 8)},
       {"dword prefetch 2, 32 WG/CU", K_(fuse_pf<2, true>, cus * 32)},
       {"dword no prefetch, 1 tile/WG", K_(fuse_pf<0, true>, (int)total)},
+      {"dword nt, 1 tile/WG", K_(fuse_pf<0, true, 1>, (int)total)},
+      {"dword sc1, 1 tile/WG", K_(fuse_pf<0, true, 2>, (int)total)},
+      {"dword sc0 sc1, 1 tile/WG", K_(fuse_pf<0, true, 3>, (int)total)},
+      {"dword sc0, 1 tile/WG", K_(fuse_pf<0, true, 4>, (int)total)},
+      {"dword sc0 sc1 nt, 1 tile/WG", K_(fuse_pf<0, true, 5>, (int)total)},
   };
   uint32_t* d_sink;
   CK(hipMalloc(&d_sink, 4));
