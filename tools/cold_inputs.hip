@@ -217,6 +217,29 @@ int main(int argc, char** argv) {
                        hipLaunchKernelGGL(touch_kernel, dim3(cus * wg), dim3(kThreads), 0, st, reinterpret_cast<const uint4*>(d_in[i % K]), n / 16, d_sink);
                        RK(r3d_fuse_frames(ctx, cam, d_in[i % K], R3D_DEPTH_U8, F, 1.0, d_pose, d_out, R3D_F32));
                      }});
+  // the sweep of launch i+1 on a side stream WHILE launch i fuses (pipelined staging): does overlapping hide the sweep,
+  // or does its read burst disturb the write stream as the sprinkled reads did?
+  hipStream_t side;
+  CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  hipEvent_t ev_touched[2], ev_fused[2];
+  for (int k = 0; k < 2; ++k) {
+    CK(hipEventCreateWithFlags(&ev_touched[k], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&ev_fused[k], hipEventDisableTiming));
+  }
+  cands.push_back({"pipelined: sweep i+1 || fuse i", [&](int i) {
+                     // sweep for launch i was enqueued during launch i-1 (or here for the first)
+                     static int primed = -1;
+                     if (primed != i) {
+                       hipLaunchKernelGGL(touch_kernel, dim3(cus * 8), dim3(kThreads), 0, side, reinterpret_cast<const uint4*>(d_in[i % K]), n / 16, d_sink);
+                       CK(hipEventRecord(ev_touched[i & 1], side));
+                     }
+                     CK(hipStreamWaitEvent(st, ev_touched[i & 1], 0));
+                     RK(r3d_fuse_frames(ctx, cam, d_in[i % K], R3D_DEPTH_U8, F, 1.0, d_pose, d_out, R3D_F32));
+                     // next sweep starts now, beside this fuse
+                     hipLaunchKernelGGL(touch_kernel, dim3(cus * 8), dim3(kThreads), 0, side, reinterpret_cast<const uint4*>(d_in[(i + 1) % K]), n / 16, d_sink);
+                     CK(hipEventRecord(ev_touched[(i + 1) & 1], side));
+                     primed = i + 1;
+                   }});
   cands.push_back({"touch only (8 WG/CU)", [&](int i) { hipLaunchKernelGGL(touch_kernel, dim3(cus * 8), dim3(kThreads), 0, st, reinterpret_cast<const uint4*>(d_in[i % K]), n / 16, d_sink); }});
   std::vector<char> ha(n * 12), hb(n * 12);
   CK(hipMemcpy(ha.data(), d_ref, n * 12, hipMemcpyDeviceToHost));
