@@ -50,6 +50,7 @@ SIGNATURES = {
     "r3d_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memset": (_i, [_vp, _vp, _i, _sz]),
+    "r3d_cache_prefetch": (_i, [_vp, _vp, _sz]),
     "r3d_host_alloc": (_i, [_vp, _sz, _pvp]),
     "r3d_host_free": (_i, [_vp, _vp]),
     "r3d_timer_start": (_i, [_vp]),

@@ -584,6 +584,16 @@ int r3d_selftest_magic_div(uint32_t d, uint32_t x, uint32_t* q_out) {
   return R3D_OK;
 }
 
+int r3d_cache_prefetch(r3d_ctx* ctx, const void* d_ptr, size_t bytes) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  if (bytes == 0) return R3D_OK;
+  R3D_REQUIRE(d_ptr != nullptr, "NULL device pointer");
+  cache_touch(ctx, d_ptr, bytes);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
 int r3d_unproject(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
                   double depth_scale, void* d_xyz_out, int out_dtype) {
   return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, nullptr, false, d_xyz_out, out_dtype);

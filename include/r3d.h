@@ -81,6 +81,11 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);
 int r3d_ctx_get_tuning(r3d_ctx* ctx, const char* key, int* value_out);
 
+/* Read-only sweep of a device buffer on the ctx stream: leaves (up to ~100 MB of) it in the 256 MiB Infinity Cache, so that a
+ * write-heavy kernel enqueued next reads it from there instead of mixing reads into its HBM write stream (the fused kernels do
+ * this themselves for big batches, see "fuse_prefetch").  Asynchronous; changes nothing. */
+int r3d_cache_prefetch(r3d_ctx* ctx, const void* d_ptr, size_t bytes);
+
 /* ---- device memory + timing helpers (so a ctypes host needs nothing but this library) */
 int r3d_dev_alloc(r3d_ctx* ctx, size_t bytes, void** d_ptr_out);
 int r3d_dev_free(r3d_ctx* ctx, void* d_ptr);

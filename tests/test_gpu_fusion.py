@@ -535,3 +535,17 @@ def test_input_staging_in_chunks_never_changes_a_bit(R, ctx, ddtype, odtype):
     finally:
         ctx.set_tuning("fuse_prefetch", 0)
         ctx.set_tuning("fuse_chunk_mb", 0)
+
+
+def test_cache_prefetch_is_a_pure_read(R, ctx):
+    """r3d_cache_prefetch sweeps a device buffer (any alignment, any length) and changes nothing."""
+    L = importlib.import_module(R.__name__ + "._lib")
+    rng = np.random.default_rng(8)
+    data = rng.integers(0, 256, 1_000_003, dtype=np.uint8)
+    buf = ctx.alloc(data.nbytes).upload(data)
+    for off, nbytes in ((0, data.nbytes), (1, data.nbytes - 1), (7, 9), (3, 0), (16, 4096), (5, 100000)):
+        L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, buf.ptr + off, nbytes))
+    np.testing.assert_array_equal(buf.download(np.uint8, data.nbytes), data)
+    with pytest.raises(R.R3DError):
+        L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, None, 16))
+    buf.free()
