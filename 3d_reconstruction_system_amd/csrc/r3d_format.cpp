@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -377,7 +378,9 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
   // format and write in slabs of 8 M points so the text never needs more than ~0.5 GB of host memory
   const int64_t slab = (int64_t)8 << 20;
   std::string header;
-  std::vector<std::string> chunks;
+  std::vector<std::string> buf[2];
+  std::thread writer;  // outside the try: it must be joined on every way out
+  bool wrote_ok = true;
   bool ok = true;
   try {
     char head[256];
@@ -387,13 +390,23 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
              (long long)n_points);
     ok = fwrite(head, 1, strlen(head), f) == strlen(head);
     const size_t esz = dtype == R3D_F32 ? 4 : 8;
-    for (int64_t lo = 0; ok && lo < n_points; lo += slab) {
+    // two text buffers: slab k is written by a helper thread while slab k+1 is being formatted
+    int cur = 0;
+    for (int64_t lo = 0; ok && lo < n_points; lo += slab, cur ^= 1) {
       const int64_t cnt = std::min(slab, n_points - lo);
-      format_chunks(static_cast<const char*>(h_xyz) + (size_t)lo * 3 * esz, dtype, cnt, &header, &chunks);
-      for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+      format_chunks(static_cast<const char*>(h_xyz) + (size_t)lo * 3 * esz, dtype, cnt, &header, &buf[cur]);
+      if (writer.joinable()) writer.join();  // the other buffer is free again once its slab is on disk
+      ok = ok && wrote_ok;
+      const std::vector<std::string>* src = &buf[cur];
+      writer = std::thread([src, f, &wrote_ok]() {
+        for (const auto& c : *src) wrote_ok = wrote_ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+      });
     }
+    if (writer.joinable()) writer.join();
+    ok = ok && wrote_ok;
     ok = ok && fwrite("\n    ", 1, 5, f) == 5;
-  } catch (const std::bad_alloc&) {
+  } catch (const std::exception&) {  // bad_alloc, or no thread to be had
+    if (writer.joinable()) writer.join();
     fclose(f);
     r3d_set_error("r3d_write_ply: out of host memory");
     return R3D_ERR_NOMEM;
