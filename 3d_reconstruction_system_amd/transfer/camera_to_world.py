@@ -124,6 +124,19 @@ def fuse_pose_file(qt_path, depth_dir='./depth/', out_dtype=np.float64):
     return names, depths, world
 
 
+def _write_camera_txts(names, cam, depths, per):
+    """./point/<stem>.txt for every frame: a few files at a time (the native formatter releases the GIL; one 491,520-point
+    frame keeps ~7 of its threads busy, so four in flight fill the host without oversubscribing it)."""
+    from concurrent.futures import ThreadPoolExecutor
+    integral = depths.dtype in (np.uint8, np.uint16)
+
+    def one(k):
+        r3d.cloud_io.write_xyz_txt('./point/' + names[k][0:-4] + '.txt', cam[k * per:(k + 1) * per],
+                                   z_raw=depths[k] if integral else None)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(one, range(len(names))))
+
+
 def _get_file_name_sharded(qt_path):
     """get_file_name when a launcher started one process per GPU (WORLD_SIZE > 1): BASELINE config 4."""
     D = _common.module("dist")
@@ -137,9 +150,7 @@ def _get_file_name_sharded(qt_path):
         if hi > lo:
             per = depths.shape[1] * depths.shape[2]
             cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=ctx)
-            for k in range(hi - lo):          # this rank's frames only
-                r3d.cloud_io.write_xyz_txt('./point/' + names[lo + k][0:-4] + '.txt', cam[k * per:(k + 1) * per],
-                                           z_raw=depths[k] if depths.dtype in (np.uint8, np.uint16) else None)
+            _write_camera_txts(names[lo:hi], cam, depths, per)          # this rank's frames only
         if comm.rank == 0:
             per = world.shape[0] // n_frames
             r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
@@ -162,9 +173,7 @@ def get_file_name(qt_path):
     if n_frames and not _common.skip_intermediate():
         per = depths.shape[1] * depths.shape[2]
         cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=_common.context())
-        for k, name in enumerate(names):  # the per-frame camera txt the reference leaves in ./point/
-            r3d.cloud_io.write_xyz_txt('./point/' + name[0:-4] + '.txt', cam[k * per:(k + 1) * per],
-                                       z_raw=depths[k] if depths.dtype in (np.uint8, np.uint16) else None)
+        _write_camera_txts(names, cam, depths, per)   # the per-frame camera txt the reference leaves in ./point/
         # the reference reopens this file with 'w' for every frame: it ends up holding the last one
         r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
     t2 = time.time()
