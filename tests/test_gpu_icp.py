@@ -608,3 +608,19 @@ def test_multi_start_keeps_the_moments_start_on_an_isotropic_cloud(icp, ctx):
     T, info = icp.icp_similarity(src, tgt, ctx=ctx)
     assert info["init_choice"] == 0 and len(info["init_candidates"]) == 5, info["init_candidates"]
     assert np.abs(T - T_true).max() <= 5e-2, np.abs(T - T_true).max()
+
+
+def test_repeated_estimates_do_not_leak_device_memory(icp, ctx):
+    """Every object of an estimate (clouds, two indexes, samples, state) is released: 40 estimates later the free HBM is where
+    it was after the first few (the context's grow-only scratch buffers reach their size once)."""
+    import torch
+    src, tgt, _, _ = OI.synthetic_pair(n_tgt=30000, n_src=30000, s=1.3, angle_deg=8.0, t_norm=0.3, seed=2)
+    for _ in range(3):
+        icp.icp_similarity(src, tgt, ctx=ctx, max_iter=8)
+    ctx.sync()
+    free0, _total = torch.cuda.mem_get_info(0)
+    for _ in range(40):
+        icp.icp_similarity(src, tgt, ctx=ctx, max_iter=8, trim=0.95)
+    ctx.sync()
+    free1, _total = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 32 * 2 ** 20, (free0 - free1) / 2 ** 20
