@@ -398,38 +398,10 @@ def main():
     ctx = r3d.Context(dev_index, stream=stream.cuda_stream)
     cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
 
-    # the exchange step: the library's own RCCL communicator (C ABI, r3d_comm_*) when it comes up on every rank,
-    # torch.distributed otherwise (always for gloo rehearsals)
+    # the exchange step's transports are created further down, AFTER the shards-stay-resident job has been measured and
+    # with the watchdog armed: a communicator bring-up that stalls must not cost the line either
     transport, transport_note = None, ""
-    if use_dist:
-        want = os.environ.get("R3D_BENCH_TRANSPORT", "r3d" if backend == "nccl" else "torch")
-        if want == "r3d":
-            try:
-                CM = importlib.import_module("3d_reconstruction_system_amd.comm")
-                box = [CM.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                transport = D.R3dTransport(CM.Comm(ctx, box[0], rank, world))
-                transport_note = "r3d_comm over RCCL (%s)" % transport.comm.rccl_origin()
-            except Exception as e:     # e.g. no librccl to dlopen: every rank takes the same way out
-                transport, transport_note = None, "r3d_comm unavailable (%s: %s); " % (type(e).__name__, str(e)[:120])
-        if transport is None:
-            transport = D.TorchTransport()
-            transport_note += "torch.distributed (%s)" % backend
-    # a second exchange channel on a side stream, for the pipelined strategy (gather chunk c+1 while chunk c is fused)
     side = side_transport = ctx2 = None
-    if use_dist and a.frames % OVERLAP_CHUNKS == 0:
-        try:
-            side = torch.cuda.Stream(dev)
-            if isinstance(transport, D.R3dTransport):
-                CM = importlib.import_module("3d_reconstruction_system_amd.comm")
-                ctx2 = r3d.Context(dev_index, stream=side.cuda_stream)
-                box = [CM.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                side_transport = D.R3dTransport(CM.Comm(ctx2, box[0], rank, world))
-            else:
-                side_transport = transport        # torch collectives follow torch's current stream
-        except Exception:
-            side = side_transport = None
 
     # synthetic job: rank r owns frames [r*F, (r+1)*F) of a world*F-frame sequence
     F = a.frames
@@ -654,16 +626,47 @@ def main():
     if use_dist:
         elapsed_none, gpu_none = headline(make_step("none"))
         fallback["elapsed"], fallback["gpu"] = elapsed_none, gpu_none
+        assemble["none"] = {"ms_per_step": round(elapsed_none / a.steps * 1e3, 4),
+                            "Mpoints_s": round(world * n_local * a.steps / elapsed_none / 1e6, 1), "fabric_bytes_in_per_gpu": 0}
+        import threading
+        beat.update(t=time.monotonic(), armed=True, what="communicator set-up")
+        threading.Thread(target=watchdog, daemon=True).start()
+        # the exchange step: the library's own RCCL communicator (C ABI, r3d_comm_*) when it comes up on every rank,
+        # torch.distributed otherwise (always for gloo rehearsals)
+        if use_dist:
+            want = os.environ.get("R3D_BENCH_TRANSPORT", "r3d" if backend == "nccl" else "torch")
+            if want == "r3d":
+                try:
+                    CM = importlib.import_module("3d_reconstruction_system_amd.comm")
+                    box = [CM.Comm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    transport = D.R3dTransport(CM.Comm(ctx, box[0], rank, world))
+                    transport_note = "r3d_comm over RCCL (%s)" % transport.comm.rccl_origin()
+                except Exception as e:     # e.g. no librccl to dlopen: every rank takes the same way out
+                    transport, transport_note = None, "r3d_comm unavailable (%s: %s); " % (type(e).__name__, str(e)[:120])
+            if transport is None:
+                transport = D.TorchTransport()
+                transport_note += "torch.distributed (%s)" % backend
+        # a second exchange channel on a side stream, for the pipelined strategy (gather chunk c+1 while chunk c is fused)
+        if use_dist and a.frames % OVERLAP_CHUNKS == 0:
+            try:
+                side = torch.cuda.Stream(dev)
+                if isinstance(transport, D.R3dTransport):
+                    CM = importlib.import_module("3d_reconstruction_system_amd.comm")
+                    ctx2 = r3d.Context(dev_index, stream=side.cuda_stream)
+                    box = [CM.Comm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    side_transport = D.R3dTransport(CM.Comm(ctx2, box[0], rank, world))
+                else:
+                    side_transport = transport        # torch collectives follow torch's current stream
+            except Exception:
+                side = side_transport = None
+
         modes = ["outputs", "inputs"]
         if isinstance(transport, D.R3dTransport):
             modes += ["outputs_direct", "inputs_direct"]
         if side_transport is not None:
             modes.append("inputs_overlap")
-        assemble["none"] = {"ms_per_step": round(elapsed_none / a.steps * 1e3, 4),
-                            "Mpoints_s": round(world * n_local * a.steps / elapsed_none / 1e6, 1), "fabric_bytes_in_per_gpu": 0}
-        import threading
-        beat.update(t=time.monotonic(), armed=True)
-        threading.Thread(target=watchdog, daemon=True).start()
         for m in modes:
             beat.update(t=time.monotonic(), what=m)
             try:   # a side measurement must never cost the headline line
