@@ -4,8 +4,10 @@
 // Replaces `cv.imread('./depth/'+name, cv.IMREAD_GRAYSCALE)` of camera_to_world.py:160 for the files that path
 // actually reads: non-interlaced greyscale PNGs (colour type 0) of 8 bits (-> uint8, identical to OpenCV) or
 // 16 bits (-> uint16 big-endian samples converted to host order; OpenCV would reduce these to 8 bits, the caller
-// decides).  Anything else (colour, palette, alpha, interlace) returns R3D_ERR_UNSUPPORTED so the Python host can
-// fall back to cv2/PIL, whose colour->grey conversions are theirs to define.
+// decides), and 8-bit RGB(A) / grey+alpha files whose colour channels agree in every pixel (a depth map saved "in
+// colour": its grey value is the same under every conversion rule).  Anything else (real colour, palette, interlace)
+// returns R3D_ERR_UNSUPPORTED so the Python host can fall back to cv2/PIL, whose colour->grey conversions are theirs
+// to define.
 // A batch of files is decoded straight into one [n][H][W] buffer (e.g. pinned memory) by a thread pool.
 #include <zlib.h>
 
@@ -155,7 +157,7 @@ int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, 
   if (w_out) *w_out = (int)info.width;
   if (bits_out) *bits_out = info.bit_depth;
   if (rc) return rc;
-  if (channels != 1) {
+  if (channels != 1 && info.bit_depth != 8) {
     *msg = std::string("'") + path + "': not a greyscale PNG (the colour -> grey conversion is the caller's to define)";
     return R3D_ERR_UNSUPPORTED;
   }
@@ -166,7 +168,19 @@ int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, 
     return R3D_ERR_NOMEM;
   }
   unsigned char* dst = static_cast<unsigned char*>(out);
-  if (info.bit_depth == 8) {
+  if (channels != 1) {
+    // 8-bit RGB / RGBA / grey+alpha: a depth map saved "in colour" has R = G = B in every pixel, and such a pixel IS its
+    // grey value under every colour -> grey rule there is (OpenCV's, libpng's, PIL's); alpha is dropped by all of them.
+    // One pixel with differing channels and the conversion is the caller's to define.
+    const unsigned char* s = px.data();
+    for (size_t k = 0; k < need; ++k, s += channels) {
+      if (channels >= 3 && (s[0] != s[1] || s[1] != s[2])) {
+        *msg = std::string("'") + path + "': a colour PNG whose channels differ (the colour -> grey conversion is the caller's to define)";
+        return R3D_ERR_UNSUPPORTED;
+      }
+      dst[k] = s[0];
+    }
+  } else if (info.bit_depth == 8) {
     memcpy(dst, px.data(), need);
   } else {  // PNG samples are big-endian
     for (size_t k = 0; k < need; k += 2) {

@@ -360,3 +360,41 @@ def test_native_parser_fast_path_is_correctly_rounded_on_a_million_numbers(R, tm
     want = np.array([float(t) for t in toks])
     bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
     assert bad.size == 0, [(toks[k], got[k], want[k]) for k in bad[:5]]
+
+
+def test_depth_maps_saved_in_colour_decode_natively_when_their_channels_agree(R, tmp_path):
+    """A depth map written as an RGB(A) PNG with R = G = B (how p2c's input is shaped) is its own grey value under every
+    colour -> grey rule, so the native batch decoder takes it (no per-file PIL / OpenCV round trip); one pixel with differing
+    channels and the file goes to the fallback, whose conversion rule is its own."""
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    H, W = 40, 56
+    greys, paths = [], []
+    for k, mode in enumerate(("RGB", "RGBA", "LA", "L", "RGB")):
+        g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        if mode == "RGB":
+            img = Image.fromarray(np.stack([g, g, g], 2), "RGB")
+        elif mode == "RGBA":
+            img = Image.fromarray(np.stack([g, g, g, rng.integers(0, 256, (H, W), dtype=np.uint8)], 2), "RGBA")
+        elif mode == "LA":
+            img = Image.fromarray(np.stack([g, rng.integers(0, 256, (H, W), dtype=np.uint8)], 2), "LA")
+        else:
+            img = Image.fromarray(g, "L")
+        p = tmp_path / ("d%d.png" % k)
+        img.save(p)
+        greys.append(g)
+        paths.append(str(p))
+    out = np.empty((5, H, W), np.uint8)
+    lib = R.load_library()
+    import ctypes as C
+    arr = (C.c_char_p * 5)(*[os.fsencode(p) for p in paths])
+    assert lib.r3d_png_gray_decode_batch(arr, 5, out.ctypes.data, H, W, 8) == 0          # all five natively
+    np.testing.assert_array_equal(out, np.stack(greys))
+    np.testing.assert_array_equal(R.cloud_io.read_depth_batch(paths), np.stack(greys))
+    real = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)                                  # real colour: not ours to convert
+    Image.fromarray(real, "RGB").save(tmp_path / "c.png")
+    arr1 = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "c.png")))
+    assert lib.r3d_png_gray_decode_batch(arr1, 1, out.ctypes.data, H, W, 8) != 0
+    got = R.cloud_io.read_depth_batch([paths[0], str(tmp_path / "c.png")])                  # falls back per file, still works
+    np.testing.assert_array_equal(got[0], greys[0])
+    assert got.shape == (2, H, W)
