@@ -68,5 +68,17 @@ for f in (0, F // 2, F - 1):
             bad += 1
             print("MISMATCH frame %d pixel (%d,%d): %s vs %s, rgba %08x" % (f, j, i, got, want, word[0]))
 print("spot check: %s" % ("OK (9 points, 3 frames)" if bad == 0 else "%d mismatches" % bad))
+# ... + the HIP voxel insert of config 5: the whole fused cloud into ONE occupied-voxel set at 0.1 m.  Every frame here is a
+# fronto-parallel plane at 12 m (constant depth), ~30k voxels per frame: heavy duplication, like a real scan.
+V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
+vs = V.VoxelSet(0.1, 1 << 28, ctx)
+ctx.sync()
+ctx.timer_start()
+vs.insert_device(d_xyz.ptr, n)
+ms_v = ctx.timer_stop()
+st = vs.stats()
+print("voxel insert of all %.3f G points: %.1f ms = %.1f Gpoints/s -> %d occupied voxels (ignored %d, overflow %d); fuse + insert = %.1f ms"
+      % (n / 1e9, ms_v, n / ms_v / 1e6, st["voxels"], st["ignored_points"], st["overflow"], ms + ms_v), flush=True)
+vs.close()
 ctx.close()
 sys.exit(1 if bad else 0)
