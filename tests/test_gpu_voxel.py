@@ -172,3 +172,32 @@ def test_insert_codes_and_single_rank_union(V, ctx, real_rccl):
     d.free()
     for v in (va, vb, vab):
         v.close()
+
+
+@pytest.mark.parametrize("res", [0.1, 0.05, 0.25, 0.3, 1.0 / 3.0])
+def test_keys_of_points_on_and_next_to_voxel_faces(V, ctx, res):
+    """Keys are OctoMap's (int)floor(factor * (double)x) + 32768.  Points exactly ON voxel faces, one and a few float ulps
+    either side, at the range limits, non-finite and ordinary ones -- every key must equal the fp64 oracle's, at several
+    resolutions (any cheaper key arithmetic has to pass this first; an fp32 fast path with an fp64 fallback did, and bought
+    nothing: DESIGN.md 4.5)."""
+    rng = np.random.default_rng(int(res * 1000))
+    k = rng.integers(-32768, 32768, 60000)
+    base = (k * res).astype(np.float32)                                    # (nearly) on a face
+    pts = []
+    for step in (0, 1, -1, 2, -2, 7, -7, 50, -50):
+        x = base.copy()
+        for _ in range(abs(step)):
+            x = np.nextafter(x, np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+        pts.append(x)
+    x = np.concatenate(pts)
+    xyz = np.stack([x, np.roll(x, 1), np.roll(x, 2)], 1).astype(np.float32)
+    xyz = np.concatenate([xyz, (rng.normal(size=(50000, 3)) * 50).astype(np.float32),
+                          np.array([[-32768 * res, 0, 0], [32768 * res, 0, 0], [np.nextafter(np.float32(32768 * res), np.float32(0)), 0, 0],
+                                    [1e30, 0, 0], [-1e30, 0, 0], [0, np.nan, 0], [0, 0, np.inf]], np.float32)])
+    vs = V.VoxelSet(res, 1 << 21, ctx)
+    vs.insert(xyz)
+    want, dropped = OM.occupied_set(xyz, res)
+    st = vs.stats()
+    assert st["overflow"] == 0 and st["ignored_points"] == dropped
+    np.testing.assert_array_equal(vs.codes(), want)
+    vs.close()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Duplicate-heavy voxel insert (300 frames of 1080p fronto-parallel planes = 622 M points) -- the program to put behind
+`rocprofv3 --pmc ... --` when looking for what bounds voxel_insert_kernel on realistic clouds."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+r3d = importlib.import_module("3d_reconstruction_system_amd")
+L = importlib.import_module("3d_reconstruction_system_amd._lib")
+V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
+ctx = r3d.Context(0)
+F, H, W = 300, 1080, 1920
+n = F * H * W
+d_depth = ctx.alloc(n * 4)
+L.check(ctx.lib.r3d_memset(ctx.handle, d_depth.ptr, 0x41, n * 4))
+rng = np.random.default_rng(5)
+tab = r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
+d_pose = ctx.alloc(tab.nbytes).upload(tab)
+cam = ctx.camera(H, W, 960.0, 960.0, 959.5, 539.5)
+d_xyz = ctx.alloc(n * 12)
+r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_xyz.ptr, np.float32)
+vs = V.VoxelSet(0.1, 1 << 26, ctx)
+for _ in range(3):
+    vs.clear()
+    ctx.sync()
+    ctx.timer_start()
+    vs.insert_device(d_xyz.ptr, n)
+    ms = ctx.timer_stop()
+print("%.2f ms = %.1f Gpoints/s, %d voxels" % (ms, n / ms / 1e6, vs.stats()["voxels"]))
