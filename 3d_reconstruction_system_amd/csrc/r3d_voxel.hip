@@ -66,27 +66,49 @@ __device__ __forceinline__ bool voxel_code(const P3& p, double factor, uint64_t*
   return true;
 }
 
-constexpr int kLdsSlots = 2048;  // per-workgroup dedupe table: 2x the 1024 points of a tile
+constexpr int kLdsSlots = 2048;     // per-workgroup dedupe table (16 KB)
+constexpr int kLdsKeepBelow = 512;   // it survives from tile to tile while it holds fewer codes than this (then <= 75 % full)
 
-// DEDUPE: a workgroup first funnels its tile's 1024 codes through a small LDS hash set; only the first lane to
-// claim a code goes on to the global table.  Real clouds put tens to hundreds of points into one 10 cm voxel,
-// so this removes most of the scattered 64-bit global atomics (the kernel's bound) for the price of LDS atomics.
+// DEDUPE: a workgroup funnels its codes through a small LDS hash set; only the first lane to claim a code goes on to the
+// global table.  Real clouds put tens to hundreds of points into one 10 cm voxel, and neighbouring image rows fall into
+// the SAME voxels.  In-kernel clocks on such a cloud (late round 2) put 46 % of the wave time into the returning global
+// atomics and 29 % into the loads -- with few atomics per tile: it is the SAME table words being hit from many compute
+// units at once.  So a workgroup walks a CONTIGUOUS run of tiles (neighbouring rows, the same voxels) and KEEPS its LDS
+// set from tile to tile: a code found there was sent to the global table by whoever claimed it, in this tile or an
+// earlier one.  The set is wiped once it has collected kLdsKeepBelow codes (every tile on all-distinct data, rarely on
+// a scan).
 template <bool DEDUPE>
 __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __restrict__ xyz, int64_t n, double factor,
                                                                 uint64_t* __restrict__ table, int log2cap,
                                                                 unsigned long long* __restrict__ counters) {
   __shared__ unsigned long long local_set[DEDUPE ? kLdsSlots : 1];
+  // codes gained per tile, three counters in rotation: tile j adds into [j % 3], everyone reads it after the next barrier,
+  // thread 0 zeroes [(j + 1) % 3] there -- whose last readers all passed that barrier -- so the running total every thread
+  // keeps in a register is the same in all of them and the decision to wipe is workgroup-uniform
+  __shared__ unsigned local_fill[3];
   const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
   const int lane = threadIdx.x & 63;
   // statistics stay in registers and reach the three global counters once per wave: a per-insert
   // atomicAdd on one word would cap the kernel at that word's ~0.09 G atomics/s
   unsigned n_new = 0, n_ignored = 0, n_over = 0;
   const int64_t n_tiles = (n + kThreads * 4 - 1) / (kThreads * 4);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const int64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;  // a contiguous run of tiles per workgroup
+  const int64_t tile_lo = (int64_t)blockIdx.x * per_wg, tile_hi = tile_lo + per_wg < n_tiles ? tile_lo + per_wg : n_tiles;
+  if (DEDUPE) {
+    for (int k = threadIdx.x; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
+    if (threadIdx.x < 3) local_fill[threadIdx.x] = 0;
+  }
+  unsigned total = 0, j = 0;  // codes in the set (same value in every thread), tiles done by this workgroup
+  for (int64_t tile = tile_lo; tile < tile_hi; ++tile, ++j) {
     if (DEDUPE) {
-      __syncthreads();  // the previous tile's lookups are done
-      for (int k = threadIdx.x; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
-      __syncthreads();
+      __syncthreads();  // the previous tile's lookups and its count are done (first tile: the wipe above has landed)
+      if (j > 0) total += local_fill[(j - 1) % 3];
+      if (threadIdx.x == 0) local_fill[(j + 1) % 3] = 0;
+      if (total >= (unsigned)kLdsKeepBelow) {  // workgroup-uniform
+        for (int k = threadIdx.x; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
+        total = 0;
+        __syncthreads();
+      }
     }
     const int64_t base = tile * (kThreads * 4) + threadIdx.x;
     P3 p[4];
@@ -95,6 +117,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       const int64_t i = base + (int64_t)r * kThreads;
       if (i < n) p[r] = reinterpret_cast<const P3*>(xyz)[i];
     }
+    unsigned claimed = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = base + (int64_t)r * kThreads;
@@ -118,12 +141,13 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
             mine = true;
             done = true;
           } else if (old == code) {
-            done = true;  // another lane of this tile already carries it to the global table
+            done = true;  // a lane of this workgroup already carries (or carried) it to the global table
           } else {
             slot = (slot + 1) & (kLdsSlots - 1);
           }
         }
-        live = mine || !done;  // a full local table (cannot happen: 1024 codes, 2048 slots) would fall through
+        claimed += mine ? 1u : 0u;
+        live = mine || !done;  // a full local table (cannot happen: < 512 + 1024 codes in 2048 slots) would fall through
       }
       if (live) {
         uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
@@ -142,6 +166,11 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
         }
         if (!done) ++n_over;
       }
+    }
+    if (DEDUPE) {  // one LDS add per wave: how many codes the set gained in this tile
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) claimed += __shfl_down(claimed, off, 64);
+      if (lane == 0 && claimed) atomicAdd(&local_fill[j % 3], claimed);
     }
   }
 #pragma unroll
