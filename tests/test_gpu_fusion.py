@@ -549,3 +549,35 @@ def test_cache_prefetch_is_a_pure_read(R, ctx):
     with pytest.raises(R.R3DError):
         L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, None, 16))
     buf.free()
+
+
+def test_auto_staging_above_64_mb_of_inputs_is_bit_identical(R, ctx):
+    """150 frames of 1280x384 u8 = 73.7 MB of raster: above the auto threshold, so the default call stages the inputs through
+    the Infinity Cache in 96 MB steps (here one step) -- and with colour (295 MB of inputs) in four.  Same bits as with the
+    staging switched off."""
+    rng = np.random.default_rng(9)
+    F, H, W = 150, 384, 1280
+    n = F * H * W
+    d = rng.integers(0, 256, size=(F, H, W), dtype=np.uint8)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    tab = R.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
+    cam = ctx.camera(H, W, *R.REF_INTRINSICS)
+    d_depth, d_pose, d_rgb = ctx.alloc(d.nbytes).upload(d), ctx.alloc(tab.nbytes).upload(tab), ctx.alloc(rgb.nbytes).upload(rgb)
+    del rgb
+    d_a, d_b, d_ca, d_cb = ctx.alloc(n * 12), ctx.alloc(n * 12), ctx.alloc(n * 4), ctx.alloc(n * 4)
+    try:
+        for colour in (False, True):
+            for knob, out, rgba in ((1, d_a, d_ca), (0, d_b, d_cb)):
+                ctx.set_tuning("fuse_prefetch", knob)
+                if colour:
+                    R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_rgb.ptr, out.ptr, np.float32, rgba.ptr)
+                else:
+                    R.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, out.ptr, np.float32)
+            a, b = d_a.download(np.uint32, n * 3), d_b.download(np.uint32, n * 3)
+            assert np.array_equal(a, b)
+            if colour:
+                assert np.array_equal(d_ca.download(np.uint32, n), d_cb.download(np.uint32, n))
+    finally:
+        ctx.set_tuning("fuse_prefetch", 0)
+        for buf in (d_depth, d_pose, d_rgb, d_a, d_b, d_ca, d_cb):
+            buf.free()
