@@ -73,6 +73,57 @@ int main(void) {
     if (strncmp(buf, "ply\n    format ascii 1.0\n    element vertex 48\n", 47) != 0) { fprintf(stderr, "PLY header mismatch\n"); return 1; }
     free(buf);
   }
+  /* the text round trip a maintainer of camera_to_world.py / transfer_T_icp.py cares about: write `X,Y,Z` lines with
+   * repr() floats, read them back (first three fields of every line), same doubles */
+  {
+    size_t n_bytes = 0;
+    char* txt;
+    double back[N * 3];
+    long long n_pts = 0, bad_line = 0;
+    CK(r3d_format_xyz_txt(xyz64, R3D_F64, N, NULL, 0, NULL, 0, &n_bytes));
+    txt = (char*)malloc(n_bytes + 1);
+    CK(r3d_format_xyz_txt(xyz64, R3D_F64, N, NULL, 0, txt, n_bytes, &n_bytes));
+    CK(r3d_parse_xyz_text(txt, n_bytes, ',', NULL, 0, (int64_t*)&n_pts, NULL));
+    if (n_pts != N) { fprintf(stderr, "parser counted %lld lines, expected %d\n", n_pts, (int)N); return 1; }
+    CK(r3d_parse_xyz_text(txt, n_bytes, ',', back, N, (int64_t*)&n_pts, (int64_t*)&bad_line));
+    if (memcmp(back, xyz64, sizeof(back)) != 0) { fprintf(stderr, "txt round trip changed a double\n"); return 1; }
+    txt[5] = 'x'; /* damage the first line */
+    if (r3d_parse_xyz_text(txt, n_bytes, ',', back, N, (int64_t*)&n_pts, (int64_t*)&bad_line) != R3D_ERR_INVALID || bad_line != 1) {
+      fprintf(stderr, "damaged line not reported (line %lld)\n", bad_line);
+      return 1;
+    }
+    free(txt);
+  }
+  /* staging sweep + colour-carrying launch on device memory */
+  {
+    void *d_depth = NULL, *d_pose = NULL, *d_rgb = NULL, *d_xyz = NULL, *d_rgba = NULL;
+    unsigned char rgb[N * 3];
+    unsigned int rgba[N];
+    for (k = 0; k < N * 3; ++k) rgb[k] = (unsigned char)(k * 7);
+    CK(r3d_dev_alloc(ctx, N, &d_depth));
+    CK(r3d_dev_alloc(ctx, sizeof(pose), &d_pose));
+    CK(r3d_dev_alloc(ctx, N * 3, &d_rgb));
+    CK(r3d_dev_alloc(ctx, N * 12, &d_xyz));
+    CK(r3d_dev_alloc(ctx, N * 4, &d_rgba));
+    CK(r3d_memcpy_h2d(ctx, d_depth, depth, N));
+    CK(r3d_memcpy_h2d(ctx, d_pose, pose, sizeof(pose)));
+    CK(r3d_memcpy_h2d(ctx, d_rgb, rgb, N * 3));
+    CK(r3d_cache_prefetch(ctx, d_rgb, N * 3));
+    CK(r3d_fuse_frames_rgb(ctx, cam, d_depth, R3D_DEPTH_U8, F, 1.0, (const double*)d_pose, (const unsigned char*)d_rgb, d_xyz, R3D_F32,
+                           (uint32_t*)d_rgba));
+    CK(r3d_memcpy_d2h(ctx, rgba, d_rgba, N * 4));
+    CK(r3d_ctx_sync(ctx));
+    for (k = 0; k < N; ++k)
+      if (rgba[k] != ((unsigned)rgb[3 * k] | ((unsigned)rgb[3 * k + 1] << 8) | ((unsigned)rgb[3 * k + 2] << 16))) {
+        fprintf(stderr, "colour of point %d wrong\n", k);
+        return 1;
+      }
+    CK(r3d_dev_free(ctx, d_depth));
+    CK(r3d_dev_free(ctx, d_pose));
+    CK(r3d_dev_free(ctx, d_rgb));
+    CK(r3d_dev_free(ctx, d_xyz));
+    CK(r3d_dev_free(ctx, d_rgba));
+  }
   /* error convention: bad arguments come back as codes with a message, nothing aborts */
   if (r3d_fuse_frames_host(ctx, cam, NULL, R3D_DEPTH_U8, F, 1.0, pose, xyz, R3D_F32) != R3D_ERR_INVALID) return 1;
   if (r3d_ctx_set_tuning(ctx, "no_such_knob", 1) != R3D_ERR_INVALID) return 1;
