@@ -68,12 +68,13 @@ def _cloud_stats(m):
 
 
 def init_candidates(mom_src, mom_tgt, with_scale=True):
-    """Starting transforms for init="auto": [("moments", T0), ("pca", T1) ... ("pca", T4)].  T0 = moments_init (no rotation).
-    T1..T4 additionally turn the source's principal axes onto the target's -- the four proper rotations V_q S V_p^T,
-    S = diag(+-1, +-1, +-1) (eigenvectors are defined up to sign; mirror images excluded) -- which lets the estimator
-    start from ANY relative orientation when the scene is anisotropic (a room, a street), e.g. a camera-frame cloud
-    against COLMAP's arbitrary world gauge.  On a near-isotropic cloud the axes mean nothing; the cost test in
-    icp_similarity then keeps T0."""
+    """Starting transforms for init="auto": [("moments", T0), 24 x ("pca" | "pca-permuted", T)].  T0 = moments_init (no
+    rotation).  The others turn the source's principal axes onto the target's: the 24 proper rotations V_q S P V_p^T with S a
+    sign matrix and P an axis permutation (eigenvectors are defined up to sign, mirror images are excluded; the permutations
+    matter when two extents are alike -- a room seen only in part can swap its two longest axes).  That lets the estimator
+    start from ANY relative orientation when the scene is anisotropic (a room, a street), e.g. a camera-frame cloud against
+    COLMAP's arbitrary world gauge.  On a near-isotropic cloud the axes mean nothing; the cost test in icp_similarity then
+    keeps T0."""
     mu_p, r_p, cov_p = _cloud_stats(mom_src)
     mu_q, r_q, cov_q = _cloud_stats(mom_tgt)
     s = (r_q / r_p if r_p > 0 and r_q > 0 else 1.0) if with_scale else 1.0
@@ -89,13 +90,17 @@ def init_candidates(mom_src, mom_tgt, with_scale=True):
     wq, Vq = np.linalg.eigh(cov_q)
     if not (np.all(np.isfinite(wp)) and np.all(np.isfinite(wq))) or wp[2] <= 0 or wq[2] <= 0:
         return out
-    for sx in (1.0, -1.0):
-        for sy in (1.0, -1.0):
-            S = np.diag([sx, sy, 1.0])
-            Rm = Vq @ S @ Vp.T
-            if np.linalg.det(Rm) < 0:
-                Rm = Vq @ np.diag([sx, sy, -1.0]) @ Vp.T
-            out.append(("pca", make(Rm)))
+    for perm in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)):
+        Pm = np.zeros((3, 3))
+        for a in range(3):
+            Pm[a, perm[a]] = 1.0                 # target axis a <- source axis perm[a]
+        for sx in (1.0, -1.0):
+            for sy in (1.0, -1.0):
+                S = np.diag([sx, sy, 1.0])
+                Rm = Vq @ S @ Pm @ Vp.T
+                if np.linalg.det(Rm) < 0:
+                    Rm = Vq @ np.diag([sx, sy, -1.0]) @ Pm @ Vp.T
+                out.append(("pca" if perm == (0, 1, 2) else "pca-permuted", make(Rm)))
     return out
 
 
@@ -107,7 +112,7 @@ def trimmed_mean(d2, keep=0.8):
     return float(d2[:k].mean()) if k > 0 else float("inf")
 
 
-INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 32768, 0.8, 1.05
+INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 8192, 0.8, 1.05
 
 
 class NNIndex:

@@ -156,7 +156,7 @@ def target_spacing(tgt, max_queries=32768):
     return float(np.sqrt(np.median(d2)))
 
 
-INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 32768, 0.8, 1.05
+INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 8192, 0.8, 1.05
 
 
 def init_candidates(P, Q, with_scale=True):
@@ -177,12 +177,16 @@ def init_candidates(P, Q, with_scale=True):
     wq, Vq = np.linalg.eigh(0.5 * (cov_q + cov_q.T))
     if wp[2] <= 0 or wq[2] <= 0:
         return out
-    for sx in (1.0, -1.0):
-        for sy in (1.0, -1.0):
-            Rm = Vq @ np.diag([sx, sy, 1.0]) @ Vp.T
-            if np.linalg.det(Rm) < 0:
-                Rm = Vq @ np.diag([sx, sy, -1.0]) @ Vp.T
-            out.append(make(Rm))
+    for perm in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)):
+        Pm = np.zeros((3, 3))
+        for a in range(3):
+            Pm[a, perm[a]] = 1.0
+        for sx in (1.0, -1.0):
+            for sy in (1.0, -1.0):
+                Rm = Vq @ np.diag([sx, sy, 1.0]) @ Pm @ Vp.T
+                if np.linalg.det(Rm) < 0:
+                    Rm = Vq @ np.diag([sx, sy, -1.0]) @ Pm @ Vp.T
+                out.append(make(Rm))
     return out
 
 
@@ -234,13 +238,14 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
     coarse = 0
     for _ in range(max_coarse):
         ia, da = nearest_neighbours(cur, tgt)
-        ga = float(np.quantile(da, trim)) if trim is not None and trim < 1.0 else -1.0
+        ct = None if trim is None else 1.0 - (1.0 - trim) / 4.0      # the coarse stage trims more gently (icp.py: coarse_trim)
+        ga = float(np.quantile(da, ct)) if ct is not None and ct < 1.0 else -1.0
         sums = pair_sums(cur, tgt, ia, da, ga, d0)
         T_inv = np.linalg.inv(T_since)
         s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
         moved = apply_T32(tgt, T_inv)
         ib, db = nearest_neighbours(moved, snap)
-        gb = float(np.quantile(db, trim)) if trim is not None and trim < 1.0 else -1.0
+        gb = float(np.quantile(db, ct)) if ct is not None and ct < 1.0 else -1.0
         sums = sums + swap_pair_sums(pair_sums(tgt, cur, ib, db, gb, d0 / s_since))
         if not sums[0] >= 3.0:
             break

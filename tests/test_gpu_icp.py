@@ -366,11 +366,11 @@ def test_full_estimator_matches_oracle_restatement(icp, ctx, scene):
     _s, _t, T_true, _ = OI.synthetic_pair(n_tgt=8, n_src=4, s=1.7, angle_deg=10.0, t_norm=0.5, seed=7)
     Ti = np.linalg.inv(T_true)
     if scene == "same points":
-        tgt = (rng.random((8000, 3)) * np.array([6.0, 4.0, 3.0])).astype(np.float32)
-        src = OI.apply_T32(tgt[rng.permutation(8000)], Ti)
+        tgt = (rng.random((4000, 3)) * np.array([6.0, 4.0, 3.0])).astype(np.float32)
+        src = OI.apply_T32(tgt[rng.permutation(4000)], Ti)
     else:
-        tgt = _cube_surface(rng, 5000, 5.0).astype(np.float32)
-        src = OI.apply_T32(_cube_surface(rng, 5000, 5.0).astype(np.float32), Ti)
+        tgt = _cube_surface(rng, 3500, 5.0).astype(np.float32)
+        src = OI.apply_T32(_cube_surface(rng, 3500, 5.0).astype(np.float32), Ti)
     T_ref, info_ref = OI.icp_similarity_auto(src, tgt)
     T, info = icp.icp_similarity(src, tgt, ctx=ctx)
     assert info["init_choice"] == info_ref["init_choice"], (info["init_candidates"], info_ref)
@@ -606,7 +606,7 @@ def test_multi_start_keeps_the_moments_start_on_an_isotropic_cloud(icp, ctx):
     tgt = _cube_surface(rng, 60000, 20.0).astype(np.float32)
     src = OI.apply_T32(_cube_surface(rng, 60000, 20.0).astype(np.float32), np.linalg.inv(T_true))
     T, info = icp.icp_similarity(src, tgt, ctx=ctx)
-    assert info["init_choice"] == 0 and len(info["init_candidates"]) == 5, info["init_candidates"]
+    assert info["init_choice"] == 0 and len(info["init_candidates"]) == 25, info["init_candidates"]
     assert np.abs(T - T_true).max() <= 5e-2, np.abs(T - T_true).max()
 
 
@@ -639,3 +639,28 @@ def test_partial_coverage_of_the_scene_is_tolerated(icp, ctx):
     src = ((sw - T_true[:3, 3]) @ np.linalg.inv(T_true[:3, :3]).T).astype(np.float32)
     T, info = icp.icp_similarity(src, tgt, ctx=ctx)
     assert np.abs(T - T_true).max() <= 5e-3, (np.abs(T - T_true).max(), info["init_candidates"], info["coarse_iterations"])
+
+
+def test_a_square_room_whose_two_long_axes_are_a_coin_toss(icp, ctx):
+    """An 8 x 8 x 3 m room: the two largest eigenvalues of each cloud's covariance are equal up to sampling noise, so WHICH
+    eigenvector comes first differs between two independent samplings -- sign flips alone cannot express that, the 24 signed
+    axis permutations can.  100 and 170 degrees / 1.7x / |t| = 0.5, no initial guess."""
+    def square_room(n, seed):
+        rng = np.random.default_rng(seed)
+
+        def rect(o, a, b, m):
+            return np.asarray(o, float) + rng.random((m, 1)) * np.asarray(a, float) + rng.random((m, 1)) * np.asarray(b, float)
+        parts = [rect([0, 0, 0], [8, 0, 0], [0, 8, 0], n // 4), rect([0, 0, 0], [8, 0, 0], [0, 0, 3], n // 8),
+                 rect([0, 0, 0], [0, 8, 0], [0, 0, 3], n // 8), rect([8, 0, 0], [0, 8, 0], [0, 0, 3], n // 8),
+                 rect([0, 8, 0], [8, 0, 0], [0, 0, 3], n // 8)]
+        m = n - sum(p.shape[0] for p in parts)
+        parts += [rect([2, 1, 0.8], [1.5, 0, 0], [0, 1, 0], m // 2), rect([5, 3, 0], [0, 1.2, 0], [0, 0, 1.5], m - m // 2)]
+        return np.concatenate(parts)
+    n = 150000
+    tgt = square_room(n, 3).astype(np.float32)
+    sw = square_room(n, 4)
+    for angle, seed in ((100.0, 1), (170.0, 2), (100.0, 3)):
+        _s, _t, T_true, _ = OI.synthetic_pair(n_tgt=8, n_src=4, s=1.7, angle_deg=angle, t_norm=0.5, seed=seed)
+        src = ((sw - T_true[:3, 3]) @ np.linalg.inv(T_true[:3, :3]).T).astype(np.float32)
+        T, info = icp.icp_similarity(src, tgt, ctx=ctx)
+        assert np.abs(T - T_true).max() <= 5e-3, (angle, seed, np.abs(T - T_true).max(), info["init_choice"], info["init_candidates"][info["init_choice"]])
