@@ -235,21 +235,63 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_codes_kernel(const uint
   }
 }
 
+// table -> dense list of its codes (order irrelevant: the radix sort follows).  One cursor bump per WORKGROUP-STEP of
+// kCompactSlots table words held in registers (round 2 bumped the one global cursor once per wave per 64 words: ~2 M
+// same-address returning atomics for a 1 GB table = 25 ms = 0.8 % of HBM; a same-address returning atomic completes at
+// ~0.09 G/s, so the count per bump decides everything).  Steps that hold no code skip the atomic.
+constexpr int kCompactPerThread = 32;                            // table words per thread per step: 16 x 16-byte loads
+constexpr int kCompactSlots = kThreads * kCompactPerThread;      // 8192 words = 64 KB per workgroup-step
+
 __global__ __launch_bounds__(kThreads) void voxel_compact_kernel(const uint64_t* __restrict__ table, uint64_t capacity,
                                                                  uint64_t* __restrict__ out,
                                                                  unsigned long long* __restrict__ counters) {
-  const int lane = threadIdx.x & 63;
-  // capacity is a power of two >= 1024: every wave runs the same number of full iterations
-  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * kThreads) {
-    const uint64_t v = table[i];
-    const bool hit = v != kEmpty;
-    const unsigned long long ballot = __ballot(hit);
-    if (ballot) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(&counters[3], (unsigned long long)__popcll(ballot));  // one cursor bump per wave
-      base = __shfl(base, 0, 64);
-      if (hit) out[base + __popcll(ballot & ((1ull << lane) - 1))] = v;
+  __shared__ unsigned wave_total[kThreads / 64];
+  __shared__ unsigned long long step_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t n_steps = (capacity + kCompactSlots - 1) / kCompactSlots;
+  for (uint64_t step = blockIdx.x; step < n_steps; step += gridDim.x) {   // workgroup-uniform trip count
+    // thread t holds words (2t, 2t+1) + k * 512 of the step: every wave instruction reads 1 KB contiguous
+    const uint64_t lo = step * kCompactSlots + 2 * (uint64_t)threadIdx.x;
+    uint64_t v[kCompactPerThread];
+#pragma unroll
+    for (int k = 0; k < kCompactPerThread / 2; ++k) {
+      const uint64_t i = lo + (uint64_t)k * (2 * kThreads);
+      if (i + 1 < capacity) {   // capacity is a power of two >= 1024: pairs never straddle the end
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(table + i);
+        v[2 * k] = w.x;
+        v[2 * k + 1] = w.y;
+      } else {
+        v[2 * k] = kEmpty;
+        v[2 * k + 1] = kEmpty;
+      }
     }
+    // per word slot k the wave's hits leave as ONE contiguous run (ballot-ranked): the counts are wave-uniform scalars
+    unsigned wave_cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactPerThread; ++k) wave_cnt += (unsigned)__popcll(__ballot(v[k] != kEmpty));
+    if (lane == 0) wave_total[wave] = wave_cnt;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+      const unsigned t = wave_total[w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    if (threadIdx.x == 0 && total) step_base = atomicAdd(&counters[3], (unsigned long long)total);
+    __syncthreads();
+    if (total) {
+      unsigned long long at = step_base + before;
+      const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll
+      for (int k = 0; k < kCompactPerThread; ++k) {
+        const bool hit = v[k] != kEmpty;
+        const unsigned long long ballot = __ballot(hit);
+        if (hit) out[at + __popcll(ballot & below)] = v[k];
+        at += __popcll(ballot);
+      }
+    }
+    // (the next step's first barrier separates this step's reads of wave_total / step_base from their next writes)
   }
 }
 
@@ -539,7 +581,7 @@ static int codes_to_device_list(r3d_voxelset* vs, uint64_t** d_list_out, int64_t
   if ((rc = r3d_scratch(vs->ctx, 2, (size_t)n * sizeof(uint64_t), &d_tmp))) return rc;
   R3D_HIP(hipMemsetAsync(vs->d_counters + 3, 0, sizeof(unsigned long long), vs->ctx->stream));
   int blocks = vs->ctx->num_cus * 8;
-  const uint64_t need = (vs->capacity + kThreads - 1) / kThreads;
+  const uint64_t need = (vs->capacity + kCompactSlots - 1) / kCompactSlots;
   if ((uint64_t)blocks > need) blocks = (int)need;
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, vs->d_table, vs->capacity,
                      static_cast<uint64_t*>(d_list), vs->d_counters);

@@ -201,3 +201,133 @@ def test_keys_of_points_on_and_next_to_voxel_faces(V, ctx, res):
     assert st["overflow"] == 0 and st["ignored_points"] == dropped
     np.testing.assert_array_equal(vs.codes(), want)
     vs.close()
+
+
+# ---- config 5 sizes: the multi-tile path of voxel_insert_kernel (round-2 kernel: contiguous tile runs per workgroup, the
+# LDS set kept from tile to tile, the rotating fill counters and the wipe) only runs above num_cus*8*1024 = 2.1 M points.
+# Everything below compares EXACT code sets + ignored / overflow counts with oracle/octomap_ref.occupied_set, and the
+# kernel with the LDS set (voxel_dedupe 0/2) against the one without it (1) bitwise.
+
+def room_views(n_frames, h, w, seed=0):
+    """Synthetic RGBD-like views of the inside of a 8 x 6 x 3 m box room: z-depth rasters (f32) of a pinhole camera turning
+    about the vertical axis near the room's centre, + the world->camera poses (q xyzw, t) in COLMAP's convention
+    p_cam = R p_w + t (c2w:57-59).  Neighbouring pixels and rows land in the same 10 cm voxels (duplicate-heavy)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 0.8 * w
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    u = (np.arange(w) - cx) / fx
+    v = (np.arange(h) - cy) / fy
+    rays = np.stack([np.broadcast_to(u[None, :], (h, w)), np.broadcast_to(v[:, None], (h, w)), np.ones((h, w))], -1)
+    lo, hi = np.array([-4.0, -1.5, -3.0]), np.array([4.0, 1.5, 3.0])
+    depths, quats, ts = [], [], []
+    for f in range(n_frames):
+        ang = 2 * np.pi * f / n_frames + 0.1
+        Rwc = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])   # camera -> world
+        c = rng.uniform(-0.8, 0.8, 3) * np.array([1.0, 0.3, 1.0])
+        d = rays @ Rwc.T                                         # ray directions in the world, per unit camera z
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_hi = np.where(d > 0, (hi - c) / d, np.inf)
+            t_lo = np.where(d < 0, (lo - c) / d, np.inf)
+        z = np.minimum(t_hi, t_lo).min(-1)                       # camera-frame z at the first wall hit
+        depths.append(z.astype(np.float32))
+        R = Rwc.T                                                # world -> camera
+        t = -R @ c
+        quats.append([0.0, np.sin(-ang / 2), 0.0, np.cos(-ang / 2)])   # R = Ry(-ang), scalar-last like the pose file
+        ts.append(t)
+    return np.stack(depths), np.array(quats), np.array(ts), (fx, fy, cx, cy)
+
+
+def fuse_on_device(ctx, depth, q, t, K, rgb=None):
+    R = _r3d()
+    F, H, W = depth.shape
+    cam = ctx.camera(H, W, *K)
+    d_depth = ctx.alloc(depth.nbytes).upload(depth)
+    tab = R.pose_table(q, t)
+    d_pose = ctx.alloc(tab.nbytes).upload(tab)
+    d_xyz = ctx.alloc(F * H * W * 12)
+    if rgb is None:
+        R.fuse_frames_device(ctx, cam, d_depth.ptr, depth.dtype.type, F, d_pose.ptr, d_xyz.ptr, np.float32)
+    else:
+        d_rgb = ctx.alloc(rgb.nbytes).upload(rgb)
+        d_rgba = ctx.alloc(F * H * W * 4)
+        R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, depth.dtype.type, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, np.float32, d_rgba.ptr)
+        ctx.sync()
+        d_rgb.free()
+        d_rgba.free()
+    ctx.sync()
+    d_depth.free()
+    d_pose.free()
+    return d_xyz
+
+
+def check_device_cloud_against_oracle(V, ctx, d_xyz, n, res, capacity):
+    """insert with the LDS set, and without it: both must equal the oracle's set of the very same f32 cloud."""
+    cloud = d_xyz.download(np.float32, n * 3).reshape(-1, 3)
+    want, dropped = OM.occupied_set(cloud, res)
+    got = {}
+    for knob in (0, 1):
+        ctx.set_tuning("voxel_dedupe", knob)
+        try:
+            vs = V.VoxelSet(res, capacity, ctx)
+            vs.insert_device(d_xyz.ptr, n)
+            assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}, (knob, vs.stats(), len(want))
+            got[knob] = vs.codes()
+            vs.insert_device(d_xyz.ptr, n)                        # idempotent at size
+            assert vs.stats()["voxels"] == len(want)
+            vs.close()
+        finally:
+            ctx.set_tuning("voxel_dedupe", 0)
+    np.testing.assert_array_equal(got[0], want)
+    np.testing.assert_array_equal(got[1], got[0])
+    return want
+
+
+@pytest.mark.parametrize("res", [0.1, 0.02, 0.005])
+def test_room_scan_20M_points_multi_tile_runs_match_oracle(V, ctx, res):
+    """>= 20 M points of a duplicate-heavy surface scene: 10 tiles per workgroup; at 0.1 m the LDS set persists over the whole
+    run, at 0.02 m it fills and is wiped mid-run, at 0.005 m (about one voxel per pixel) nearly every tile wipes it."""
+    depth, q, t, K = room_views(26, 768, 1024, seed=3)
+    n = depth.size
+    assert n >= 20_000_000
+    d_xyz = fuse_on_device(ctx, depth, q, t, K)
+    want = check_device_cloud_against_oracle(V, ctx, d_xyz, n, res, 1 << 26)
+    assert len(want) > {0.1: 10_000, 0.02: 400_000, 0.005: 4_000_000}[res]
+    d_xyz.free()
+
+
+@pytest.mark.parametrize("order", ["shuffled", "lattice"])
+def test_8M_all_distinct_points_wipe_every_tile(V, ctx, order):
+    """Every point its own voxel (centres of a 256 x 256 x 128 lattice of 10 cm cells): each tile brings 1024 new codes, so
+    the LDS set is wiped before every tile; lattice order also exercises runs of x-neighbours in one wave."""
+    n = 256 * 256 * 128
+    i = np.arange(n, dtype=np.int64)
+    if order == "shuffled":
+        i = np.random.default_rng(8).permutation(n)
+    pts = np.stack([(i % 256) - 128, (i // 256) % 256 - 128, i // 65536 - 64], 1).astype(np.float32) * np.float32(0.1) + np.float32(0.05)
+    d_xyz = ctx.alloc(n * 12).upload(pts)
+    want = check_device_cloud_against_oracle(V, ctx, d_xyz, n, 0.1, 1 << 25)
+    assert len(want) == n
+    d_xyz.free()
+
+
+@pytest.mark.parametrize("kind", ["room", "random"])
+def test_fused_c5_geometry_cloud_to_voxels_matches_oracle(V, ctx, kind):
+    """BASELINE config 5's own pipeline at its geometry: >= 10 frames of 1920x1080 f32 depth + RGB through the colour-carrying
+    fused launch (r3d_fuse_frames_rgb), the cloud voxelised where it lies in HBM; 20.7 M points = 10 tiles per workgroup.
+    'room': surfaces (about 60 points per voxel, like an indoor scan); 'random': random depth (about 1 voxel per point, what
+    bench.py --workload c5 feeds)."""
+    F, H, W = 10, 1080, 1920
+    rng = np.random.default_rng(5)
+    if kind == "room":
+        depth, q, t, K = room_views(F, H, W, seed=5)
+    else:
+        depth = rng.random((F, H, W), dtype=np.float32) * 99.5 + 0.5
+        q, t, K = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10, (960.0, 960.0, 959.5, 539.5)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    d_xyz = fuse_on_device(ctx, depth, q, t, K, rgb=rgb)
+    want = check_device_cloud_against_oracle(V, ctx, d_xyz, F * H * W, 0.1, 1 << 26)
+    assert len(want) > (10_000 if kind == "room" else 10_000_000)
+    # and the map file: the library's serialiser on the GPU's codes == the oracle's on its own
+    if kind == "room":
+        assert V.format_bt(want, 0.1)[0] == OM.write_bt_bytes(want, 0.1)[0]
+    d_xyz.free()
