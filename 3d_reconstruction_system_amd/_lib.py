@@ -87,6 +87,12 @@ SIGNATURES = {
     "r3d_icp_state_reset": (_i, [_vp, _vp]),
     "r3d_icp_solve_dev": (_i, [_vp, _vp, _i, _vp]),
     "r3d_icp_iterate": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
+    "r3d_normals_organized": (_i, [_vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
+    "r3d_select_quantile_f32": (_i, [_vp, _vp, _i64, _d, _vp, _vp]),
+    "r3d_icp_plane_residuals": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),
+    "r3d_icp_plane_accumulate": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _f, _f, _f, _vp]),
+    "r3d_plane_step_from_sums": (_i, [_vp, _vp, _vp]),
+    "r3d_icp_iterate_plane": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _vp]),
     "r3d_comm_unique_id": (_i, [_vp]),
     "r3d_comm_create": (_i, [_vp, _vp, _i, _i, _pvp]),
     "r3d_comm_destroy": (_i, [_vp]),

@@ -29,7 +29,7 @@ struct r3d_ctx {
   // HIP-event stopwatch
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // grow-only scratch buffers for the *_host entry points and reductions
-  static constexpr int kScratchSlots = 6;
+  static constexpr int kScratchSlots = 8;   // 6, 7: point-to-plane / selection workspace (r3d_plane.hip)
   void* scratch[kScratchSlots] = {};
   size_t scratch_bytes[kScratchSlots] = {};
   // pinned staging buffers of the host pipeline: slot = ((direction * kPipeBufs + array) * 2 + parity)
@@ -93,6 +93,8 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
 // Stable LSD radix sort of 64-bit keys by their low `bits` bits (r3d_sort.hip); d_tmp holds n keys.
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits);
 
+// r3d_nnindex.hip: the index's own copy of the target cloud (original order), its size and its context
+int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx);
 // r3d_icp.hip: last kernel of a sums pass (partial rows + flagged fallback sources -> 18 sums [-> solve + ICP state])
 int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
                         const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,

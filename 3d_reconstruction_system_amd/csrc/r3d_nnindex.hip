@@ -693,6 +693,14 @@ int r3d_nn_index_query_sums(r3d_nn_index* ix, const float* d_src, int64_t n_src,
 
 }  // extern "C"
 
+int r3d_nn_index_target(r3d_nn_index* ix, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx) {
+  R3D_REQUIRE(ix != nullptr, "nn index is NULL");
+  if (d_tgt) *d_tgt = ix->d_tgt;
+  if (n_tgt) *n_tgt = ix->n;
+  if (ctx) *ctx = ix->ctx;
+  return R3D_OK;
+}
+
 int r3d_nn_index_query_solve(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
                              float max_d2, double* d_sums_out, int with_scale, double* d_state) {
   return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, 1, nullptr, true, max_d2, 0.f, d_sums_out, with_scale,

@@ -529,3 +529,190 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
     finally:
         dev.free()
     return T_total, info
+
+
+# ---- rigid point-to-plane registration of two partially overlapping single views (readme.md:25; icp:99-108) ----
+PLANE_SUMS = 29
+
+
+def plane_step_from_sums(sums):
+    """4x4 rigid step from the 29 sums of r3d_icp_plane_accumulate (library host code: the same arithmetic the device-side
+    solve runs).  Raises ValueError when the matched normals leave a freedom unconstrained."""
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    if sums.shape != (PLANE_SUMS,):
+        raise ValueError("expected 29 sums")
+    T = np.zeros(16, dtype=np.float64)
+    rms = C.c_double()
+    rc = L.load().r3d_plane_step_from_sums(sums.ctypes.data, T.ctypes.data, C.byref(rms))
+    if rc != L.OK:
+        raise ValueError(L.last_error())
+    return T.reshape(4, 4), rms.value
+
+
+def organized_normals(xyz, height, width, max_jump=0.05, viewpoint=None, ctx=None):
+    """Normals [F*H*W,3] float32 of an organised cloud (raster order of gentxtcord, p2c:34-44): r3d_normals_organized."""
+    ctx = ctx or default_context()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = xyz.shape[0]
+    if n % (height * width) != 0:
+        raise ValueError("cloud of %d points is not a whole number of %dx%d rasters" % (n, height, width))
+    out = np.zeros((n, 3), dtype=np.float32)
+    if n == 0:
+        return out
+    d_in, d_out = ctx.alloc(xyz.nbytes).upload(xyz), ctx.alloc(xyz.nbytes)
+    try:
+        vp = None if viewpoint is None else np.ascontiguousarray(viewpoint, dtype=np.float64)
+        L.check(ctx.lib.r3d_normals_organized(ctx.handle, d_in.ptr, n // (height * width), int(height), int(width),
+                                              float(max_jump), None if vp is None else vp.ctypes.data, d_out.ptr))
+        out = d_out.download(np.float32, n * 3).reshape(-1, 3)
+    finally:
+        d_in.free()
+        d_out.free()
+    return out
+
+
+def select_quantile(d_values_ptr, n, q, ctx=None):
+    """(value, count): the element of rank floor(q (m - 1)) of the m finite values of a DEVICE float32 array, selected on the
+    GPU (three histogram passes; 8 bytes come back)."""
+    ctx = ctx or default_context()
+    v, m = C.c_float(), C.c_int64()
+    L.check(ctx.lib.r3d_select_quantile_f32(ctx.handle, d_values_ptr, int(n), float(q), C.byref(v), C.byref(m)))
+    return v.value, m.value
+
+
+class PlaneIcpDevice:
+    """Source cloud + organised target cloud (with its normals) resident on one GPU for point-to-plane ICP."""
+
+    def __init__(self, src, tgt, tgt_shape=None, tgt_normals=None, max_jump=0.05, ctx=None):
+        self.ctx = c = ctx or default_context()
+        src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
+        tgt = np.ascontiguousarray(tgt, dtype=np.float32).reshape(-1, 3)
+        if tgt.shape[0] < 1 or src.shape[0] < 6:
+            raise ValueError("need a target cloud and at least 6 source points")
+        self.n, self.m = src.shape[0], tgt.shape[0]
+        self.d_src = c.alloc(src.nbytes).upload(src)         # moved cloud, index order
+        self.d_src0 = c.alloc(src.nbytes)                    # the cloud as it was at the last state reset
+        self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
+        self.d_nrm = c.alloc(tgt.nbytes)
+        if tgt_normals is not None:
+            nrm = np.ascontiguousarray(tgt_normals, dtype=np.float32).reshape(-1, 3)
+            if nrm.shape != tgt.shape:
+                raise ValueError("one normal per target point")
+            self.d_nrm.upload(nrm)
+        else:
+            if tgt_shape is None or int(tgt_shape[0]) * int(tgt_shape[1]) != self.m:
+                raise ValueError("an organised target needs tgt_shape=(H, W) with H*W == number of target points "
+                                 "(or pass tgt_normals)")
+            L.check(c.lib.r3d_normals_organized(c.handle, self.d_tgt.ptr, 1, int(tgt_shape[0]), int(tgt_shape[1]),
+                                                float(max_jump), None, self.d_nrm.ptr))
+        self.d_idx, self.d_d2 = c.alloc(self.n * 4), c.alloc(self.n * 4)
+        self.d_sums = c.alloc(PLANE_SUMS * 8)
+        self.d_state = c.alloc(STATE_DOUBLES * 8)
+        self.index = NNIndex(c, self.d_tgt.ptr, self.m)
+        self.d_perm = c.alloc(self.n * 4)
+        self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
+
+    def move_source(self, T):
+        c = self.ctx
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        L.check(c.lib.r3d_apply_T(c.handle, self.d_src.ptr, L.F32, self.n, T.ctypes.data, self.d_src.ptr, L.F32))
+
+    def state_reset(self):
+        c = self.ctx
+        L.check(c.lib.r3d_icp_state_reset(c.handle, self.d_state.ptr))
+        L.check(c.lib.r3d_memcpy_d2d(c.handle, self.d_src0.ptr, self.d_src.ptr, self.n * 12))
+
+    def nn(self):
+        self.index.query(self.d_src.ptr, self.n, self.d_idx.ptr, self.d_d2.ptr, presorted=True)
+
+    def sums(self, trim_q=0.5, gate_scale=20.0, max_d2=-1.0):
+        c = self.ctx
+        L.check(c.lib.r3d_icp_plane_accumulate(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.d_nrm.ptr, self.m,
+                                               self.d_idx.ptr, self.d_d2.ptr, float(max_d2), float(trim_q), float(gate_scale),
+                                               self.d_sums.ptr))
+        return self.d_sums.download(np.float64, PLANE_SUMS)
+
+    def iterate(self, n_iters, trim_q=0.5, gate_scale=20.0, max_d2=-1.0):
+        c = self.ctx
+        L.check(c.lib.r3d_icp_iterate_plane(c.handle, self.index.handle, self.d_src0.ptr, self.d_src.ptr, self.n, self.d_nrm.ptr,
+                                            self.d_idx.ptr, self.d_d2.ptr, int(n_iters), float(trim_q), float(gate_scale),
+                                            float(max_d2), self.d_state.ptr))
+
+    def state(self):
+        st = self.d_state.download(np.float64, STATE_DOUBLES)
+        it = int(st[32])
+        return {"T_total": st[0:16].reshape(4, 4).copy(), "T_step": st[16:32].reshape(4, 4).copy(), "iterations": it,
+                "degenerate": bool(st[33]), "rms": float(st[34]), "pairs": float(st[35]),
+                "rms_history": st[STATE_HISTORY:STATE_HISTORY + min(it, STATE_DOUBLES - STATE_HISTORY)].tolist()}
+
+    def normals(self):
+        return self.d_nrm.download(np.float32, self.m * 3).reshape(-1, 3)
+
+    def free(self):
+        self.index.close()
+        for b in (self.d_src, self.d_src0, self.d_tgt, self.d_nrm, self.d_idx, self.d_d2, self.d_sums, self.d_state, self.d_perm):
+            b.free()
+
+
+def icp_point_to_plane(src, tgt, tgt_shape=None, tgt_normals=None, init=None, max_iter=60, trim=0.5, gate_scale=20.0,
+                       max_dist=None, tol=1e-7, check_every=6, max_jump=0.05, ctx=None):
+    """RIGID transform (4x4, no scale) that maps the single-view cloud `src` onto the partially overlapping single-view cloud
+    `tgt` -- the T_data.txt of transfer_T_icp.py:99-108 for ./point/24.txt (src) against ./point/0.txt (tgt).
+    Returns (T, info).
+
+    tgt is ORGANISED: tgt_shape = (H, W), rows in gentxtcord's raster order (p2c:34-44); its normals come from the raster
+    neighbours on the GPU (or pass tgt_normals for an unorganised target).  Source rows at the camera origin (Z = 0 pixels, which
+    the reference emits like any other) and non-finite rows are left out.
+    init: 4x4 rough pose (e.g. the relative COLMAP pose with a guessed scale); None = identity.
+    Every iteration (all on the GPU, no host round trip inside a block of `check_every`): exact nearest neighbours through the
+    culled index -> residual r = n . (p - q) of every pair whose target has a plane -> per direction class of the target
+    normals the `trim` order statistic of r^2, pairs above gate_scale x that are left out (non-overlap / outlier rejection that
+    cannot silence a whole wall) -> 29 sums -> 6x6 solve -> move.  Stops when a step turns by less than `tol` rad and moves by
+    less than `tol` x the cloud's size, or after max_iter.
+    max_dist: pairs farther apart than this (point to point) never take part."""
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
+    keep = np.isfinite(src).all(axis=1) & np.any(src != 0, axis=1)
+    src = src[keep]
+    dev = PlaneIcpDevice(src, tgt, tgt_shape, tgt_normals, max_jump, ctx)
+    try:
+        T0 = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
+        if init is not None:
+            dev.move_source(T0)
+        dev.state_reset()
+        extent = float(np.sqrt(np.mean(np.sum((src - src.mean(0)) ** 2, axis=1)))) or 1.0
+        max_d2 = -1.0 if max_dist is None else float(max_dist) ** 2
+        done, converged = 0, None
+        while done < max_iter and converged is None:
+            k = min(max(int(check_every), 1), max_iter - done)
+            dev.iterate(k, trim, gate_scale, max_d2)
+            done += k
+            st = dev.state()
+            Ts = st["T_step"]
+            ang = float(np.arccos(np.clip((np.trace(Ts[:3, :3]) - 1.0) / 2.0, -1.0, 1.0)))
+            if st["degenerate"]:
+                raise ValueError("point-to-plane step undefined: the matched normals leave a freedom unconstrained "
+                                 "(one plane / parallel walls in the overlap), or fewer than 6 pairs")
+            if ang <= tol and float(np.abs(Ts[:3, 3]).max()) <= tol * extent:
+                converged = done
+        info = {"iterations": st["iterations"], "rms_history": st["rms_history"], "pairs": st["pairs"], "converged_at": converged,
+                "source_points_used": int(src.shape[0])}
+        return st["T_total"] @ T0, info
+    finally:
+        dev.free()
+
+
+def scale_from_baselines(T_icp, pose_a, pose_b):
+    """The scale that takes COLMAP's (arbitrary) unit to the depth maps' unit: |t_icp| / |t_colmap| for the same image pair
+    (readme.md:25).  T_icp maps camera-b points onto camera-a points in depth units; pose_* = (q_xyzw, t) rows of the COLMAP pose
+    file (p_cam = R p_world + t, c2w:57-59).  Returns (scale, T_colmap_ab)."""
+    from .poses import _rotation_matrix_xyzw
+
+    def mat(q, t):
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = _rotation_matrix_xyzw(q), np.asarray(t, dtype=np.float64)
+        return T
+    T_rel = mat(*pose_a) @ np.linalg.inv(mat(*pose_b))
+    base = float(np.linalg.norm(T_rel[:3, 3]))
+    if not base > 1e-12 * (float(np.linalg.norm(pose_a[1])) + float(np.linalg.norm(pose_b[1])) + 1e-300):
+        raise ValueError("the two COLMAP poses share their camera centre: no baseline to compare")
+    return float(np.linalg.norm(np.asarray(T_icp)[:3, 3])) / base, T_rel

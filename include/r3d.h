@@ -259,6 +259,60 @@ int r3d_icp_solve_dev(r3d_ctx* ctx, const double* d_sums, int with_scale, double
 int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,
                     uint32_t* d_idx, float* d_d2, int n_iters, int with_scale, float max_d2, double* d_state);
 
+/* ---- a8 continued: RIGID POINT-TO-PLANE registration of two partially overlapping single-view clouds -- the reference's
+ * own use of ICP ("match the point clouds corresponding to two images", readme.md:25; transfer_T_icp.py:107-108 merges the
+ * camera clouds ./point/0.txt and ./point/24.txt with the T this produces).  Build-defined; this text is the specification.
+ *
+ * r3d_normals_organized: unit normals of an ORGANISED cloud [n_frames][height][width][3] f32 -- the row-major raster order
+ * gentxtcord emits (pixel_to_camera.py:34-44).  For an interior pixel: a = p[j][i+1] - p[j][i-1], b = p[j+1][i] - p[j-1][i],
+ * n = a x b normalised (fp64 throughout, rounded once to f32), turned towards the viewpoint (h_viewpoint, 3 doubles; NULL =
+ * the origin, i.e. a camera-frame cloud).  The zero vector ("no plane here") is written for raster-border pixels, when the
+ * centre or a neighbour is non-finite or AT the viewpoint (Z = 0 pixels: the reference emits every pixel, p2c:24-44), when a
+ * neighbour's range differs from the centre's by more than max_jump x that range (a depth edge), and when a x b vanishes. */
+int r3d_normals_organized(r3d_ctx* ctx, const float* d_xyz, int64_t n_frames, int height, int width, float max_jump,
+                          const double* h_viewpoint, float* d_normals_out);
+/* Exact order statistic of a device fp32 array: the finite values (NaN, +-inf never count) sorted ascending, the element of
+ * rank floor(q (m - 1)) of the m finite ones (numpy.quantile(..., method="lower")); +inf and count 0 when there are none.
+ * Three histogram passes on the GPU, 8 bytes come back.  Synchronous. */
+int r3d_select_quantile_f32(r3d_ctx* ctx, const float* d_values, int64_t n, double q, float* h_value_out, int64_t* h_count_out);
+/* One matched pair = (p = src[k], q = tgt[idx[k]], n = tgt_normals[idx[k]]); it is ADMISSIBLE when idx[k] < n_tgt, n is not
+ * the zero vector, p, q, n are finite, and (max_d2 < 0 or d2[k] <= max_d2).  Residual r = n.x (p.x - q.x) + n.y (p.y - q.y)
+ * + n.z (p.z - q.z) in fp64, left to right.  r3d_icp_plane_residuals writes (float)(r r) per source row, +inf for pairs that
+ * are not admissible, and (d_class_out, optional) the DIRECTION CLASS of the pair's target normal, 255 for such pairs:
+ *   class = 8 major + 4 [n_major < 0] + 2 [n_(major+1) < 0] + [n_(major+2) < 0]   (24 classes; indices cyclic in x, y, z)
+ * where major is the axis of largest |component| of the stored f32 normal (lowest axis on ties).  Asynchronous. */
+int r3d_icp_plane_residuals(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const float* d_tgt_normals,
+                            int64_t n_tgt, const uint32_t* d_idx, const float* d_d2, float max_d2, float* d_r2_out,
+                            unsigned char* d_class_out);
+/* The 29 fp64 sums of the linearised point-to-plane normal equations over the admissible pairs -- with 0 < trim_q < 1 only
+ * over those whose (float)(r r) is <= g_c x gate_scale (one fp32 multiply), g_c = the trim_q order statistic
+ * (r3d_select_quantile_f32's rule) of that value over the admissible pairs OF THE SAME DIRECTION CLASS c.  The statistic is
+ * taken per class so that a wall whose pairs all disagree with the current pose keeps its say against walls that already
+ * fit (ranking all pairs together drops exactly the family that carries the missing constraint, and the pose slides along
+ * it); trim_q = 0.5, gate_scale = 20 keeps what lies within ~3 sigma of each class's median-based scale; gate_scale = 1 is
+ * plain rank trimming.  All selections run on the GPU.  With J = [p x n ; n]:
+ *   sums[0] = pairs, [1] = sum r^2, [2..7] = sum J r, [8..28] = upper triangle of sum J J^T, row-major.
+ * Deterministic (wave shuffle tree -> LDS -> fixed-order second stage, no float atomics).  d_sums_out: 29 doubles in HBM.
+ * Asynchronous. */
+#define R3D_PLANE_SUMS 29
+int r3d_icp_plane_accumulate(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const float* d_tgt_normals,
+                             int64_t n_tgt, const uint32_t* d_idx, const float* d_d2, float max_d2, float trim_q,
+                             float gate_scale, double* d_sums_out);
+/* The rigid step from the 29 sums: solve (sum J J^T) x = - sum J r (Cholesky, fp64, unknowns scaled to one length unit),
+ * x = (omega, v); h_T = [exp([omega]x) v; 0 1] (Rodrigues: exactly a rotation).  h_rms_out (optional) = sqrt(sum r^2 / pairs)
+ * before the step.  Pure host arithmetic -- and the very code the device-side solve runs.  R3D_ERR_INVALID (h_T = identity)
+ * with fewer than 6 pairs or when the matched normals leave a freedom unconstrained (one plane, two parallel walls ...). */
+int r3d_plane_step_from_sums(const double* h_sums, double* h_T, double* h_rms_out);
+/* n_iters whole point-to-plane iterations with NO host round trip: culled exact NN (d_src in the index's order,
+ * r3d_nn_index_sort_cloud; rigid moves preserve it) -> residuals + classes -> per-class selection -> 29 sums -> device solve
+ * -> source moved.  d_tgt_normals: normals of the index's target cloud in its ORIGINAL order.  d_src_orig != NULL: the cloud
+ * as it was when d_state was reset (same order as d_src); every iteration then writes d_src = T_total . d_src_orig (one
+ * rounding per point however many steps were taken); NULL: d_src is moved in place step by step.  d_state: the
+ * R3D_ICP_STATE_DOUBLES layout above ([34] / history = rms of r over the kept pairs).  Asynchronous. */
+int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_orig, float* d_src, int64_t n_src,
+                          const float* d_tgt_normals, uint32_t* d_idx, float* d_d2, int n_iters, float trim_q, float gate_scale,
+                          float max_d2, double* d_state);
+
 /* ---- (e) multi-GPU: one process per GPU, frames sharded in contiguous blocks (the frame loop of camera_to_world.py:149-172
  * carries no state between frames), ONE exchange step: an all-gather over RCCL / xGMI.  The reference has no
  * counterpart (single process, no collective); these entry points let a ctypes or plain-C host shard without torch.

@@ -1,0 +1,336 @@
+"""GPU: rigid point-to-plane registration of two PARTIALLY OVERLAPPING single-view depth clouds -- the reference's own use
+of ICP (readme.md:25; other_tools/transfer_T_icp.py:99-108 merges ./point/0.txt and ./point/24.txt with the resulting T).
+The reference holds no ICP code, so parity is against oracle/plane_ref.py (the build's definition restated in NumPy,
+include/r3d.h is the specification; PARITY UNPINNED) plus an independent SciPy implementation (cKDTree neighbours, row-wise
+least squares, scipy Rotation) of the same estimator, and known relative poses of synthetic two-view scenes."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import PKG, ROOT, r3d as _r3d
+from oracle import fusion_ref as O
+from oracle import icp_ref as OI
+from oracle import plane_ref as PR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def icp():
+    return importlib.import_module(PKG + ".icp")
+
+
+@pytest.fixture(scope="module")
+def S():
+    return importlib.import_module(PKG + ".synthetic")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _r3d().Context(0)
+    yield c
+    c.close()
+
+
+def rot(axis, deg):
+    a = np.deg2rad(deg)
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+
+def rough(T_true, deg=5.0, shift=(0.06, -0.05, 0.06)):
+    """A rough initial pose: the truth turned by `deg` about a skew axis and shifted (5 degrees / 10 cm off by default)."""
+    E = np.eye(4)
+    E[:3, :3] = rot([0.3, 1.0, 0.2], deg)
+    E[:3, 3] = shift
+    return E @ T_true
+
+
+def scene(S, h, w, yaw, baseline, noise=0.0, seed=1):
+    v = S.two_views(h, w, yaw_deg=yaw, baseline=baseline, depth_noise=noise, seed=seed)
+    K = v["K"]
+    pa = O.unproject(v["depth_a"], *K).astype(np.float32)
+    pb = O.unproject(v["depth_b"], *K).astype(np.float32)
+    return v, pa, pb
+
+
+# ---- the pieces, each against the oracle ---------------------------------------------------------------------------
+
+def test_organized_normals_bit_exact(icp, S, ctx):
+    """Interior pixels, raster borders, Z = 0 holes (at the viewpoint), non-finite points, depth edges; two frames in one
+    launch; a viewpoint that is not the origin."""
+    h, w = 60, 80
+    v, pa, pb = scene(S, h, w, 15.0, (0.35, 0.05, -0.2), noise=0.002)
+    cloud = np.concatenate([pa, pb]).reshape(2, h, w, 3).copy()
+    cloud[0, 10:14, 20:30] = 0.0                      # missing depth: the reference emits (0, 0, 0) for Z = 0 pixels
+    cloud[0, 30, 40] = np.nan
+    cloud[1, 5, 5] = np.inf
+    cloud[1, 20:40, 50:60] *= 0.6                     # an object in front of the wall: depth edges all round
+    flat = cloud.reshape(-1, 3)
+    for vp in (None, np.array([0.1, -0.2, 0.05])):
+        got = icp.organized_normals(flat, h, w, max_jump=0.05, viewpoint=vp, ctx=ctx)
+        want = PR.organized_normals(flat, h, w, 0.05, vp)
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    n = got.reshape(2, h, w, 3)
+    assert not n[:, 0].any() and not n[:, -1].any() and not n[:, :, 0].any() and not n[:, :, -1].any()     # raster borders
+    assert not n[0, 9:15, 20:30].any() and not n[0, 10:14, 19:31].any()              # holes + their 4-neighbours
+    assert not n[0, 29:32, 40].any() and not n[0, 30, 39:42].any() and n[0, 29, 39].any()
+    lens = np.linalg.norm(n.reshape(-1, 3).astype(np.float64), axis=1)
+    assert np.all((lens == 0) | (np.abs(lens - 1) < 1e-6)) and (lens > 0).mean() > 0.8
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 1000, 300001])
+def test_select_quantile_is_the_lower_order_statistic(icp, ctx, n):
+    rng = np.random.default_rng(n)
+    v = (rng.normal(size=n) * 10 ** rng.uniform(-6, 3, size=n)).astype(np.float32)
+    if n >= 1000:
+        v[::7] = np.abs(v[::7])
+        v[5::50] = np.inf
+        v[6::50] = np.nan
+        v[7::50] = -np.inf
+        v[11::13] = v[3]                               # many equal values
+        v[8::97] = 0.0
+        v[9::97] = -0.0
+    d = ctx.alloc(max(v.nbytes, 16))
+    if n:
+        d.upload(v)
+    for q in (0.0, 0.3, 0.5, 0.8, 1.0):
+        val, cnt = icp.select_quantile(d.ptr, n, q, ctx)
+        want, m = PR.quantile_lower(v, q)
+        assert cnt == m
+        if m == 0:
+            assert val == np.inf
+        else:
+            assert np.float32(val) == want or (val == 0 and want == 0), (q, val, want)
+    d.free()
+
+
+def matched_state(icp, S, ctx, h=96, w=128, yaw=15.0, baseline=(0.35, 0.05, -0.2), noise=0.002, holes=True):
+    """A PlaneIcpDevice a rough pose away from the truth, neighbours found; returns it with the host copies."""
+    v, pa, pb = scene(S, h, w, yaw, baseline, noise)
+    if holes:
+        pa = pa.copy()
+        pa.reshape(h, w, 3)[40:44, 60:70] = 0.0
+    dev = icp.PlaneIcpDevice(pb, pa, (h, w), ctx=ctx)
+    dev.move_source(rough(v["T_ab"]))
+    dev.state_reset()
+    dev.nn()
+    cur = dev.d_src.download(np.float32, dev.n * 3).reshape(-1, 3)
+    idx = dev.d_idx.download(np.uint32, dev.n)
+    d2 = dev.d_d2.download(np.float32, dev.n)
+    return v, pa, dev, cur, idx, d2
+
+
+def test_residuals_and_direction_classes_exact(icp, S, ctx):
+    v, pa, dev, cur, idx, d2 = matched_state(icp, S, ctx)
+    L = importlib.import_module(PKG + "._lib")
+    nrm = dev.normals()
+    np.testing.assert_array_equal(nrm.view(np.uint32), PR.organized_normals(pa, 96, 128, 0.05).view(np.uint32))
+    d_r2, d_cls = ctx.alloc(dev.n * 4), ctx.alloc(dev.n)
+    for max_d2 in (-1.0, 0.09):
+        L.check(ctx.lib.r3d_icp_plane_residuals(ctx.handle, dev.d_src.ptr, dev.n, dev.d_tgt.ptr, dev.d_nrm.ptr, dev.m, dev.d_idx.ptr,
+                                                dev.d_d2.ptr, max_d2, d_r2.ptr, d_cls.ptr))
+        r2, cls = d_r2.download(np.float32, dev.n), d_cls.download(np.uint8, dev.n)
+        want_r2, want_cls = PR.plane_residuals(cur, pa, nrm, idx, d2, max_d2)
+        np.testing.assert_array_equal(r2.view(np.uint32), want_r2.view(np.uint32))
+        np.testing.assert_array_equal(cls, want_cls)
+        assert np.isinf(r2).mean() > 0.02 and len(set(cls[cls < 255].tolist())) >= 3      # borders / holes; several wall classes
+    d_r2.free()
+    d_cls.free()
+    dev.free()
+
+
+@pytest.mark.parametrize("trim_q,gate_scale,max_d2", [(0.0, 1.0, -1.0), (0.5, 1.0, -1.0), (0.5, 20.0, -1.0), (0.8, 4.0, 0.09)])
+def test_29_sums_match_oracle_and_are_repeatable(icp, S, ctx, trim_q, gate_scale, max_d2):
+    v, pa, dev, cur, idx, d2 = matched_state(icp, S, ctx)
+    nrm = dev.normals()
+    got = dev.sums(trim_q, gate_scale, max_d2)
+    want = PR.plane_sums(cur, pa, nrm, idx, d2, max_d2, trim_q, gate_scale)
+    assert got[0] == want[0] and got[0] > 3000                   # the very same pairs take part
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11 * np.abs(want).max())
+    again = dev.sums(trim_q, gate_scale, max_d2)
+    np.testing.assert_array_equal(got.view(np.uint64), again.view(np.uint64))     # fixed-order tree: bitwise repeatable
+    T_lib, rms_lib = icp.plane_step_from_sums(got)
+    T_ref, rms_ref = PR.step_from_sums(want)
+    np.testing.assert_allclose(T_lib, T_ref, atol=1e-10)
+    assert abs(rms_lib - rms_ref) <= 1e-12 and abs(np.linalg.det(T_lib[:3, :3]) - 1) < 1e-12
+    dev.free()
+
+
+def test_device_loop_follows_the_oracle_loop_step_for_step(icp, S, ctx):
+    """r3d_icp_iterate_plane (culled exact NN, per-class selection, device solve, no host in the loop) against the oracle's
+    loop with the brute-force fp32 neighbour definition: same pairs, same steps."""
+    h, w = 72, 96
+    v, pa, pb = scene(S, h, w, 15.0, (0.35, 0.05, -0.2), noise=0.002)
+    T0 = rough(v["T_ab"])
+    na = PR.organized_normals(pa, h, w, 0.05)
+    keep = np.any(pb != 0, axis=1)
+    T_ref, hist = PR.icp_point_to_plane(pb[keep], pa, na, T0=T0, max_iter=8, trim_q=0.5, gate_scale=20.0, tol=0.0)
+    dev = icp.PlaneIcpDevice(pb[keep], pa, (h, w), ctx=ctx)
+    dev.move_source(T0)
+    dev.state_reset()
+    for k in range(8):
+        dev.iterate(1)
+        st = dev.state()
+        assert abs(st["rms"] - hist[k]) <= 1e-6 * hist[0], (k, st["rms"], hist[k])
+    np.testing.assert_allclose(st["T_total"] @ T0, T_ref, atol=2e-6)
+    dev.free()
+
+
+# ---- the estimator -----------------------------------------------------------------------------------------------------
+
+def independent_p2plane(src, tgt, h, w, T0, iters, trim=0.5, scale=20.0):
+    """The same estimator written independently with SciPy: cKDTree neighbours (fp64), normals by np.gradient-style slicing,
+    per-class gates with np.partition, row-wise least squares (no normal equations), scipy's rotation vector."""
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+    P = tgt.astype(np.float64).reshape(h, w, 3)
+    N = np.zeros_like(P)
+    a = P[1:-1, 2:] - P[1:-1, :-2]
+    b = P[2:, 1:-1] - P[:-2, 1:-1]
+    n = np.cross(a, b)
+    ln = np.linalg.norm(n, axis=2)
+    c = P[1:-1, 1:-1]
+    rc = np.linalg.norm(c, axis=2)
+    ok = (ln > 0) & (rc > 0)
+    for nb in (P[1:-1, :-2], P[1:-1, 2:], P[:-2, 1:-1], P[2:, 1:-1]):
+        rn = np.linalg.norm(nb, axis=2)
+        ok &= (rn > 0) & (np.abs(rn - rc) <= float(np.float32(0.05)) * rc)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = n / ln[..., None]
+    n[np.einsum("ijk,ijk->ij", n, c) > 0] *= -1
+    n[~ok] = 0
+    N[1:-1, 1:-1] = n
+    N = N.reshape(-1, 3).astype(np.float32)
+    has = np.any(N != 0, axis=1)
+    absn = np.abs(N)
+    major = np.where((absn[:, 1] > absn[:, 0]) & (absn[:, 1] >= absn[:, 2]), 1, np.where((absn[:, 2] > absn[:, 0]) & (absn[:, 2] > absn[:, 1]), 2, 0))
+    r_ = np.arange(N.shape[0])
+    cls_t = major * 8 + (N[r_, major] < 0) * 4 + (N[r_, (major + 1) % 3] < 0) * 2 + (N[r_, (major + 2) % 3] < 0)
+    tree = cKDTree(tgt.astype(np.float64))
+    start = (src.astype(np.float64) @ T0[:3, :3].T + T0[:3, 3]).astype(np.float32)
+    T_run = np.eye(4)
+    cur = start
+    for _ in range(iters):
+        _d, j = tree.query(cur.astype(np.float64))
+        p, q, nn = cur.astype(np.float64), tgt.astype(np.float64)[j], N[j].astype(np.float64)
+        r = np.einsum("ij,ij->i", nn, p - q)
+        r2 = (r * r).astype(np.float32)
+        adm = has[j]
+        keep = np.zeros(len(r), bool)
+        for k in np.unique(cls_t[j][adm]):
+            m = adm & (cls_t[j] == k)
+            vals = r2[m]
+            g = np.partition(vals, int(np.floor(float(np.float32(trim)) * (vals.size - 1))))[int(np.floor(float(np.float32(trim)) * (vals.size - 1)))]
+            keep |= m & (r2 <= np.float32(g) * np.float32(scale))
+        J = np.concatenate([np.cross(p[keep], nn[keep]), nn[keep]], axis=1)
+        x = np.linalg.lstsq(J, -r[keep], rcond=None)[0]
+        St = np.eye(4)
+        St[:3, :3] = Rotation.from_rotvec(x[:3]).as_matrix()
+        St[:3, 3] = x[3:]
+        T_run = St @ T_run
+        cur = (start.astype(np.float64) @ T_run[:3, :3].T + T_run[:3, 3]).astype(np.float32)
+    return T_run @ T0
+
+
+@pytest.mark.parametrize("yaw,baseline,overlap", [(12.0, (0.25, 0.03, -0.1), 0.74), (15.0, (0.35, 0.05, -0.2), 0.67),
+                                                  (20.0, (0.2, 0.02, -0.1), 0.62)])
+def test_two_partially_overlapping_views_are_registered(icp, S, ctx, yaw, baseline, overlap):
+    """Two 480x640 single views of a box room, 12-20 degrees apart (62-74 % of view b lies inside view a), depth noise 0.1 %,
+    from a rough pose 5 degrees / 10 cm off: the relative pose comes back to 1e-3 -- the case free-scale point-to-point ICP
+    cannot do (it slides along the walls: DESIGN.md 4.4).  Also from 10 degrees / 25 cm off, and noise-free to 2e-5."""
+    h, w = 480, 640
+    v, pa, pb = scene(S, h, w, yaw, baseline, noise=0.001)
+    K = v["K"]
+    x = pb.astype(np.float64) @ v["T_ab"][:3, :3].T + v["T_ab"][:3, 3]
+    inside = (x[:, 2] > 0) & (np.abs(x[:, 0] / x[:, 2] * K[0]) <= w / 2) & (np.abs(x[:, 1] / x[:, 2] * K[1]) <= h / 2)
+    assert abs(inside.mean() - overlap) < 0.03, inside.mean()
+    T, info = icp.icp_point_to_plane(pb, pa, tgt_shape=(h, w), init=rough(v["T_ab"]), ctx=ctx)
+    assert np.abs(T - v["T_ab"]).max() <= 1e-3, (np.abs(T - v["T_ab"]).max(), info)
+    assert info["converged_at"] is not None and info["iterations"] <= 60 and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-9
+    T2, info2 = icp.icp_point_to_plane(pb, pa, tgt_shape=(h, w), init=rough(v["T_ab"], 10.0, (-0.15, 0.1, 0.15)), ctx=ctx)
+    assert np.abs(T2 - v["T_ab"]).max() <= 1e-3, np.abs(T2 - v["T_ab"]).max()
+    v0, pa0, pb0 = scene(S, h, w, yaw, baseline, noise=0.0)
+    T3, _ = icp.icp_point_to_plane(pb0, pa0, tgt_shape=(h, w), init=rough(v0["T_ab"]), ctx=ctx)
+    assert np.abs(T3 - v0["T_ab"]).max() <= 2e-5, np.abs(T3 - v0["T_ab"]).max()
+    # bitwise repeatable end to end
+    T4, _ = icp.icp_point_to_plane(pb, pa, tgt_shape=(h, w), init=rough(v["T_ab"]), ctx=ctx)
+    np.testing.assert_array_equal(T, T4)
+
+
+def test_gpu_estimate_equals_an_independent_scipy_implementation(icp, S, ctx):
+    h, w = 240, 320
+    v, pa, pb = scene(S, h, w, 15.0, (0.35, 0.05, -0.2), noise=0.002)
+    T0 = rough(v["T_ab"])
+    keep = np.any(pb != 0, axis=1)
+    T_gpu, info = icp.icp_point_to_plane(pb, pa, tgt_shape=(h, w), init=T0, max_iter=18, check_every=18, tol=0.0, ctx=ctx)
+    T_ind = independent_p2plane(pb[keep], pa, h, w, T0, 18)
+    assert np.abs(T_gpu - T_ind).max() <= 2e-5, np.abs(T_gpu - T_ind).max()
+    assert np.abs(T_gpu - v["T_ab"]).max() <= 1e-3
+
+
+def test_one_wall_alone_is_reported_not_guessed(icp, S, ctx):
+    """A camera facing one wall square on sees a single plane: three freedoms are open.  The device solve flags it."""
+    h, w = 120, 160
+    z, q, t, K = S.room_view(h, w, 0.0, (0.0, 0.0, 0.0), fx=2.0 * w)             # narrow view of the z = +3 wall only
+    p = O.unproject(z.astype(np.float32), *K).astype(np.float32)
+    with pytest.raises(ValueError, match="unconstrained"):
+        icp.icp_point_to_plane(p, p, tgt_shape=(h, w), init=rough(np.eye(4), 1.0, (0.01, 0.0, 0.01)), ctx=ctx)
+
+
+def test_scale_from_the_two_baselines(icp, S, ctx):
+    """readme.md:25: COLMAP's unit is arbitrary; the ratio of the ICP baseline (depth units) to COLMAP's baseline for the same
+    image pair is the scale correction.  COLMAP poses given in a unit 1/2.5 of the depth maps' -> 2.5 comes back."""
+    h, w = 240, 320
+    v, pa, pb = scene(S, h, w, 12.0, (0.25, 0.03, -0.1), noise=0.001)
+    s_true = 2.5
+    pose_a = (v["pose_a"][0], v["pose_a"][1] / s_true)
+    pose_b = (v["pose_b"][0], v["pose_b"][1] / s_true)
+    _s, T_rel = icp.scale_from_baselines(np.eye(4), pose_a, pose_b)
+    np.testing.assert_allclose(T_rel[:3, :3], v["T_ab"][:3, :3], atol=1e-12)      # rotations need no scale
+    init = T_rel.copy()
+    init[:3, 3] *= 2.0                                                             # a guessed unit ratio, 20 % off
+    T, info = icp.icp_point_to_plane(pb, pa, tgt_shape=(h, w), init=init, ctx=ctx)
+    s, _ = icp.scale_from_baselines(T, pose_a, pose_b)
+    assert abs(s - s_true) / s_true <= 5e-3, s
+
+
+def run_script(rel, cwd, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, PKG, rel)] + list(args), cwd=cwd, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_dropin_estimates_T_data_from_two_camera_txt_files(icp, S, tmp_path):
+    """`python transfer_T_icp.py --estimate-rigid --colmap ...` in the reference's working directory: ./point/0.txt and
+    ./point/24.txt as pixel_to_camera.py writes them (repr() text, raster order), a COLMAP pose file in other units ->
+    T_data.txt (rigid, get_T's format), scale.txt, and the merged cloud of icp:99-110."""
+    R = _r3d()
+    h, w = 240, 320
+    v, pa, pb = scene(S, h, w, 12.0, (0.25, 0.03, -0.1), noise=0.001)
+    for d in ("point", "point_world", "ply/icp", "camera_pose"):
+        os.makedirs(tmp_path / d)
+    K = v["K"]
+    for name, depth in (("0", v["depth_a"]), ("24", v["depth_b"])):        # the camera txt format of gentxtcord (repr() text)
+        (tmp_path / "point" / (name + ".txt")).write_bytes(R.cloud_io.format_xyz_txt(O.unproject(depth, *K)))
+    s_true = 3.0
+    with open(tmp_path / "camera_pose" / "poses.txt", "w") as f:
+        f.write("id,tx,ty,tz,qx,qy,qz,qw,name,extra\n")
+        for k, (name, (q, t)) in enumerate((("0.png", v["pose_a"]), ("24.png", v["pose_b"]))):
+            f.write(",".join([str(k)] + [repr(float(x)) for x in (t / s_true)] + [repr(float(x)) for x in q] + [name, "x"]) + "\n")
+    out = run_script("other_tools/transfer_T_icp.py", str(tmp_path), "--estimate-rigid", "--colmap", "camera_pose/poses.txt",
+                     "0.png", "24.png", "--colmap-scale", "2.6")
+    assert "240x320 raster" in out and "scale" in out
+    T = R.get_T(str(tmp_path / "T_data.txt"))
+    assert np.abs(T - v["T_ab"]).max() <= 1e-3, np.abs(T - v["T_ab"]).max()
+    assert abs(float(open(tmp_path / "scale.txt").read()) - s_true) / s_true <= 5e-3
+    merged = R.cloud_io.read_ply(str(tmp_path / "ply" / "icp" / "024.ply"))
+    assert merged.shape == (2 * h * w, 3)
+    want_b = pb.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    np.testing.assert_allclose(merged[h * w:], want_b, atol=6e-5 + 1e-4)          # %.4f text

@@ -209,32 +209,9 @@ def test_keys_of_points_on_and_next_to_voxel_faces(V, ctx, res):
 # kernel with the LDS set (voxel_dedupe 0/2) against the one without it (1) bitwise.
 
 def room_views(n_frames, h, w, seed=0):
-    """Synthetic RGBD-like views of the inside of a 8 x 6 x 3 m box room: z-depth rasters (f32) of a pinhole camera turning
-    about the vertical axis near the room's centre, + the world->camera poses (q xyzw, t) in COLMAP's convention
-    p_cam = R p_w + t (c2w:57-59).  Neighbouring pixels and rows land in the same 10 cm voxels (duplicate-heavy)."""
-    rng = np.random.default_rng(seed)
-    fx = fy = 0.8 * w
-    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
-    u = (np.arange(w) - cx) / fx
-    v = (np.arange(h) - cy) / fy
-    rays = np.stack([np.broadcast_to(u[None, :], (h, w)), np.broadcast_to(v[:, None], (h, w)), np.ones((h, w))], -1)
-    lo, hi = np.array([-4.0, -1.5, -3.0]), np.array([4.0, 1.5, 3.0])
-    depths, quats, ts = [], [], []
-    for f in range(n_frames):
-        ang = 2 * np.pi * f / n_frames + 0.1
-        Rwc = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])   # camera -> world
-        c = rng.uniform(-0.8, 0.8, 3) * np.array([1.0, 0.3, 1.0])
-        d = rays @ Rwc.T                                         # ray directions in the world, per unit camera z
-        with np.errstate(divide="ignore", invalid="ignore"):
-            t_hi = np.where(d > 0, (hi - c) / d, np.inf)
-            t_lo = np.where(d < 0, (lo - c) / d, np.inf)
-        z = np.minimum(t_hi, t_lo).min(-1)                       # camera-frame z at the first wall hit
-        depths.append(z.astype(np.float32))
-        R = Rwc.T                                                # world -> camera
-        t = -R @ c
-        quats.append([0.0, np.sin(-ang / 2), 0.0, np.cos(-ang / 2)])   # R = Ry(-ang), scalar-last like the pose file
-        ts.append(t)
-    return np.stack(depths), np.array(quats), np.array(ts), (fx, fy, cx, cy)
+    """Views of the inside of a box room (3d_reconstruction_system_amd/synthetic.py): neighbouring pixels and rows land in the
+    same 10 cm voxels (duplicate-heavy, like an indoor scan)."""
+    return importlib.import_module(PKG + ".synthetic").room_views(n_frames, h, w, seed)
 
 
 def fuse_on_device(ctx, depth, q, t, K, rgb=None):
