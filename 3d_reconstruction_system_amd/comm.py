@@ -45,12 +45,33 @@ def env_local_device():
     return local
 
 
+def _rendezvous_tag():
+    return os.environ.get("R3D_RENDEZVOUS", "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "29500"),
+                                                             os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getuid()))
+
+
 def _rendezvous_name():
     # abstract-namespace Unix socket: lives only as long as rank 0 holds it, nothing to clean up or to go stale.
-    # Concurrent jobs on one node already need distinct MASTER_PORTs for their launcher.
-    tag = os.environ.get("R3D_RENDEZVOUS", "%s_%s" % (os.environ.get("MASTER_PORT", "29500"),
-                                                      os.environ.get("TORCHELASTIC_RUN_ID", "none")))
-    return b"\0r3d_comm_" + tag.encode()
+    # The name carries a digest of (MASTER_ADDR, MASTER_PORT, run id, uid): concurrent jobs on one node already need distinct
+    # MASTER_PORTs for their launcher, and another user's job cannot collide with this one by accident.
+    import hashlib
+    return b"\0r3d_comm_" + hashlib.sha256(_rendezvous_tag().encode()).hexdigest()[:32].encode()
+
+
+def _nonce():
+    """16 bytes both sides derive from the job's tag: a stray or foreign connection that does not send them is ignored."""
+    import hashlib
+    return hashlib.sha256(b"r3d-nonce:" + _rendezvous_tag().encode()).digest()[:16]
+
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        part = conn.recv(n - len(buf))
+        if not part:
+            return None
+        buf += part
+    return buf
 
 
 def exchange_unique_id(rank, world, timeout=120.0):
@@ -77,10 +98,14 @@ def exchange_unique_id(rank, world, timeout=120.0):
                 with conn:
                     conn.settimeout(10.0)
                     try:
-                        who = int.from_bytes(conn.recv(4), "little")
-                        conn.sendall(uid)
-                        if conn.recv(1) == b"k":          # the rank holds all 128 bytes
-                            served.add(who)
+                        hello = _recv_exact(conn, 20)         # nonce + rank, exactly
+                        if hello is None or hello[:16] != _nonce():
+                            continue                          # not one of this job's ranks
+                        who = int.from_bytes(hello[16:], "little")
+                        if not 0 < who < world:
+                            continue
+                        conn.sendall(uid)                     # all 128 bytes handed to the kernel = served (a lost
+                        served.add(who)                       # ack must not keep rank 0 here while the others move on)
                     except OSError:
                         pass                 # that rank will retry
         finally:
@@ -91,15 +116,9 @@ def exchange_unique_id(rank, world, timeout=120.0):
         try:
             c.settimeout(10.0)
             c.connect(name)
-            c.sendall(int(rank).to_bytes(4, "little"))
-            uid = b""
-            while len(uid) < ID_BYTES:
-                part = c.recv(ID_BYTES - len(uid))
-                if not part:
-                    break
-                uid += part
-            if len(uid) == ID_BYTES:
-                c.sendall(b"k")
+            c.sendall(_nonce() + int(rank).to_bytes(4, "little"))
+            uid = _recv_exact(c, ID_BYTES)
+            if uid is not None:
                 return uid
         except OSError:
             pass

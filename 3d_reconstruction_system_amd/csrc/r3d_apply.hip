@@ -42,16 +42,15 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// One point's three coordinates as doubles, loaded with nontemporal loads.  The compiler does not see inline-asm
-// loads: the caller issues all of them, then wait_loads(), then reads the registers.
+// A lane's N points, loaded with nontemporal loads (a once-read stream: +6 % over cached loads on this 1:1 read/write
+// kernel).  The compiler does not track vmcnt for inline-asm loads, so ALL of a lane's loads AND the s_waitcnt that
+// completes them sit in ONE asm statement: its outputs are defined only after the wait, and no register copy or spill the
+// compiler may insert can read them early.  Addresses are clamped by the caller (unconditional loads).
 template <typename T>
 struct RawPoint;
 template <>
 struct RawPoint<float> {
   f32x3 v;
-  __device__ __forceinline__ void issue(const float* src) {
-    asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(v) : "v"(src) : "memory");
-  }
   __device__ __forceinline__ void get(double p[3]) const {
     p[0] = (double)v.x;
     p[1] = (double)v.y;
@@ -62,19 +61,47 @@ template <>
 struct RawPoint<double> {
   f64x2 xy;
   double z;
-  __device__ __forceinline__ void issue(const double* src) {
-    asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx2 %1, %2, off offset:16 nt"
-                 : "=&v"(xy), "=&v"(z)
-                 : "v"(src)
-                 : "memory");
-  }
   __device__ __forceinline__ void get(double p[3]) const {
     p[0] = xy.x;
     p[1] = xy.y;
     p[2] = z;
   }
 };
-__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#define R3D_LD3(o, a) "global_load_dwordx3 %" #o ", %" #a ", off nt\n\t"
+#define R3D_LD6(o, o2, a) "global_load_dwordx4 %" #o ", %" #a ", off nt\n\tglobal_load_dwordx2 %" #o2 ", %" #a ", off offset:16 nt\n\t"
+
+__device__ __forceinline__ void load_points(RawPoint<float> (&r)[4], const float* const (&a)[4]) {
+  asm volatile(R3D_LD3(0, 4) R3D_LD3(1, 5) R3D_LD3(2, 6) R3D_LD3(3, 7) "s_waitcnt vmcnt(0)"
+               : "=&v"(r[0].v), "=&v"(r[1].v), "=&v"(r[2].v), "=&v"(r[3].v)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+               : "memory");
+}
+__device__ __forceinline__ void load_points(RawPoint<float> (&r)[8], const float* const (&a)[8]) {
+  asm volatile(R3D_LD3(0, 8) R3D_LD3(1, 9) R3D_LD3(2, 10) R3D_LD3(3, 11) R3D_LD3(4, 12) R3D_LD3(5, 13) R3D_LD3(6, 14) R3D_LD3(7, 15)
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(r[0].v), "=&v"(r[1].v), "=&v"(r[2].v), "=&v"(r[3].v), "=&v"(r[4].v), "=&v"(r[5].v), "=&v"(r[6].v), "=&v"(r[7].v)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+               : "memory");
+}
+__device__ __forceinline__ void load_points(RawPoint<double> (&r)[4], const double* const (&a)[4]) {
+  asm volatile(R3D_LD6(0, 1, 8) R3D_LD6(2, 3, 9) R3D_LD6(4, 5, 10) R3D_LD6(6, 7, 11) "s_waitcnt vmcnt(0)"
+               : "=&v"(r[0].xy), "=&v"(r[0].z), "=&v"(r[1].xy), "=&v"(r[1].z), "=&v"(r[2].xy), "=&v"(r[2].z), "=&v"(r[3].xy),
+                 "=&v"(r[3].z)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+               : "memory");
+}
+__device__ __forceinline__ void load_points(RawPoint<double> (&r)[8], const double* const (&a)[8]) {
+  asm volatile(R3D_LD6(0, 1, 16) R3D_LD6(2, 3, 17) R3D_LD6(4, 5, 18) R3D_LD6(6, 7, 19) R3D_LD6(8, 9, 20) R3D_LD6(10, 11, 21)
+               R3D_LD6(12, 13, 22) R3D_LD6(14, 15, 23) "s_waitcnt vmcnt(0)"
+               : "=&v"(r[0].xy), "=&v"(r[0].z), "=&v"(r[1].xy), "=&v"(r[1].z), "=&v"(r[2].xy), "=&v"(r[2].z), "=&v"(r[3].xy),
+                 "=&v"(r[3].z), "=&v"(r[4].xy), "=&v"(r[4].z), "=&v"(r[5].xy), "=&v"(r[5].z), "=&v"(r[6].xy), "=&v"(r[6].z),
+                 "=&v"(r[7].xy), "=&v"(r[7].z)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+               : "memory");
+}
+#undef R3D_LD3
+#undef R3D_LD6
 
 // output row `r` of the transform for the point p (fp64, the reference's order)
 template <bool SE3>
@@ -95,12 +122,13 @@ __global__ __launch_bounds__(kThreads) void apply_lane_kernel(const ApplyArgs a)
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t base = tile * kTile + threadIdx.x;
     RawPoint<IT> raw[kPts];
+    const IT* addr[kPts];
 #pragma unroll
     for (int r = 0; r < kPts; ++r) {
       const uint64_t i = base + (uint64_t)r * kThreads;
-      if (i < a.n) raw[r].issue(in + i * 3);
+      addr[r] = in + (i < a.n ? i : a.n - 1) * 3;   // clamped: the loads are unconditional
     }
-    wait_loads();
+    load_points(raw, addr);
 #pragma unroll
     for (int r = 0; r < kPts; ++r) {
       const uint64_t i = base + (uint64_t)r * kThreads;
@@ -132,12 +160,13 @@ __global__ __launch_bounds__(kThreads) void apply_pair_kernel(const ApplyArgs a)
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t p0 = tile * kTile;
     RawPoint<IT> raw[kItems];
+    const IT* addr[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; ++r) {
       const uint64_t i = p0 + ((r * kThreads + threadIdx.x) >> 1);
-      if (i < a.n) raw[r].issue(in + i * 3);
+      addr[r] = in + (i < a.n ? i : a.n - 1) * 3;   // clamped: the loads are unconditional
     }
-    wait_loads();
+    load_points(raw, addr);
 #pragma unroll
     for (int r = 0; r < kItems; ++r) {
       const uint32_t q = r * kThreads + threadIdx.x;

@@ -40,7 +40,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPx = 4;                      // pixels per lane (f32 kernels)
 constexpr int kTile = kThreads * kPx;       // pixels per workgroup tile (all kernels)
-constexpr int kStageAutoMB = 64;            // auto: stage a launch's inputs in the Infinity Cache when they exceed this
 constexpr int kStageChunkMB = 96;           // ... in steps of this many input MB (sweep: profiles/r02_cold_inputs.log)
 
 struct FuseDims {
@@ -452,7 +451,7 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   // but f32 depth + colour (7 of 23 B/point are inputs) 5.7 -> 5.0: that one stays as it is)
   const bool small_inputs = dsz <= 2 || (out_dtype == R3D_F64 && !(d_rgb && !colour_after));
   const bool stage = ctx->fuse_prefetch == 2 ||
-                     (ctx->fuse_prefetch == 0 && small_inputs && in_bytes > ((uint64_t)kStageAutoMB << 20));
+                     (ctx->fuse_prefetch == 0 && small_inputs && in_bytes > ((uint64_t)ctx->fuse_stage_auto_mb << 20));
   int frames_per_step = n_frames;
   if (stage) {
     const uint64_t f = chunk_bytes / (in_per_frame ? in_per_frame : 1);

@@ -22,6 +22,7 @@ struct r3d_ctx {
   int fuse_loads = 0;    // 0 auto (vector loads + in-wave redistribution where the raster allows), 1 element loads (A/B)
   int fuse_prefetch = 0; // 0 auto, 1 off, 2 on: stage the inputs of a launch in the Infinity Cache with a read-only sweep first
   int fuse_chunk_mb = 0; // 0 auto: input bytes staged (and fused) per step when the prefetch is on
+  int fuse_stage_auto_mb = 64;  // fuse_prefetch auto: stage a launch's inputs when they exceed this many MB
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;

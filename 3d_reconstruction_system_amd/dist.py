@@ -66,7 +66,10 @@ class TorchTransport:
 class R3dTransport:
     """The exchange step through the C ABI (comm.Comm: RCCL bound by libr3d_hip.so, unequal shards by grouped
     send/recv, no padding, no torch.distributed).  Tensors only lend their HBM addresses; the transfers run on the
-    comm's ctx stream, so create that ctx on the torch stream the tensors live on (Context(dev, stream=...))."""
+    comm's ctx stream.  When that is not the torch stream current at the call (e.g. under `with torch.cuda.stream(s)`), the
+    two are ordered here: the comm stream waits for what torch has enqueued so far (the fuse that wrote the shard), torch's
+    stream waits for the collective, and both tensors are recorded on the comm stream so that the caching allocator does not
+    hand their memory out while it is still in flight there."""
 
     name = "r3d_comm"
 
@@ -74,11 +77,24 @@ class R3dTransport:
         self.comm, self.algo = comm, int(algo)
         self.rank, self.world = comm.rank, comm.world
 
+    def _comm_stream(self, device):
+        """The comm ctx's raw hipStream_t as a torch stream object, or None when it IS torch's current stream."""
+        import torch
+        handle = self.comm.ctx.stream_handle()
+        cur = torch.cuda.current_stream(device)
+        if handle == cur.cuda_stream:
+            return None, cur
+        ext = torch.cuda.default_stream(device) if handle == 0 else torch.cuda.ExternalStream(handle, device=device)
+        return ext, cur
+
     def allgather_rows(self, shard, rows_per_rank, out=None):
         import torch
         assert len(rows_per_rank) == self.world and shard.shape[0] == rows_per_rank[self.rank]
         if shard.device.type != "cuda":
             raise RuntimeError("r3d_comm moves HBM buffers; got a tensor on %s" % shard.device)
+        idx = shard.device.index if shard.device.index is not None else torch.cuda.current_device()
+        if idx != self.comm.ctx.device:
+            raise RuntimeError("the communicator lives on GPU %d, the shard on GPU %d" % (self.comm.ctx.device, idx))
         tail = tuple(shard.shape[1:])
         row_bytes = shard.element_size()
         for d in tail:
@@ -86,7 +102,14 @@ class R3dTransport:
         if out is None:
             out = torch.empty((sum(rows_per_rank),) + tail, dtype=shard.dtype, device=shard.device)
         shard = shard.contiguous()
+        ext, cur = self._comm_stream(shard.device)
+        if ext is not None:
+            ext.wait_stream(cur)                # producers of `shard` (and earlier readers of `out`) first
         self.comm.allgather(shard.data_ptr(), [c * row_bytes for c in rows_per_rank], out.data_ptr(), self.algo)
+        if ext is not None:
+            cur.wait_stream(ext)                # consumers on torch's stream see the gathered rows
+            shard.record_stream(ext)
+            out.record_stream(ext)
         return out
 
 
@@ -126,7 +149,8 @@ class ShardedFusion:
     def _ctx_for(self, device):
         """(Context, Camera) bound to the torch stream that is current NOW on `device`: a context launches on the
         stream it was created with, so it is cached per (device, stream) -- a caller that switches streams
-        (torch.cuda.stream(s)) gets a context on that stream, ordered with its producers and consumers."""
+        (torch.cuda.stream(s)) gets a context on that stream, ordered with its producers and consumers.  The comm's own
+        context is reused when it sits on that very stream; otherwise R3dTransport.allgather_rows orders the two streams."""
         torch = self.torch
         idx = device.index if device.index is not None else torch.cuda.current_device()
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -134,12 +158,11 @@ class ShardedFusion:
         hit = self._ctxs.get(key)
         if hit is None:
             from .device import Context
-            if isinstance(self._transport, R3dTransport) and self._transport.comm.ctx.device == idx:
-                c = self._transport.comm.ctx          # the comm's ctx: compute and exchange share one stream
-                stream_of = c.stream_handle()
-                if stream_of != stream:
-                    c = Context(idx, stream=stream)
-            else:
+            c = None
+            if isinstance(self._transport, R3dTransport) and self._transport.comm.ctx.device == idx \
+                    and self._transport.comm.ctx.stream_handle() == stream:
+                c = self._transport.comm.ctx          # compute and exchange share one stream
+            if c is None:
                 c = Context(idx, stream=stream)
             hit = (c, c.camera(self.h, self.w, *self.intrinsics))
             self._ctxs[key] = hit
@@ -261,8 +284,30 @@ def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm,
     if n_frames == 0:
         return names, 0, 0, np.empty((0, 0, 0), np.uint8), (np.empty((0, 3), out_dtype) if rank == 0 or everywhere else None)
     paths = [os.path.join(depth_dir, n) for n in names]
-    # a rank whose block is empty (more GPUs than frames) still needs the raster size: the first frame's
-    probe = cloud_io.read_depth_batch(paths[lo:hi] if hi > lo else paths[:1])
+    # a rank whose block is empty (more GPUs than frames) still needs the raster size: the first frame's.
+    # Every rank must enter the collective below or none: a rank-local failure (missing / corrupt PNG) or rasters that differ
+    # between blocks would leave the others waiting in RCCL for ever (it has no timeout).  So the ranks first agree on
+    # (ok, H, W, bytes per depth value) with one small all-gather and raise the SAME error everywhere.
+    err, probe = None, None
+    try:
+        probe = cloud_io.read_depth_batch(paths[lo:hi] if hi > lo else paths[:1])
+    except Exception as e:          # noqa: BLE001 -- reported on every rank below
+        err = e
+    mine_row = np.array([0.0 if err is None else 1.0, 0.0 if probe is None else probe.shape[1], 0.0 if probe is None else probe.shape[2],
+                         0.0 if probe is None else probe.dtype.itemsize], dtype=np.float64)
+    d_rows = ctx.alloc(8 * 4 * (world_size + 1))
+    try:
+        from . import _lib as L
+        L.check(ctx.lib.r3d_memcpy_h2d(ctx.handle, d_rows.ptr + 32 * world_size, mine_row.ctypes.data, 32))
+        comm.allgather(d_rows.ptr + 32 * world_size, [32] * world_size, d_rows.ptr)
+        rows = d_rows.download(np.float64, 4 * world_size).reshape(world_size, 4)
+    finally:
+        d_rows.free()
+    bad = [r for r in range(world_size) if rows[r, 0] != 0]
+    if bad:
+        raise RuntimeError("rank(s) %s could not read their depth frames%s" % (bad, "" if err is None else ": %s" % err))
+    if not (np.all(rows[:, 1:] == rows[0, 1:])):
+        raise ValueError("depth rasters differ between the ranks' frame blocks (H, W, bytes): %s" % rows[:, 1:].tolist())
     depths = probe if hi > lo else probe[:0]
     h, w = probe.shape[1], probe.shape[2]
     per = h * w

@@ -74,8 +74,8 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
  * (workgroup counts), "nn_variant" (sources per lane of the NN sweeps: 1/2/4), "voxel_dedupe" (0 auto, 1 off, 2 on),
  * "fuse_prefetch" (0 auto, 1 off, 2 on: a read-only sweep stages a fused launch's inputs in the 256 MiB Infinity Cache first,
  * chunk by chunk -- "fuse_chunk_mb", 0 = 96 -- so that the kernel's reads do not mix with its write stream at the DRAM; auto:
- * on when one launch reads more than 64 MB of small-share inputs, i.e. more than the cache will have kept from their
- * producer), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
+ * on when one launch reads more than "fuse_stage_auto_mb" (default 64) MB of small-share inputs, i.e. more than the cache will
+ * have kept from their producer), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
  * No knob changes any result bit.  Unknown key -> R3D_ERR_INVALID.  (Kernel A/B variants live in tools/ab_kernels.hip,
  * not in the library.) */
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);

@@ -78,6 +78,17 @@ def test_sharded_engine_over_r3d_transport_single_rank(R, real_rccl):
     s.synchronize()
     np.testing.assert_array_equal(d.cpu().numpy(), want)
     assert len(eng._ctxs) == 2
+    # ... and the exchange orders itself with that stream: compute on the side stream, the collective on the comm's
+    # stream.  Many rounds with a busy side stream: a missing wait would ship the shard before the fuse wrote it.
+    with torch.cuda.stream(s):
+        for k in range(12):
+            big = torch.empty((F * H * W, 3), dtype=torch.float32, device=dev)
+            filler = torch.randn(1 << 22, device=dev).sin_().sum()         # keeps the side stream behind the host
+            got = eng.fuse_and_gather(dd, pp, [F], out=big)
+            gi = eng.gather_inputs_and_fuse(dd, pp, [F])
+            assert torch.equal(got, torch.from_numpy(want).to(dev)) and torch.equal(gi, got), k
+            del filler
+    s.synchronize()
     comm.close()
     ctx.close()
 

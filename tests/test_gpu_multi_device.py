@@ -1,0 +1,107 @@
+"""GPU, only where >= 2 MI355X are visible (skipped on the one-GPU test box): everything that so far met RCCL with one
+rank only -- the plain-C sharded consumer, bench.py --gpus 2 exactly as the driver launches it, the config-5 shape and the
+sharded camera_to_world drop-in -- on the REAL RCCL over xGMI.  The first multi-GPU lease exercises them automatically."""
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import PKG, ROOT, r3d as _r3d
+
+pytestmark = pytest.mark.gpu
+
+
+def visible_gpus():
+    L = importlib.import_module(PKG + "._lib")
+    n = C.c_int(0)
+    if L.load().r3d_device_count(C.byref(n)) != 0:
+        return 0
+    return n.value
+
+
+@pytest.fixture(scope="module")
+def n_gpus():
+    n = visible_gpus()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs for RCCL ranks on distinct devices (this box shows %d)" % n)
+    return n
+
+
+def launch(world, script_args, timeout=900, env=None):
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
+           "127.0.0.1", "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                   **(env or {})))
+
+
+def test_plain_c_consumer_on_real_rccl(tmp_path, n_gpus):
+    exe = str(tmp_path / "comm_2rank")
+    libdir = os.path.join(ROOT, PKG)
+    build = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c", "comm_2rank.c"), "-o", exe, "-L", libdir, "-lr3d_hip", "-lm",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    for world, frames, algo in ((2, 5, 0), (2, 6, 1), (min(n_gpus, 4), 9, 2)):
+        run = subprocess.run([exe, str(world), str(frames), str(algo)], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert run.stdout.count("identical to the single-GPU cloud") == world, run.stdout
+
+
+def test_bench_two_gpus_as_the_driver_launches_it(n_gpus):
+    r = launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "watchdog" not in d and "r3d_comm over RCCL" in d["transport"], d.get("transport")
+    for m in ("none", "outputs", "inputs", "outputs_direct", "inputs_direct", "inputs_overlap"):
+        assert "ms_per_step" in d["assemble"][m], (m, d["assemble"][m])
+    # shards stay resident: two GPUs fuse twice the points in the time of one
+    assert d["value_shards_resident"] > 1.6 * d["kernel_only_Mpoints_s_per_gpu"] * 0.9
+    assert d["assemble"]["outputs_direct"]["xgmi_GBps_per_link"] > 10
+
+
+def test_config5_shape_on_two_gpus(n_gpus):
+    r = launch(2, [os.path.join(ROOT, "bench.py"), "--workload", "c5", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                   "--frames", "10"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    n = 10 * 1080 * 1920
+    assert d["n_gpus"] == 2 and d["union_overflow"] == 0 and n < d["union_voxels"] <= 2 * n
+
+
+def test_sharded_camera_to_world_dropin_on_real_rccl(tmp_path, n_gpus, golden_dir):
+    """The drop-in under a one-process-per-GPU launcher, 2 ranks on 2 GPUs: every output file equals the single-process run."""
+    import shutil
+    R = _r3d()
+    rng = np.random.default_rng(3)
+    F, H, W = 7, 48, 64
+    from PIL import Image
+    for sub in ("a", "b"):
+        for d in ("depth", "point", "point_world", "ply", "camera_pose"):
+            os.makedirs(tmp_path / sub / d)
+    with open(tmp_path / "a" / "camera_pose" / "image_colmap_simi_2.txt", "w") as f:
+        f.write("id,tx,ty,tz,qx,qy,qz,qw,name,extra\n")
+        for k in range(F):
+            Image.fromarray(rng.integers(0, 256, (H, W), dtype=np.uint8)).save(tmp_path / "a" / "depth" / ("%03d.png" % k))
+            q, t = rng.normal(size=4), rng.normal(size=3) * 10
+            f.write(",".join([str(k)] + [repr(float(x)) for x in t] + [repr(float(x)) for x in q] + ["%03d.png" % k, "x"]) + "\n")
+    shutil.copytree(tmp_path / "a" / "depth", tmp_path / "b" / "depth", dirs_exist_ok=True)
+    shutil.copy(tmp_path / "a" / "camera_pose" / "image_colmap_simi_2.txt", tmp_path / "b" / "camera_pose")
+    script = os.path.join(ROOT, PKG, "transfer", "camera_to_world.py")
+    one = subprocess.run([sys.executable, script], cwd=tmp_path / "a", capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    port = 29650 + os.getpid() % 200
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), script], cwd=tmp_path / "b", capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    for rel in ["ply/small_035_p8.ply", "point_world/small_worldpoint_5_23_5.txt"] + ["point/%03d.txt" % k for k in range(F)]:
+        assert (tmp_path / "a" / rel).read_bytes() == (tmp_path / "b" / rel).read_bytes(), rel
