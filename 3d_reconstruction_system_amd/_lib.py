@@ -74,10 +74,14 @@ SIGNATURES = {
     "r3d_apply_T": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_apply_T_host": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
     "r3d_apply_T_dev": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),
+    "r3d_apply_T_many": (_i, [_vp, _vp, _i, _i64, _vp, _i, _vp, _i]),
     "r3d_icp_nn": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "r3d_icp_nn_host": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "r3d_nn_index_create": (_i, [_vp, _vp, _i64, _pvp]),
     "r3d_nn_index_destroy": (_i, [_vp]),
+    "r3d_nn_index_rebuild": (_i, [_vp, _vp, _i64]),
+    "r3d_gather_rows_strided": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "r3d_gather_rows": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "r3d_nn_index_query": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "r3d_nn_index_sort_cloud": (_i, [_vp, _vp, _i64, _vp]),
     "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),
@@ -89,6 +93,8 @@ SIGNATURES = {
     "r3d_icp_iterate": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _f, _vp]),
     "r3d_normals_organized": (_i, [_vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
     "r3d_select_quantile_f32": (_i, [_vp, _vp, _i64, _d, _vp, _vp]),
+    "r3d_select_quantile_f32_dev": (_i, [_vp, _vp, _i64, _d, _vp]),
+    "r3d_trimmed_means_f32": (_i, [_vp, _vp, _i, _i64, _d, _vp]),
     "r3d_icp_plane_residuals": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),
     "r3d_icp_plane_accumulate": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _f, _f, _f, _vp]),
     "r3d_plane_step_from_sums": (_i, [_vp, _vp, _vp]),

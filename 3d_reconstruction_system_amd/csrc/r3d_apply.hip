@@ -296,6 +296,20 @@ int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n
   return apply_host_common<false>(ctx, h_xyz_in, in_dtype, n_points, h_T, h_xyz_out, out_dtype);
 }
 
+int r3d_apply_T_many(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_Ts, int n_transforms,
+                     void* d_xyz_out, int out_dtype) {
+  R3D_REQUIRE(n_transforms >= 0 && (n_transforms == 0 || h_Ts != nullptr), "bad transform list");
+  R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
+  R3D_REQUIRE(n_transforms == 0 || d_xyz_in != d_xyz_out, "the copies cannot be written over the cloud they are made from");
+  const size_t block = (size_t)(n_points > 0 ? n_points : 0) * 3 * r3d_xyz_size(out_dtype);
+  for (int k = 0; k < n_transforms; ++k) {
+    const int rc = apply_common<false>(ctx, d_xyz_in, in_dtype, n_points, h_Ts + 16 * (size_t)k,
+                                       static_cast<char*>(d_xyz_out) + block * (size_t)k, out_dtype);
+    if (rc) return rc;
+  }
+  return R3D_OK;
+}
+
 int r3d_apply_T_dev(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* d_T,
                     void* d_xyz_out, int out_dtype) {
   R3D_REQUIRE(d_T != nullptr, "d_T is NULL");

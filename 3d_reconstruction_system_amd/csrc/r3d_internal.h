@@ -22,7 +22,11 @@ struct r3d_ctx {
   int fuse_loads = 0;    // 0 auto (vector loads + in-wave redistribution where the raster allows), 1 element loads (A/B)
   int fuse_prefetch = 0; // 0 auto, 1 off, 2 on: stage the inputs of a launch in the Infinity Cache with a read-only sweep first
   int fuse_chunk_mb = 0; // 0 auto: input bytes staged (and fused) per step when the prefetch is on
-  int fuse_stage_auto_mb = 64;  // fuse_prefetch auto: stage a launch's inputs when they exceed this many MB
+  // fuse_prefetch auto: stage a launch's small-share inputs when they exceed this many MB.  Round 2 had 64 ("less than that
+  // is usually still in the cache from its producer"); measured in round 3 (bench.py --workload regimes): a 49 MB raster that
+  // an H2D copy has just written is NOT in the Infinity Cache -- the launch runs at 0.49 of peak plain, 0.82 staged -- while
+  // staging a raster that IS cached costs 4 %.  Below ~8 MB the extra launch eats the gain.
+  int fuse_stage_auto_mb = 8;
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;

@@ -29,6 +29,7 @@ struct r3d_nn_index {
   r3d_ctx* ctx = nullptr;
   int device = 0;  // kept so that destroy never has to touch a ctx that may already be gone
   int64_t n = 0;
+  int64_t capacity = 0;  // target points the allocations can hold (r3d_nn_index_rebuild reuses them)
   int64_t n_tiles = 0;
   int idx_bits = 1, axis_bits = 16;
   float* d_tgt = nullptr;      // [n][3] original order (fallback scan)
@@ -39,6 +40,8 @@ struct r3d_nn_index {
   float* d_super_box = nullptr; // [ceil(n_tiles/16)][6] boxes of 16 consecutive tiles
   uint64_t* d_tile_code = nullptr;  // [n_tiles] Morton code (without index bits) of the tile's first target
   float* d_frame = nullptr;    // [8]: lo xyz, scale xyz, unused: quantisation frame shared by both clouds
+  void* d_slab = nullptr;      // ONE allocation holds every table above (eight hipMalloc / hipFree pairs per index were a
+                               // measurable share of a 10 ms estimate)
 };
 
 namespace {
@@ -515,15 +518,42 @@ int r3d_nn_index_destroy(r3d_nn_index* ix) {
   if (!ix) return R3D_OK;
   (void)hipSetDevice(ix->device);
   (void)hipDeviceSynchronize();
-  if (ix->d_tgt) (void)hipFree(ix->d_tgt);
-  if (ix->d_tgt4) (void)hipFree(ix->d_tgt4);
-  if (ix->d_tile_box) (void)hipFree(ix->d_tile_box);
-  if (ix->d_sub_box) (void)hipFree(ix->d_sub_box);
-  if (ix->d_group_box) (void)hipFree(ix->d_group_box);
-  if (ix->d_super_box) (void)hipFree(ix->d_super_box);
-  if (ix->d_tile_code) (void)hipFree(ix->d_tile_code);
-  if (ix->d_frame) (void)hipFree(ix->d_frame);
+  if (ix->d_slab) (void)hipFree(ix->d_slab);
   delete ix;
+  return R3D_OK;
+}
+
+// (re)builds every table of the index for a target cloud of n_tgt <= capacity points; asynchronous on the ctx stream
+static int nn_index_build(r3d_nn_index* ix, const float* d_tgt, int64_t n_tgt) {
+  r3d_ctx* ctx = ix->ctx;
+  ix->n = n_tgt;
+  ix->n_tiles = (n_tgt + kTile - 1) / kTile;
+  ix->idx_bits = bits_for(n_tgt);
+  ix->axis_bits = 10;  // 2^30 cells order any cloud finely enough for tile coherence and leave 34 bits for indices
+  const int64_t n_pad = ix->n_tiles * kTile;
+  int rc;
+  void *keys = nullptr, *tmp = nullptr;
+  if ((rc = r3d_scratch(ctx, 0, (size_t)n_tgt * 8, &keys)) || (rc = r3d_scratch(ctx, 2, (size_t)n_tgt * 8, &tmp))) return rc;
+  hipStream_t st = ctx->stream;
+  if (d_tgt != ix->d_tgt) R3D_HIP(hipMemcpyAsync(ix->d_tgt, d_tgt, (size_t)n_tgt * 12, hipMemcpyDeviceToDevice, st));
+  // 4 points per thread in flight; the rows of bounds go to a scratch slot
+  const int blocks = (int)std::min<int64_t>((n_tgt + 4 * kThreads - 1) / (4 * kThreads), (int64_t)ctx->num_cus * 2);
+  void* rows = nullptr;
+  if ((rc = r3d_scratch(ctx, 4, (size_t)blocks * 6 * sizeof(float), &rows))) return rc;
+  hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(kThreads), 0, st, ix->d_tgt, n_tgt, (float*)rows);
+  hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(64), 0, st, (const float*)rows, blocks, ix->axis_bits, ix->d_frame);
+  if ((rc = sorted_keys(ctx, ix->d_tgt, n_tgt, ix->d_frame, ix->axis_bits, ix->idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) return rc;
+  hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ix->d_tgt,
+                     (const uint64_t*)keys, n_tgt, n_pad, ix->idx_bits, ix->d_tgt4);
+  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ix->n_tiles), dim3(kThreads), 0, st, ix->d_tgt4, (const uint64_t*)keys,
+                     n_tgt, ix->idx_bits, kTile, ix->d_tile_box, ix->d_tile_code);
+  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)(ix->n_tiles * (kTile / kSub))), dim3(kThreads), 0, st, ix->d_tgt4,
+                     (const uint64_t*)keys, n_tgt, ix->idx_bits, kSub, ix->d_sub_box, (uint64_t*)nullptr);
+  hipLaunchKernelGGL(group_box_kernel, dim3((unsigned)ix->n_tiles), dim3(kThreads), 0, st, ix->d_tgt4, n_tgt, ix->d_group_box);
+  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)((ix->n_tiles + kSuper - 1) / kSuper)), dim3(kThreads), 0, st, ix->d_tgt4,
+                     (const uint64_t*)keys, n_tgt, ix->idx_bits, kSuper * kTile, ix->d_super_box, (uint64_t*)nullptr);
+  // asynchronous: the scratch key buffers are only ever reused by later work on this same stream
+  R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
 
@@ -542,65 +572,51 @@ int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_
   }
   ix->ctx = ctx;
   ix->device = ctx->device;
-  ix->n = n_tgt;
-  ix->n_tiles = (n_tgt + kTile - 1) / kTile;
-  ix->idx_bits = bits_for(n_tgt);
-  ix->axis_bits = 10;  // 2^30 cells order any cloud finely enough for tile coherence and leave 34 bits for indices
-  const int64_t n_pad = ix->n_tiles * kTile;
-  hipError_t e = hipMalloc((void**)&ix->d_tgt, (size_t)n_tgt * 12);
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tgt4, (size_t)n_pad * sizeof(float4));
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tile_box, (size_t)ix->n_tiles * 6 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sub_box, (size_t)ix->n_tiles * (kTile / kSub) * 6 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_group_box, (size_t)ix->n_tiles * (kTile / kGroup) * 6 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_super_box, (size_t)((ix->n_tiles + kSuper - 1) / kSuper) * 6 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_tile_code, (size_t)ix->n_tiles * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_frame, 16 * sizeof(float));
+  ix->capacity = n_tgt;
+  const int64_t n_tiles = (n_tgt + kTile - 1) / kTile, n_pad = n_tiles * kTile;
+  // one slab, every table at a 256-byte boundary
+  size_t off = 0;
+  auto take = [&off](size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return at;
+  };
+  const size_t o_tgt4 = take((size_t)n_pad * sizeof(float4)), o_tgt = take((size_t)n_tgt * 12),
+               o_tile = take((size_t)n_tiles * 6 * sizeof(float)), o_sub = take((size_t)n_tiles * (kTile / kSub) * 6 * sizeof(float)),
+               o_group = take((size_t)n_tiles * (kTile / kGroup) * 6 * sizeof(float)),
+               o_super = take((size_t)((n_tiles + kSuper - 1) / kSuper) * 6 * sizeof(float)),
+               o_code = take((size_t)n_tiles * sizeof(uint64_t)), o_frame = take(16 * sizeof(float));
+  hipError_t e = hipMalloc(&ix->d_slab, off);
   if (e != hipSuccess) {
     r3d_nn_index_destroy(ix);
     return r3d_fail_hip(e, "nn index allocation", __FILE__, __LINE__);
   }
-  void *keys = nullptr, *tmp = nullptr;
-  if ((rc = r3d_scratch(ctx, 0, (size_t)n_tgt * 8, &keys)) || (rc = r3d_scratch(ctx, 2, (size_t)n_tgt * 8, &tmp))) {
+  char* slab = static_cast<char*>(ix->d_slab);
+  ix->d_tgt4 = reinterpret_cast<float4*>(slab + o_tgt4);
+  ix->d_tgt = reinterpret_cast<float*>(slab + o_tgt);
+  ix->d_tile_box = reinterpret_cast<float*>(slab + o_tile);
+  ix->d_sub_box = reinterpret_cast<float*>(slab + o_sub);
+  ix->d_group_box = reinterpret_cast<float*>(slab + o_group);
+  ix->d_super_box = reinterpret_cast<float*>(slab + o_super);
+  ix->d_tile_code = reinterpret_cast<uint64_t*>(slab + o_code);
+  ix->d_frame = reinterpret_cast<float*>(slab + o_frame);
+  if ((rc = nn_index_build(ix, d_tgt, n_tgt))) {
     r3d_nn_index_destroy(ix);
     return rc;
-  }
-  hipStream_t st = ctx->stream;
-  e = hipMemcpyAsync(ix->d_tgt, d_tgt, (size_t)n_tgt * 12, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) {
-    r3d_nn_index_destroy(ix);
-    return r3d_fail_hip(e, "nn index setup", __FILE__, __LINE__);
-  }
-  // 4 points per thread in flight; the rows of bounds live in the (not yet sorted) key scratch
-  const int blocks = (int)std::min<int64_t>((n_tgt + 4 * kThreads - 1) / (4 * kThreads), (int64_t)ctx->num_cus * 2);
-  void* rows = nullptr;
-  if ((rc = r3d_scratch(ctx, 4, (size_t)blocks * 6 * sizeof(float), &rows))) {
-    r3d_nn_index_destroy(ix);
-    return rc;
-  }
-  hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(kThreads), 0, st, ix->d_tgt, n_tgt, (float*)rows);
-  hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(64), 0, st, (const float*)rows, blocks, ix->axis_bits, ix->d_frame);
-  rc = sorted_keys(ctx, ix->d_tgt, n_tgt, ix->d_frame, ix->axis_bits, ix->idx_bits, (uint64_t*)keys, (uint64_t*)tmp);
-  if (rc) {
-    r3d_nn_index_destroy(ix);
-    return rc;
-  }
-  hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ix->d_tgt,
-                     (const uint64_t*)keys, n_tgt, n_pad, ix->idx_bits, ix->d_tgt4);
-  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ix->n_tiles), dim3(kThreads), 0, st, ix->d_tgt4, (const uint64_t*)keys,
-                     n_tgt, ix->idx_bits, kTile, ix->d_tile_box, ix->d_tile_code);
-  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)(ix->n_tiles * (kTile / kSub))), dim3(kThreads), 0, st, ix->d_tgt4,
-                     (const uint64_t*)keys, n_tgt, ix->idx_bits, kSub, ix->d_sub_box, (uint64_t*)nullptr);
-  hipLaunchKernelGGL(group_box_kernel, dim3((unsigned)ix->n_tiles), dim3(kThreads), 0, st, ix->d_tgt4, n_tgt, ix->d_group_box);
-  hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)((ix->n_tiles + kSuper - 1) / kSuper)), dim3(kThreads), 0, st, ix->d_tgt4,
-                     (const uint64_t*)keys, n_tgt, ix->idx_bits, kSuper * kTile, ix->d_super_box, (uint64_t*)nullptr);
-  // asynchronous: the scratch key buffers are only ever reused by later work on this same stream
-  e = hipGetLastError();
-  if (e != hipSuccess) {
-    r3d_nn_index_destroy(ix);
-    return r3d_fail_hip(e, "nn index build", __FILE__, __LINE__);
   }
   *ix_out = ix;
   return R3D_OK;
+}
+
+int r3d_nn_index_rebuild(r3d_nn_index* ix, const float* d_tgt, int64_t n_tgt) {
+  R3D_REQUIRE(ix != nullptr, "nn index is NULL");
+  int rc = r3d_ctx_enter(ix->ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_tgt >= 1, "target cloud is empty");
+  R3D_REQUIRE(n_tgt <= ix->capacity, "index was created for %lld points, cannot hold %lld", (long long)ix->capacity,
+              (long long)n_tgt);
+  R3D_REQUIRE(d_tgt != nullptr, "NULL device pointer");
+  return nn_index_build(ix, d_tgt, n_tgt);
 }
 
 static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
@@ -737,6 +753,50 @@ int r3d_nn_index_sort_cloud(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t*
   R3D_HIP(hipMemcpyAsync(copy, d_xyz, (size_t)n * 12, hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(gather3_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
                      (const float*)copy, (const uint64_t*)keys, n, idx_bits, d_xyz, d_perm_out);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+// rows first, first + step, ... of an xyz cloud
+__global__ __launch_bounds__(kThreads) void rows_strided_kernel(const float* __restrict__ xyz, int64_t first, int64_t step,
+                                                                int64_t n_out, float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n_out) return;
+  reinterpret_cast<P3*>(out)[j] = reinterpret_cast<const P3*>(xyz)[first + j * step];
+}
+
+// rows perm[0], perm[1], ... of an xyz cloud
+__global__ __launch_bounds__(kThreads) void rows_by_index_kernel(const float* __restrict__ xyz, int64_t n_points,
+                                                                 const uint32_t* __restrict__ perm, int64_t n_out,
+                                                                 float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n_out) return;
+  const int64_t i = perm[j];
+  reinterpret_cast<P3*>(out)[j] = i < n_points ? reinterpret_cast<const P3*>(xyz)[i] : P3{NAN, NAN, NAN};
+}
+
+int r3d_gather_rows(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, const uint32_t* d_rows, int64_t n_out, float* d_xyz_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_points >= 0 && n_out >= 0, "negative size");
+  if (n_out == 0) return R3D_OK;
+  R3D_REQUIRE(d_xyz && d_rows && d_xyz_out && d_xyz != d_xyz_out, "NULL or aliased device pointer");
+  hipLaunchKernelGGL(rows_by_index_kernel, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz,
+                     n_points, d_rows, n_out, d_xyz_out);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+int r3d_gather_rows_strided(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, int64_t first, int64_t step, int64_t n_out,
+                            float* d_xyz_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_points >= 0 && first >= 0 && step >= 1 && n_out >= 0, "bad row selection");
+  if (n_out == 0) return R3D_OK;
+  R3D_REQUIRE(first + (n_out - 1) * step < n_points, "row selection runs past the cloud (%lld rows)", (long long)n_points);
+  R3D_REQUIRE(d_xyz && d_xyz_out && d_xyz != d_xyz_out, "NULL or aliased device pointer");
+  hipLaunchKernelGGL(rows_strided_kernel, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz,
+                     first, step, n_out, d_xyz_out);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

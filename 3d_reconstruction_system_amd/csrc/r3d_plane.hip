@@ -97,7 +97,7 @@ __device__ __forceinline__ unsigned order_key(float f) {
 // BUCKETED = false: one class, per-workgroup LDS histogram flushed once; true: straight to the class's global histogram
 template <bool BUCKETED>
 __global__ __launch_bounds__(kThreads) void select_hist_kernel(const float* __restrict__ v, const unsigned char* __restrict__ bucket,
-                                                               int64_t n, int n_buckets, int shift, int bits,
+                                                               int64_t per_class, int64_t n, int n_buckets, int shift, int bits,
                                                                unsigned* __restrict__ hist,
                                                                const unsigned long long* __restrict__ state) {
   __shared__ unsigned local[BUCKETED ? 1 : kBins];
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kThreads) void select_hist_kernel(const float* __re
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
     const float f = v[i];
     if ((__float_as_uint(f) & 0x7f800000u) == 0x7f800000u) continue;   // inf / NaN never count
-    const int c = BUCKETED ? (int)bucket[i] : 0;
+    // class of element i: its byte in `bucket`, or (bucket == NULL) the contiguous block of per_class elements it lies in
+    const int c = BUCKETED ? (bucket ? (int)bucket[i] : (int)(i / per_class)) : 0;
     if (c >= n_buckets) continue;
     const unsigned key = order_key(f);
     if ((key & s_mask[c]) != s_prefix[c]) continue;
@@ -352,25 +353,62 @@ int workspace(r3d_ctx* ctx, int n_buckets, int n_rows, Workspace* ws) {
   return R3D_OK;
 }
 
+// d_bucket != NULL: class per element; else per_class > 0: classes are contiguous blocks of that many elements; else one class
 int select_enqueue(r3d_ctx* ctx, const float* d_values, const unsigned char* d_bucket, int n_buckets, int64_t n, double q,
-                   const Workspace& ws) {
+                   const Workspace& ws, int64_t per_class = 0) {
   hipStream_t st = ctx->stream;
   R3D_HIP(hipMemsetAsync(ws.hist, 0, ws.clear_bytes, st));
   int blocks = (int)std::min<int64_t>((n + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->num_cus);
   if (blocks < 1) blocks = 1;
   const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
   for (int pass = 0; pass < 3; ++pass) {
-    if (d_bucket)
-      hipLaunchKernelGGL(select_hist_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, n, n_buckets,
+    const bool classes = d_bucket != nullptr || per_class > 0;
+    if (classes)
+      hipLaunchKernelGGL(select_hist_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, per_class, n, n_buckets,
                          shifts[pass], bits[pass], ws.hist, (const unsigned long long*)ws.state);
     else
-      hipLaunchKernelGGL(select_hist_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, n, 1, shifts[pass],
-                         bits[pass], ws.hist, (const unsigned long long*)ws.state);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(d_bucket ? n_buckets : 1), dim3(kThreads), 0, st, ws.hist, ws.state, pass,
+      hipLaunchKernelGGL(select_hist_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, (int64_t)0, n, 1,
+                         shifts[pass], bits[pass], ws.hist, (const unsigned long long*)ws.state);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(classes ? n_buckets : 1), dim3(kThreads), 0, st, ws.hist, ws.state, pass,
                        shifts[pass], bits[pass], q, pass == 2 ? 1 : 0, ws.out);
   }
   R3D_HIP(hipGetLastError());
   return R3D_OK;
+}
+
+// one workgroup per class (a contiguous block of per_class values): sum and count of the finite values <= the class's
+// selected order statistic, fp64, fixed order
+__global__ __launch_bounds__(kThreads) void class_sum_below_kernel(const float* __restrict__ v, int64_t per_class, int64_t n,
+                                                                   const SelectOut* __restrict__ gates, double* __restrict__ out2) {
+  __shared__ double red[2][kThreads / 64];
+  const int c = blockIdx.x;
+  const float g = gates[c].value;
+  const int64_t lo = (int64_t)c * per_class, hi = lo + per_class < n ? lo + per_class : n;
+  double sum = 0.0, cnt = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    const float f = v[i];
+    if ((__float_as_uint(f) & 0x7f800000u) == 0x7f800000u) continue;
+    if (f <= g) {
+      sum += (double)f;
+      cnt += 1.0;
+    }
+  }
+  sum = r3d_plane::wave_sum(sum);
+  cnt = r3d_plane::wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sum;
+    red[1][threadIdx.x >> 6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0, k = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) {
+      s += red[0][w];
+      k += red[1][w];
+    }
+    out2[2 * c] = s;
+    out2[2 * c + 1] = k;
+  }
 }
 
 int accumulate_blocks(r3d_ctx* ctx, int64_t n_src) {
@@ -413,6 +451,40 @@ int r3d_select_quantile_f32(r3d_ctx* ctx, const float* d_values, int64_t n, doub
   R3D_HIP(hipStreamSynchronize(ctx->stream));
   if (h_value_out) *h_value_out = o.value;
   if (h_count_out) *h_count_out = (int64_t)o.count;
+  return R3D_OK;
+}
+
+int r3d_select_quantile_f32_dev(r3d_ctx* ctx, const float* d_values, int64_t n, double q, void* d_out8) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n >= 0, "negative count");
+  R3D_REQUIRE(q >= 0.0 && q <= 1.0, "q must be in [0, 1]");
+  R3D_REQUIRE((n == 0 || d_values != nullptr) && d_out8 != nullptr, "NULL device pointer");
+  Workspace ws;
+  if ((rc = workspace(ctx, 1, 0, &ws))) return rc;
+  if ((rc = select_enqueue(ctx, d_values, nullptr, 1, n, q, ws))) return rc;
+  R3D_HIP(hipMemcpyAsync(d_out8, ws.out, sizeof(SelectOut), hipMemcpyDeviceToDevice, ctx->stream));
+  return R3D_OK;
+}
+
+int r3d_trimmed_means_f32(r3d_ctx* ctx, const float* d_values, int n_classes, int64_t per_class, double keep, double* h_means_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n_classes >= 1 && n_classes <= kMaxBuckets, "1..%d classes", kMaxBuckets);
+  R3D_REQUIRE(per_class >= 1, "per_class must be >= 1");
+  R3D_REQUIRE(keep >= 0.0 && keep <= 1.0, "keep must be in [0, 1]");
+  R3D_REQUIRE(d_values && h_means_out, "NULL argument");
+  const int64_t n = (int64_t)n_classes * per_class;
+  Workspace ws;
+  if ((rc = workspace(ctx, n_classes, 2 * n_classes / kSums + 2, &ws))) return rc;
+  if ((rc = select_enqueue(ctx, d_values, nullptr, n_classes, n, keep, ws, per_class))) return rc;
+  hipLaunchKernelGGL(class_sum_below_kernel, dim3(n_classes), dim3(kThreads), 0, ctx->stream, d_values, per_class, n,
+                     (const SelectOut*)ws.out, ws.rows);
+  R3D_HIP(hipGetLastError());
+  double pairs[2 * kMaxBuckets];
+  R3D_HIP(hipMemcpyAsync(pairs, ws.rows, (size_t)n_classes * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  for (int c = 0; c < n_classes; ++c) h_means_out[c] = pairs[2 * c + 1] > 0.0 ? pairs[2 * c] / pairs[2 * c + 1] : INFINITY;
   return R3D_OK;
 }
 

@@ -90,26 +90,25 @@ def init_candidates(mom_src, mom_tgt, with_scale=True):
     wq, Vq = np.linalg.eigh(cov_q)
     if not (np.all(np.isfinite(wp)) and np.all(np.isfinite(wq))) or wp[2] <= 0 or wq[2] <= 0:
         return out
-    for perm in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)):
-        Pm = np.zeros((3, 3))
-        for a in range(3):
-            Pm[a, perm[a]] = 1.0                 # target axis a <- source axis perm[a]
+    # proper rotations only: the third sign follows from the other two, the permutation's parity and the handedness of the
+    # two eigenvector frames (no determinant per candidate: this runs inside the timed estimate)
+    hand = (1.0 if np.linalg.det(Vq) > 0 else -1.0) * (1.0 if np.linalg.det(Vp) > 0 else -1.0)
+    for perm, parity in (((0, 1, 2), 1.0), ((0, 2, 1), -1.0), ((1, 0, 2), -1.0), ((1, 2, 0), 1.0), ((2, 0, 1), 1.0), ((2, 1, 0), -1.0)):
+        PVt = Vp.T[list(perm), :]                # P V_p^T: row a = source axis perm[a]
         for sx in (1.0, -1.0):
             for sy in (1.0, -1.0):
-                S = np.diag([sx, sy, 1.0])
-                Rm = Vq @ S @ Pm @ Vp.T
-                if np.linalg.det(Rm) < 0:
-                    Rm = Vq @ np.diag([sx, sy, -1.0]) @ Pm @ Vp.T
+                sz = 1.0 if hand * parity * sx * sy > 0 else -1.0
+                Rm = (Vq * np.array([sx, sy, sz])) @ PVt
                 out.append(("pca" if perm == (0, 1, 2) else "pca-permuted", make(Rm)))
     return out
 
 
-def trimmed_mean(d2, keep=0.8):
-    """Mean of the lowest `keep` share of the finite values (fp64); +inf when there are none."""
-    d2 = np.asarray(d2, dtype=np.float64)
-    d2 = np.sort(d2[np.isfinite(d2)])
-    k = int(np.ceil(keep * d2.size))
-    return float(d2[:k].mean()) if k > 0 else float("inf")
+def trimmed_means_device(d_values_ptr, n_classes, per_class, keep, ctx):
+    """Per consecutive block of per_class device floats: the mean of the finite values <= the block's `keep` order statistic
+    ("lower" rule), selected and summed on the GPU (r3d_trimmed_means_f32); +inf for a block with no finite value."""
+    out = np.empty(n_classes, dtype=np.float64)
+    L.check(ctx.lib.r3d_trimmed_means_f32(ctx.handle, d_values_ptr, int(n_classes), int(per_class), float(keep), out.ctypes.data))
+    return out
 
 
 INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 8192, 0.8, 1.05
@@ -131,6 +130,10 @@ class NNIndex:
                                                 1 if presorted else 0, C.byref(swept) if want_stats else None))
         return swept.value
 
+    def rebuild(self, d_tgt_ptr, n_tgt):
+        """Index another cloud of at most the size this one was created with, reusing the allocations."""
+        L.check(self.ctx.lib.r3d_nn_index_rebuild(self.handle, d_tgt_ptr, int(n_tgt)))
+
     def sort_cloud(self, d_xyz_ptr, n, d_perm_ptr=None):
         L.check(self.ctx.lib.r3d_nn_index_sort_cloud(self.handle, d_xyz_ptr, int(n), d_perm_ptr))
 
@@ -149,6 +152,52 @@ class NNIndex:
 STATE_DOUBLES, STATE_HISTORY = 512, 48       # R3D_ICP_STATE_DOUBLES / R3D_ICP_STATE_HISTORY (include/r3d.h)
 
 
+class _Slice:
+    """A piece of an arena block: the DeviceBuffer surface (ptr, nbytes, upload, download) without an allocation of its own."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, int(nbytes)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        L.check(self.ctx.lib.r3d_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes))
+        self.ctx.sync()  # `host` may be a temporary
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(self.ctx.lib.r3d_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        self.ctx.sync()
+        return out
+
+    def free(self):
+        pass
+
+
+class _Arena:
+    """Bump allocator over a few big HBM blocks: an estimate makes ~30 buffers, and every hipMalloc / hipFree pair (the free
+    synchronises the device) is tens of microseconds -- a measurable share of a 10 ms job.  Everything goes at once."""
+
+    def __init__(self, ctx, first_block):
+        self.ctx, self.blocks, self.at, self.block_bytes = ctx, [], 0, max(int(first_block), 1 << 20)
+
+    def take(self, nbytes):
+        nbytes = (max(int(nbytes), 16) + 255) & ~255
+        if not self.blocks or self.at + nbytes > self.blocks[-1].nbytes:
+            self.blocks.append(self.ctx.alloc(max(nbytes, self.block_bytes)))
+            self.at = 0
+        s = _Slice(self.ctx, self.blocks[-1].ptr + self.at, nbytes)
+        self.at += nbytes
+        return s
+
+    def free(self):
+        for b in self.blocks:
+            b.free()
+        self.blocks = []
+
+
 class IcpDevice:
     """Source / target clouds resident on one GPU.  culled=True (default) answers NN queries through the
     Morton-tile index (same results, far fewer pair evaluations); culled=False runs the plain brute-force sweep."""
@@ -165,20 +214,48 @@ class IcpDevice:
         self._tgt_host = tgt             # the target never moves: target_spacing() samples it without a D2H
         self._src_host = src             # the source as handed over (original order and frame): init_costs() samples it
         c = self.ctx
-        self.d_src = c.alloc(max(src.nbytes, 16)).upload(src)
-        self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
-        self.d_idx = c.alloc(max(self.n * 4, 16))
-        self.d_d2 = c.alloc(max(self.n * 4, 16))
-        self.d_sums = c.alloc(18 * 8)
-        self.d_state = c.alloc(STATE_DOUBLES * 8)
+        # one block for the clouds, the match arrays and (culled estimates) the work buffers of every stage
+        self._arena = _Arena(c, 24 * self.n + (66 if culled else 14) * self.m + (12 << 20 if culled else 1 << 16))
+        take = self._arena.take
+        self.d_src = take(max(src.nbytes, 16)).upload(src)
+        self.d_tgt = take(tgt.nbytes).upload(tgt)
+        self.d_idx = take(max(self.n * 4, 16))
+        self.d_d2 = take(max(self.n * 4, 16))
+        self.d_sums = take(18 * 8)
+        self.d_state = take(STATE_DOUBLES * 8)
         self.index = NNIndex(c, self.d_tgt.ptr, self.m) if culled else None
         self.d_perm = None
         self._back = None            # lazily built: reverse-direction search (target -> source snapshot)
+        self._pool = {}              # named grow-only device buffers: no hipMalloc / hipFree (each a sync) inside an estimate
+        self._src_index = None       # index of the source AS UPLOADED (sorted order), shared by init_costs and the back search
+        self._spacing = None
+        self._spacing_pending, self._probe_index = False, None
+        self.trace = None            # a list: _tick(name) then syncs and appends (name, seconds) -- icp_similarity(profile=True)
         if self.index is not None and self.n:
             # put the source cloud into the index's Morton order ONCE: rigid / similarity moves keep every
             # workgroup's 256 sources a compact blob, so no later query needs to sort.  d_perm maps back.
-            self.d_perm = c.alloc(self.n * 4)
+            self.d_perm = take(self.n * 4)
             self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
+
+    def _tick(self, name):
+        if self.trace is not None:
+            import time
+            self.ctx.sync()
+            self.trace.append((name, time.perf_counter()))
+
+    def _buf(self, name, nbytes):
+        """Named work buffer from the arena (kept for the life of this object; asked again with a larger size it is re-taken)."""
+        b = self._pool.get(name)
+        if b is None or b.nbytes < nbytes:
+            b = self._arena.take(nbytes)
+            self._pool[name] = b
+        return b
+
+    def source_index(self):
+        """Index of the source cloud as it was uploaded (call before the first move, or not at all)."""
+        if self._src_index is None:
+            self._src_index = NNIndex(self.ctx, self.d_src.ptr, self.n)
+        return self._src_index
 
     def nn(self, want_stats=False):
         c = self.ctx
@@ -212,33 +289,59 @@ class IcpDevice:
 
     def moments(self, which):
         """The 18 sums of one cloud paired with itself: [0] n, [1:4] sum p, [7:16] sum p p^T, [16] sum |p|^2."""
+        return self.moments_both()[0 if which == "src" else 1] if which == "both" else self._moments_one(which)
+
+    def _moments_one(self, which):
         c = self.ctx
         buf, n = (self.d_src, self.n) if which == "src" else (self.d_tgt, self.m)
         L.check(c.lib.r3d_icp_accumulate_dev(c.handle, buf.ptr, n, buf.ptr, n, None, None, -1.0, 0.0, self.d_sums.ptr))
         return self._download_sums()
 
-    def target_spacing(self, max_queries=32768):
-        """Median nearest-neighbour distance between two interleaved halves of the target cloud: its sampling
-        resolution, independent of how the clouds are aligned."""
-        if self.m < 8:
-            return 0.0
+    def moments_both(self):
+        """(source moments, target moments) with ONE trip to the host."""
         c = self.ctx
-        tgt = self._tgt_host
-        base, probe = tgt[1::2], tgt[0::2]
-        probe = probe[::max(1, probe.shape[0] // max_queries)]
-        d_base = c.alloc(base.nbytes).upload(base)
-        d_probe = c.alloc(probe.nbytes).upload(probe)
-        d_i, d_d = c.alloc(probe.shape[0] * 4), c.alloc(probe.shape[0] * 4)
-        ix = NNIndex(c, d_base.ptr, base.shape[0])
-        try:
-            ix.query(d_probe.ptr, probe.shape[0], d_i.ptr, d_d.ptr)
-            d2 = d_d.download(np.float32, probe.shape[0])
-        finally:
-            ix.close()
-            for b in (d_base, d_probe, d_i, d_d):
-                b.free()
-        d2 = d2[np.isfinite(d2)]
-        return float(np.sqrt(np.median(d2))) if d2.size else 0.0
+        d = self._buf("mom", 36 * 8)
+        L.check(c.lib.r3d_icp_accumulate_dev(c.handle, self.d_src.ptr, self.n, self.d_src.ptr, self.n, None, None, -1.0, 0.0, d.ptr))
+        L.check(c.lib.r3d_icp_accumulate_dev(c.handle, self.d_tgt.ptr, self.m, self.d_tgt.ptr, self.m, None, None, -1.0, 0.0,
+                                             d.ptr + 18 * 8))
+        both = d.download(np.float64, 36)
+        return both[:18].copy(), both[18:].copy()
+
+    def target_spacing_begin(self, max_queries=32768):
+        """Enqueue the sampling-resolution probe of the target (see target_spacing) without waiting for it: strided row
+        gathers, a probe index, one query and the selection of the median all run on the GPU while the host goes on (the
+        estimator starts it first and reads it three stages later)."""
+        if self._spacing is not None or self._spacing_pending or self.m < 8:
+            return
+        c = self.ctx
+        n_base, n_half = self.m // 2, (self.m + 1) // 2           # tgt[1::2], tgt[0::2]
+        step = max(1, n_half // max_queries)
+        n_probe = -(-n_half // step)
+        d_base, d_probe = self._buf("sp_base", n_base * 12), self._buf("sp_probe", n_probe * 12)
+        d_i, d_d, d_o = self._buf("sp_idx", n_probe * 4), self._buf("sp_d2", n_probe * 4), self._buf("sp_out", 8)
+        L.check(c.lib.r3d_gather_rows_strided(c.handle, self.d_tgt.ptr, self.m, 1, 2, n_base, d_base.ptr))
+        L.check(c.lib.r3d_gather_rows_strided(c.handle, self.d_tgt.ptr, self.m, 0, 2 * step, n_probe, d_probe.ptr))
+        self._probe_index = NNIndex(c, d_base.ptr, n_base)
+        self._probe_index.query(d_probe.ptr, n_probe, d_i.ptr, d_d.ptr)
+        L.check(c.lib.r3d_select_quantile_f32_dev(c.handle, d_d.ptr, n_probe, 0.5, d_o.ptr))
+        self._spacing_pending = True
+
+    def target_spacing(self, max_queries=32768):
+        """"Lower" median nearest-neighbour distance between two interleaved halves of the target cloud: its sampling
+        resolution, independent of how the clouds are aligned.  All on the GPU (strided row gathers, a probe index, the order
+        statistic selected on the device; 8 bytes come back); cached: the target never moves."""
+        if self._spacing is not None:
+            return self._spacing
+        if self.m < 8:
+            self._spacing = 0.0
+            return 0.0
+        self.target_spacing_begin(max_queries)
+        out = self._pool["sp_out"].download(np.uint32, 2)
+        med, cnt = float(out[:1].view(np.float32)[0]), int(out[1])
+        self._probe_index.close()
+        self._probe_index, self._spacing_pending = None, False
+        self._spacing = float(np.sqrt(med)) if cnt else 0.0
+        return self._spacing
 
     def init_costs(self, transforms):
         """Symmetric, robust misfit of each candidate start (call BEFORE the source is moved): a strided sample of the
@@ -246,78 +349,80 @@ class IcpDevice:
         the source (distances brought to target units); each side the mean of the lowest INIT_KEEP share of d2.
         All candidates share ONE query per direction (their moved samples are laid end to end): two queries, not ten."""
         c = self.ctx
-        ss = self._src_host[::max(1, self.n // INIT_SAMPLES)]
-        st = self._tgt_host[::max(1, self.m // INIT_SAMPLES)]
-        k, ns, nt = len(transforms), ss.shape[0], st.shape[0]
+        ss_host = self._src_host[::max(1, self.n // INIT_SAMPLES)]
+        st_host = self._tgt_host[::max(1, self.m // INIT_SAMPLES)]
+        k, ns, nt = len(transforms), ss_host.shape[0], st_host.shape[0]
         cap = k * max(ns, nt)
-        d_ss, d_st = c.alloc(ss.nbytes).upload(ss), c.alloc(st.nbytes).upload(st)
-        d_mv, d_i, d_d = c.alloc(cap * 12), c.alloc(cap * 4), c.alloc(cap * 4)
-        ix_src = NNIndex(c, self.d_src.ptr, self.n)
-        try:
-            Ts = [np.ascontiguousarray(T, dtype=np.float64) for T in transforms]
-            for j, T in enumerate(Ts):
-                L.check(c.lib.r3d_apply_T(c.handle, d_ss.ptr, L.F32, ns, T.ctypes.data, d_mv.ptr + j * ns * 12, L.F32))
-            self.index.query(d_mv.ptr, k * ns, d_i.ptr, d_d.ptr)
-            fwd = d_d.download(np.float32, k * ns).reshape(k, ns)
-            invs = [np.ascontiguousarray(np.linalg.inv(T), dtype=np.float64) for T in Ts]
-            for j, Ti in enumerate(invs):
-                L.check(c.lib.r3d_apply_T(c.handle, d_st.ptr, L.F32, nt, Ti.ctypes.data, d_mv.ptr + j * nt * 12, L.F32))
-            ix_src.query(d_mv.ptr, k * nt, d_i.ptr, d_d.ptr)
-            back = d_d.download(np.float32, k * nt).reshape(k, nt)
-            costs = []
-            for j, T in enumerate(Ts):
-                s2 = float(np.cbrt(abs(np.linalg.det(T[:3, :3])))) ** 2
-                costs.append(trimmed_mean(fwd[j], INIT_KEEP) + trimmed_mean(back[j], INIT_KEEP) * s2)
-        finally:
-            ix_src.close()
-            for b in (d_ss, d_st, d_mv, d_i, d_d):
-                b.free()
-        return costs
+        d_ss, d_st = self._buf("ic_ss", ns * 12).upload(ss_host), self._buf("ic_st", nt * 12).upload(st_host)
+        d_mv, d_i, d_d = self._buf("ic_mv", cap * 12), self._buf("ic_i", cap * 4), self._buf("ic_d", cap * 4)
+        self._tick("ic.samples_up")
+        ix_src = self.source_index()
+        self._tick("ic.source_index")
+        Ts = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).reshape(4, 4) for T in transforms]))
+        L.check(c.lib.r3d_apply_T_many(c.handle, d_ss.ptr, L.F32, ns, Ts.ctypes.data, k, d_mv.ptr, L.F32))
+        self._tick("ic.fwd_moves")
+        self.index.query(d_mv.ptr, k * ns, d_i.ptr, d_d.ptr)
+        self._tick("ic.fwd_query")
+        fwd = trimmed_means_device(d_d.ptr, k, ns, INIT_KEEP, c)
+        self._tick("ic.fwd_means")
+        invs = np.ascontiguousarray(np.linalg.inv(Ts))
+        L.check(c.lib.r3d_apply_T_many(c.handle, d_st.ptr, L.F32, nt, invs.ctypes.data, k, d_mv.ptr, L.F32))
+        self._tick("ic.back_moves")
+        ix_src.query(d_mv.ptr, k * nt, d_i.ptr, d_d.ptr)
+        self._tick("ic.back_query")
+        back = trimmed_means_device(d_d.ptr, k, nt, INIT_KEEP, c)
+        self._tick("ic.back_means")
+        s2 = np.cbrt(np.abs(np.linalg.det(Ts[:, :3, :3]))) ** 2
+        return (fwd + back * s2).tolist()
 
     # ---- reverse direction (symmetric coarse phase): every TARGET point's nearest point of a source snapshot ----
-    def back_begin(self):
-        """Freeze the current source cloud as a second index; keep a copy of the target in that index's order."""
+    def back_begin(self, T_since=None):
+        """Reverse direction: every TARGET point's nearest point of the source.  The source is searched through the index of
+        its UPLOADED state (source_index(): built once, shared with init_costs); back_sums takes the target into that frame
+        by the inverse of everything the source has been moved by since (T_since).  Keeps a copy of the target whose ROW ORDER
+        is the index's Morton order of the target as it lies in that frame now (a workgroup's 256 queries stay a compact blob
+        under the small moves that follow -- sorting the world-frame target by a frame it does not lie in cost 4x in culling)."""
         c = self.ctx
-        self.back_end()
-        ix = NNIndex(c, self.d_src.ptr, self.n)
-        d_tgt_b = c.alloc(self.m * 12)
-        L.check(c.lib.r3d_memcpy_d2d(c.handle, d_tgt_b.ptr, self.d_tgt.ptr, self.m * 12))
-        ix.sort_cloud(d_tgt_b.ptr, self.m, None)
-        self._back = {"index": ix, "tgt": d_tgt_b, "moved": c.alloc(self.m * 12), "idx": c.alloc(self.m * 4),
-                      "d2": c.alloc(self.m * 4), "sums": c.alloc(18 * 8)}
+        ix = self.source_index()
+        d_tgt_b, d_moved = self._buf("bk_tgt", self.m * 12), self._buf("bk_moved", self.m * 12)
+        d_perm = self._buf("bk_perm", self.m * 4)
+        T_inv = np.ascontiguousarray(np.linalg.inv(np.eye(4) if T_since is None else T_since), dtype=np.float64)
+        L.check(c.lib.r3d_apply_T(c.handle, self.d_tgt.ptr, L.F32, self.m, T_inv.ctypes.data, d_moved.ptr, L.F32))
+        ix.sort_cloud(d_moved.ptr, self.m, d_perm.ptr)
+        L.check(c.lib.r3d_gather_rows(c.handle, self.d_tgt.ptr, self.m, d_perm.ptr, self.m, d_tgt_b.ptr))
+        self._back = {"index": ix, "tgt": d_tgt_b, "moved": d_moved, "idx": self._buf("bk_idx", self.m * 4),
+                      "d2": self._buf("bk_d2", self.m * 4), "sums": self._buf("bk_sums", 18 * 8)}
 
     def d2_quantile(self, q):
-        """The q-quantile of the current source -> target squared match distances (after nn() / nn_sums())."""
-        d2 = self.d_d2.download(np.float32, self.n)
-        d2 = d2[np.isfinite(d2)]
-        return float(np.quantile(d2, q)) if d2.size else -1.0
+        """The q order statistic ("lower" rule) of the current source -> target squared match distances (after nn() /
+        nn_sums()), selected on the GPU; -1 when no distance is finite."""
+        v, cnt = select_quantile(self.d_d2.ptr, self.n, q, self.ctx)
+        return float(v) if cnt else -1.0
 
     def back_sums(self, T_since, dead_zone=0.0, trim=None):
         """18 sums over the pairs (p = CURRENT source point nearest to target point q, q): the target is taken
-        into the snapshot's frame by T_since^-1, searched there, and the sums are formed in the world frame.
-        trim: keep only the pairs up to that quantile of the match distances (outlier rejection)."""
+        into the source index's frame by T_since^-1 (T_since = everything the source was moved by since it was uploaded),
+        searched there, and the sums are formed in the world frame.
+        trim: keep only the pairs up to that order statistic of the match distances (outlier rejection)."""
         c, b = self.ctx, self._back
         T_inv = np.ascontiguousarray(np.linalg.inv(T_since), dtype=np.float64)
         s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
         L.check(c.lib.r3d_apply_T(c.handle, b["tgt"].ptr, L.F32, self.m, T_inv.ctypes.data, b["moved"].ptr, L.F32))
+        self._tick("back.move")
         b["index"].query(b["moved"].ptr, self.m, b["idx"].ptr, b["d2"].ptr, presorted=True)
+        self._tick("back.query")
         gate = -1.0
         if trim is not None and trim < 1.0:
-            d2 = b["d2"].download(np.float32, self.m)
-            d2 = d2[np.isfinite(d2)]
-            gate = float(np.quantile(d2, trim)) if d2.size else -1.0
-        # roles swapped: "src" = target rows (world frame), "tgt" = current source rows; d2 lives in the snapshot frame
+            v, cnt = select_quantile(b["d2"].ptr, self.m, trim, c)
+            gate = float(v) if cnt else -1.0
+        # roles swapped: "src" = target rows (world frame), "tgt" = current source rows; d2 lives in the index's frame
         L.check(c.lib.r3d_icp_accumulate_dev(c.handle, b["tgt"].ptr, self.m, self.d_src.ptr, self.n, b["idx"].ptr,
                                              b["d2"].ptr, gate, float(dead_zone) / s_since if dead_zone > 0 else 0.0,
                                              b["sums"].ptr))
         return swap_pair_sums(b["sums"].download(np.float64, 18))
 
     def back_end(self):
-        if self._back is not None:
-            self._back["index"].close()
-            for k in ("tgt", "moved", "idx", "d2", "sums"):
-                self._back[k].free()
-            self._back = None
+        self._back = None          # its buffers live in the pool, its index is source_index()
 
     # ---- whole iterations on the GPU, no host round trip ----
     def state_reset(self):
@@ -364,9 +469,15 @@ class IcpDevice:
         self.back_end()
         if self.index is not None:
             self.index.close()
-        for b in (self.d_src, self.d_tgt, self.d_idx, self.d_d2, self.d_perm, self.d_sums, self.d_state):
-            if b is not None:
-                b.free()
+        if self._src_index is not None:
+            self._src_index.close()
+            self._src_index = None
+        if self._probe_index is not None:
+            self._probe_index.close()
+            self._probe_index = None
+        self._pool = {}
+        self.ctx.sync()
+        self._arena.free()
 
 
 def nearest_neighbours(src, tgt, ctx=None, culled=False):
@@ -432,8 +543,11 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
         if profile:
             dev.ctx.sync()
             marks.append((name, time.perf_counter()))
+            dev.trace.append((name, marks[-1][1]))
 
     dev = IcpDevice(src, tgt, ctx, culled)
+    if profile:
+        dev.trace = [("start", marks[0][1])]
     info = {"init": init if isinstance(init, str) else "matrix", "coarse_iterations": 0, "coarse_history": []}
     T_total = np.eye(4)
     try:
@@ -443,12 +557,18 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
         mode = init if isinstance(init, str) else "matrix"
         if mode not in ("identity", "moments", "auto", "matrix"):
             raise ValueError("init must be 'identity', 'moments', 'auto' or a 4x4 matrix")
-        mom_t = dev.moments("tgt") if mode in ("moments", "auto") else None
+        mom_s = mom_t = None
+        if mode == "auto" and dev.index is not None:
+            dev.source_index()               # of the source as uploaded: must exist before the first move
+            if dead_zone is None:
+                dev.target_spacing_begin()   # runs on the GPU while the host prepares the multi-start
+        if mode in ("moments", "auto"):
+            mom_s, mom_t = dev.moments_both()
         if mode == "matrix":
             T_total = np.array(init, dtype=np.float64).reshape(4, 4)
             dev.move_source(T_total)
         elif mode in ("moments", "auto"):
-            mom_s = dev.moments("src")
+            dev._tick("init.moments")
             T_total = moments_init(mom_s, mom_t)
             if not with_scale:
                 T_total = np.eye(4)
@@ -457,6 +577,7 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                 # multi-start: the moments transform and the four principal-axis alignments, judged by a symmetric
                 # trimmed misfit on samples; the plain moments start keeps the job unless an axis alignment is clearly better
                 cands = init_candidates(mom_s, mom_t, with_scale)
+                dev._tick("init.candidates")
                 costs = dev.init_costs([T for _n, T in cands])
                 best = int(np.argmin(costs))
                 if costs[0] <= INIT_PREFER_MOMENTS * costs[best]:
@@ -473,8 +594,9 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
             info["dead_zone"] = d0
             mark("spacing_probe")
             if d0 > 0 and extent > 0:
-                dev.back_begin()
-                T_since = np.eye(4)
+                T_since = T_total.copy()      # the back search runs in the frame of the source as uploaded
+                dev.back_begin(T_since)
+                dev._tick("coarse.back_begin")
                 ct = coarse_trim if coarse_trim is not None else (None if trim is None else 1.0 - (1.0 - trim) / 4.0)
                 info["coarse_trim"] = ct
                 for _ in range(max_coarse):
@@ -482,7 +604,10 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                         dev.nn()
                         sums = dev.sums(dev.d2_quantile(ct), d0) + dev.back_sums(T_since, d0, ct)
                     else:
-                        sums = dev.nn_sums(-1.0, d0) + dev.back_sums(T_since, d0)
+                        sums = dev.nn_sums(-1.0, d0)
+                        dev._tick("coarse.fwd")
+                        sums = sums + dev.back_sums(T_since, d0)
+                        dev._tick("coarse.back")
                     info["coarse_history"].append(float(sums[0]))
                     if not sums[0] >= 3.0:
                         break                       # every match is inside the dead zone: extents agree
@@ -500,6 +625,7 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
             mark("coarse")
         # fine stage
         dev.state_reset()
+        dev._tick("fine.reset")
         max_d2 = -1.0 if trim_d2 is None else float(trim_d2)
         done, stop_at = 0, None
         while done < max_iter and stop_at is None:
@@ -510,8 +636,10 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                 if trim_d2 is not None:
                     max_d2 = min(max_d2, float(trim_d2))
             dev.iterate(k, with_scale, max_d2)
+            dev._tick("fine.iterate")
             done += k
             st = dev.state()
+            dev._tick("fine.state")
             h = st["rms_history"]
             for i in range(max(1, done - k), len(h)):
                 if abs(h[i - 1] - h[i]) <= tol * max(h[i - 1], 1e-30):
@@ -524,6 +652,7 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
         mark("fine")
         if profile:
             info["timings_ms"] = {b[0]: (b[1] - a[1]) * 1e3 for a, b in zip(marks, marks[1:])}
+            info["trace_ms"] = [(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(dev.trace, dev.trace[1:])]
         info.update({"iterations": st["iterations"], "rms_history": st["rms_history"], "degenerate": st["degenerate"],
                      "converged_at": stop_at})
     finally:

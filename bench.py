@@ -212,7 +212,7 @@ def regimes(a):
         tab4 = r3d.pose_table(rng.normal(size=(F4, 4)), rng.normal(size=(F4, 3)) * 10)
         d_pose4 = ctx.alloc(tab4.nbytes).upload(tab4)
         ms = median_ms(lambda: r3d.fuse_frames_device(ctx, cam, d_depth4.ptr, np.uint8, F4, d_pose4.ptr, d_xyz4.ptr, np.float32),
-                       groups=5, per=2, warm=3)
+                       groups=5, per=4, warm=12)
         out["c4_1000_frames_one_gpu"] = {"ms": round(ms, 4), "Mpoints_s": round(n4 / ms / 1e3, 1),
                                          "frac": round(n4 * BYTES_PER_POINT / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "points": n4, "what": "BASELINE config 4's 1000 frames fused by one call on one GPU "
@@ -385,6 +385,7 @@ def secondary(a):
             vs.clear()
             vs.insert_device(d_xyz.ptr, n)
         ms_v = timed(both, 5) - timed(vs.clear, 5)
+        both()
         st_all = vs.stats()
         # a checkable digest of the map's voxel half: the occupied set of the first k frames' cloud (the test suite forms the
         # same set with the oracle and compares count, ignored points and two order-independent digests of the codes)

@@ -74,8 +74,8 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
  * (workgroup counts), "nn_variant" (sources per lane of the NN sweeps: 1/2/4), "voxel_dedupe" (0 auto, 1 off, 2 on),
  * "fuse_prefetch" (0 auto, 1 off, 2 on: a read-only sweep stages a fused launch's inputs in the 256 MiB Infinity Cache first,
  * chunk by chunk -- "fuse_chunk_mb", 0 = 96 -- so that the kernel's reads do not mix with its write stream at the DRAM; auto:
- * on when one launch reads more than "fuse_stage_auto_mb" (default 64) MB of small-share inputs, i.e. more than the cache will
- * have kept from their producer), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
+ * on when one launch reads more than "fuse_stage_auto_mb" (default 8) MB of small-share inputs: frames that a host upload has just
+ * written are not in that cache -- measured: 0.49 of the HBM peak plain, 0.82 staged; staging cached inputs costs 4 %), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
  * No knob changes any result bit.  Unknown key -> R3D_ERR_INVALID.  (Kernel A/B variants live in tools/ab_kernels.hip,
  * not in the library.) */
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);
@@ -185,6 +185,10 @@ int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n
 /* The same with the matrix in HBM (16 doubles, row-major; e.g. the step a device-side ICP solve just wrote). */
 int r3d_apply_T_dev(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* d_T,
                     void* d_xyz_out, int out_dtype);
+/* n_transforms copies of one cloud, copy k moved by h_Ts[16 k .. 16 k + 15] (row-major 4x4) and written to block k of
+ * d_xyz_out (n_points rows each): the candidates of a multi-start in one call.  Asynchronous. */
+int r3d_apply_T_many(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_Ts, int n_transforms,
+                     void* d_xyz_out, int out_dtype);
 
 /* ---- a8: ICP estimation kernels (NOT in the reference -- transfer_T_icp.py only consumes a
  * T_data.txt made by an external tool; build-defined per SURVEY.md 8(a8)).
@@ -207,6 +211,17 @@ int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float
 typedef struct r3d_nn_index r3d_nn_index;
 int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_index** index_out);
 int r3d_nn_index_destroy(r3d_nn_index* index);
+/* Builds the index anew for another target cloud of n_tgt <= the size it was created with, reusing its allocations (an
+ * estimator that probes several clouds keeps one index object instead of paying eight hipMalloc / hipFree pairs per probe).
+ * Asynchronous. */
+int r3d_nn_index_rebuild(r3d_nn_index* index, const float* d_tgt, int64_t n_tgt);
+/* Rows d_rows[0], d_rows[1], ... (n_out uint32 row numbers; a number >= n_points yields a NaN row) of a device xyz cloud into
+ * d_xyz_out -- e.g. the permutation r3d_nn_index_sort_cloud reports, applied to a second cloud.  Asynchronous. */
+int r3d_gather_rows(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, const uint32_t* d_rows, int64_t n_out, float* d_xyz_out);
+/* Rows first, first + step, ... (n_out of them) of a device xyz cloud into d_xyz_out: strided samples without a trip to the
+ * host.  Asynchronous. */
+int r3d_gather_rows_strided(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, int64_t first, int64_t step, int64_t n_out,
+                            float* d_xyz_out);
 /* presorted = 0: the call sorts a copy of the sources into index order itself (any source order is fine).
  * presorted = 1: the caller keeps the sources spatially coherent -- r3d_nn_index_sort_cloud once, then rigid /
  * similarity moves of the whole cloud (ICP) preserve it -- and the sort is skipped.  Results are the same either way
@@ -275,6 +290,12 @@ int r3d_normals_organized(r3d_ctx* ctx, const float* d_xyz, int64_t n_frames, in
  * rank floor(q (m - 1)) of the m finite ones (numpy.quantile(..., method="lower")); +inf and count 0 when there are none.
  * Three histogram passes on the GPU, 8 bytes come back.  Synchronous. */
 int r3d_select_quantile_f32(r3d_ctx* ctx, const float* d_values, int64_t n, double q, float* h_value_out, int64_t* h_count_out);
+/* The same selection left in HBM: d_out8 receives {float value; uint32 count} (8 bytes).  Asynchronous. */
+int r3d_select_quantile_f32_dev(r3d_ctx* ctx, const float* d_values, int64_t n, double q, void* d_out8);
+/* Robust means of n_classes (<= 32) consecutive blocks of per_class device floats: per block the fp64 mean of the finite values
+ * that are <= the block's `keep` order statistic (the rule above); +inf for a block without finite values.  The estimator's
+ * multi-start judges all its candidate poses with one such call per direction.  Synchronous; n_classes doubles come back. */
+int r3d_trimmed_means_f32(r3d_ctx* ctx, const float* d_values, int n_classes, int64_t per_class, double keep, double* h_means_out);
 /* One matched pair = (p = src[k], q = tgt[idx[k]], n = tgt_normals[idx[k]]); it is ADMISSIBLE when idx[k] < n_tgt, n is not
  * the zero vector, p, q, n are finite, and (max_d2 < 0 or d2[k] <= max_d2).  Residual r = n.x (p.x - q.x) + n.y (p.y - q.y)
  * + n.z (p.z - q.z) in fp64, left to right.  r3d_icp_plane_residuals writes (float)(r r) per source row, +inf for pairs that

@@ -147,13 +147,21 @@ def apply_T32(xyz, T):
     return (x @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
 
 
+def quantile_lower(values, q):
+    """Element of rank floor(q (m - 1)) of the m finite values (r3d_select_quantile_f32's rule); -1 when there are none."""
+    v = np.asarray(values, dtype=np.float32)
+    v = np.sort(v[np.isfinite(v)])
+    return float(v[int(np.floor(q * (v.size - 1)))]) if v.size else -1.0
+
+
 def target_spacing(tgt, max_queries=32768):
     """Median NN distance between the interleaved halves of the target (its sampling resolution)."""
     tgt = np.asarray(tgt, dtype=np.float32)
     base, probe = tgt[1::2], tgt[0::2]
     probe = probe[::max(1, probe.shape[0] // max_queries)]
     _i, d2 = nearest_neighbours(probe, base)
-    return float(np.sqrt(np.median(d2)))
+    d2 = np.sort(d2[np.isfinite(d2)])          # the "lower" median: rank floor(0.5 (m - 1)), like the GPU's selection
+    return float(np.sqrt(d2[(d2.size - 1) // 2])) if d2.size else 0.0
 
 
 INIT_SAMPLES, INIT_KEEP, INIT_PREFER_MOMENTS = 8192, 0.8, 1.05
@@ -191,10 +199,14 @@ def init_candidates(P, Q, with_scale=True):
 
 
 def trimmed_mean(d2, keep=0.8):
-    d2 = np.asarray(d2, dtype=np.float64)
-    d2 = np.sort(d2[np.isfinite(d2)])
-    k = int(np.ceil(keep * d2.size))
-    return float(d2[:k].mean()) if k > 0 else float("inf")
+    """Mean (fp64) of the finite values that are <= their `keep` order statistic ("lower" rule: rank floor(keep (m - 1)));
+    +inf when there are none (r3d_trimmed_means_f32)."""
+    v = np.asarray(d2, dtype=np.float32)
+    v = v[np.isfinite(v)]
+    if v.size == 0:
+        return float("inf")
+    gate = np.sort(v)[int(np.floor(keep * (v.size - 1)))]
+    return float(v[v <= gate].astype(np.float64).mean())
 
 
 def init_costs(src, tgt, transforms):
@@ -233,19 +245,19 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
         T_total = cands[choice]
     cur = apply_T32(src, T_total)
     d0 = float(dead_zone) if dead_zone is not None else 2.0 * target_spacing(tgt)
-    snap = cur.copy()
-    T_since = np.eye(4)
+    snap = np.asarray(src, dtype=np.float32)      # the back search runs against the source AS GIVEN (icp.IcpDevice.source_index);
+    T_since = T_total.copy()                        # T_since = everything the source has been moved by since
     coarse = 0
     for _ in range(max_coarse):
         ia, da = nearest_neighbours(cur, tgt)
         ct = None if trim is None else 1.0 - (1.0 - trim) / 4.0      # the coarse stage trims more gently (icp.py: coarse_trim)
-        ga = float(np.quantile(da, ct)) if ct is not None and ct < 1.0 else -1.0
+        ga = quantile_lower(da, ct) if ct is not None and ct < 1.0 else -1.0
         sums = pair_sums(cur, tgt, ia, da, ga, d0)
         T_inv = np.linalg.inv(T_since)
         s_since = float(np.cbrt(abs(np.linalg.det(T_since[:3, :3]))))
         moved = apply_T32(tgt, T_inv)
         ib, db = nearest_neighbours(moved, snap)
-        gb = float(np.quantile(db, ct)) if ct is not None and ct < 1.0 else -1.0
+        gb = quantile_lower(db, ct) if ct is not None and ct < 1.0 else -1.0
         sums = sums + swap_pair_sums(pair_sums(tgt, cur, ib, db, gb, d0 / s_since))
         if not sums[0] >= 3.0:
             break
@@ -263,7 +275,7 @@ def icp_similarity_auto(src, tgt, max_iter=60, tol=1e-7, with_scale=True, dead_z
     for it in range(max_iter):
         idx, d2 = nearest_neighbours(cur, tgt)
         if trim is not None and trim < 1.0 and it % check_every == 0:     # re-ranked once per block, like the GPU loop
-            gate = float(np.quantile(d2, trim))
+            gate = quantile_lower(d2, trim)
         sums = pair_sums(cur, tgt, idx, d2, gate)
         rms = float(np.sqrt(max(sums[16] + sums[17] - 2 * (sums[7] + sums[11] + sums[15]), 0.0) / sums[0]))
         T = umeyama_from_sums(sums, with_scale)

@@ -500,7 +500,7 @@ def test_seeded_random_shape_sweep_every_kernel(R, ctx):
 @pytest.mark.parametrize("odtype", [np.float32, np.float64])
 def test_input_staging_in_chunks_never_changes_a_bit(R, ctx, ddtype, odtype):
     """Big batches have their inputs swept into the Infinity Cache chunk by chunk before each chunk is fused (fuse_prefetch /
-    fuse_chunk_mb; auto above 64 MB of inputs).  Forced on with 1 MB chunks here: several chunks, a ragged last one, frame
+    fuse_chunk_mb; auto above fuse_stage_auto_mb = 8 MB of inputs).  Forced on with 1 MB chunks here: several chunks, a ragged last one, frame
     offsets into every array (raster, pose table, xyz, colour, rgba) -- the results must equal the single launch bit for bit."""
     rng = np.random.default_rng(5)
     F, H, W = 37, 96, 130                                       # 12,480 pixels per frame: not a multiple of the 1024-pixel tile

@@ -32,4 +32,5 @@ T_true[:3, :3], T_true[:3, 3] = 1.7 * R, t
 print("coarse %d fine %d  |T-T_true| %.2e  stages %s" % (info["coarse_iterations"], info["iterations"],
                                                           np.abs(T - T_true).max(),
                                                           {k: round(v, 2) for k, v in info["timings_ms"].items()}))
+print("trace:", info.get("trace_ms"))
 ctx.close()
