@@ -161,24 +161,17 @@ using r3d_icp::kSums;
 using r3d_icp::pair_accumulate;
 using r3d_icp::pair_weight;
 
-// flag != nullptr: only sources whose flag byte is non-zero take part (the cross-group ties of the culled
-// NN kernel, whose winners the exact fallback wrote after the main kernel's fused sums were taken).
-// only_if != nullptr: the whole launch is a no-op when *only_if == 0 (partials are zeroed).
 __global__ __launch_bounds__(kThreads) void accumulate_kernel(const float* __restrict__ src, int64_t n_src,
                                                               const float* __restrict__ tgt, int64_t n_tgt,
                                                               const uint32_t* __restrict__ idx,
                                                               const float* __restrict__ d2, float max_d2, float dead_zone,
-                                                              const unsigned char* __restrict__ flag,
-                                                              const unsigned* __restrict__ only_if,
                                                               double* __restrict__ partials) {
   __shared__ double red[kThreads / 64][kSums];
   double acc[kSums];
 #pragma unroll
   for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
-  const bool active = only_if == nullptr || *only_if != 0u;
-  if (active) {
+  {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_src; i += (int64_t)gridDim.x * kThreads) {
-      if (flag != nullptr && flag[i] == 0) continue;
       if (max_d2 >= 0.f && !(d2[i] <= max_d2)) continue;
       const int64_t j = idx ? (int64_t)idx[i] : i;  // no index array: pair k with k (per-cloud moments)
       if (j >= n_tgt) continue;                      // a caller's index array is data: never read past the target cloud
@@ -230,16 +223,9 @@ __global__ void icp_solve_kernel(const double* __restrict__ sums, int with_scale
 }
 
 // ONE workgroup finishes a sums pass: (1) the per-workgroup partial rows, lane t taking rows t, t+256, ... in order;
-// (2) when the culled NN kernel handed sources to its exact fallback (flag != 0; *tie_count says whether any), their
-// pairs, lane t taking sources t, t+256, ...; (3) fixed shuffle / LDS tree -> the 18 sums; (4) optionally the similarity
-// solve and the ICP state update by lane 0.  Every order is fixed: bitwise repeatable.  One launch instead of
-// (flagged pass, final reduction, solve).
+// (2) fixed shuffle / LDS tree -> the 18 sums; (3) optionally the similarity solve and the ICP state update by lane 0.
+// Every order is fixed: bitwise repeatable.  One launch instead of (final reduction, solve).
 __global__ __launch_bounds__(kThreads) void sums_finish_kernel(const double* __restrict__ partials, int n_rows,
-                                                               const float* __restrict__ src, int64_t n_src,
-                                                               const float* __restrict__ tgt, const uint32_t* __restrict__ idx,
-                                                               const float* __restrict__ d2, float max_d2, float dead_zone,
-                                                               const unsigned char* __restrict__ flag,
-                                                               const unsigned* __restrict__ tie_count,
                                                                double* __restrict__ sums_out, int with_scale,
                                                                double* __restrict__ state) {
   __shared__ double red[kThreads / 64][kSums];
@@ -250,16 +236,6 @@ __global__ __launch_bounds__(kThreads) void sums_finish_kernel(const double* __r
   for (int b = threadIdx.x; b < n_rows; b += kThreads) {
 #pragma unroll
     for (int k = 0; k < kSums; ++k) acc[k] += partials[(int64_t)b * kSums + k];
-  }
-  if (flag != nullptr && *tie_count != 0u) {
-    for (int64_t i = threadIdx.x; i < n_src; i += kThreads) {
-      if (flag[i] == 0) continue;
-      if (max_d2 >= 0.f && !(d2[i] <= max_d2)) continue;
-      const int64_t j = idx[i];
-      const double p[3] = {(double)src[i * 3 + 0], (double)src[i * 3 + 1], (double)src[i * 3 + 2]};
-      const double q[3] = {(double)tgt[j * 3 + 0], (double)tgt[j * 3 + 1], (double)tgt[j * 3 + 2]};
-      pair_accumulate(acc, pair_weight(d2[i], dead_zone), p, q);
-    }
   }
   block_reduce_store(acc, red, total);
   __syncthreads();
@@ -275,13 +251,8 @@ __global__ __launch_bounds__(kThreads) void sums_finish_kernel(const double* __r
 
 // Second half of every sums pass (also of the fused NN + sums path of r3d_nnindex.hip): see sums_finish_kernel.
 // d_state != NULL additionally solves the similarity step on the GPU and updates the ICP state.
-int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
-                        const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,
-                        const unsigned* d_tie_count, const double* d_partials, int n_rows, double* d_sums_out,
-                        int with_scale, double* d_state) {
-  hipLaunchKernelGGL(sums_finish_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d_partials, n_rows, d_src, n_src, d_tgt,
-                     d_idx, d_d2, max_d2 >= 0.f ? max_d2 : -1.f, dead_zone, d_flag, d_tie_count, d_sums_out, with_scale,
-                     d_state);
+int r3d_icp_sums_finish(r3d_ctx* ctx, const double* d_partials, int n_rows, double* d_sums_out, int with_scale, double* d_state) {
+  hipLaunchKernelGGL(sums_finish_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d_partials, n_rows, d_sums_out, with_scale, d_state);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
@@ -386,11 +357,9 @@ static int accumulate_impl(r3d_ctx* ctx, const float* d_src, int64_t n_src, cons
   if ((rc = r3d_scratch(ctx, 4, ((size_t)blocks + 1) * kSums * sizeof(double), &d_part_v))) return rc;
   double* d_part = static_cast<double*>(d_part_v);
   hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, d_src, n_src, d_tgt, n_tgt, d_idx,
-                     (gated || dead_zone > 0.f) ? d_d2 : nullptr, gated ? max_d2 : -1.f, dead_zone,
-                     (const unsigned char*)nullptr, (const unsigned*)nullptr, d_part);
+                     (gated || dead_zone > 0.f) ? d_d2 : nullptr, gated ? max_d2 : -1.f, dead_zone, d_part);
   R3D_HIP(hipGetLastError());
-  return r3d_icp_sums_finish(ctx, d_src, n_src, d_tgt, d_idx, d_d2, -1.f, 0.f, nullptr, nullptr, d_part, blocks, d_sums_out,
-                             with_scale, d_state);
+  return r3d_icp_sums_finish(ctx, d_part, blocks, d_sums_out, with_scale, d_state);
 }
 
 int r3d_icp_accumulate_dev(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, int64_t n_tgt,

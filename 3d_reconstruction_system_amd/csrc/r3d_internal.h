@@ -100,11 +100,8 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
 
 // r3d_nnindex.hip: the index's own copy of the target cloud (original order), its size and its context
 int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx);
-// r3d_icp.hip: last kernel of a sums pass (partial rows + flagged fallback sources -> 18 sums [-> solve + ICP state])
-int r3d_icp_sums_finish(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_tgt, const uint32_t* d_idx,
-                        const float* d_d2, float max_d2, float dead_zone, const unsigned char* d_flag,
-                        const unsigned* d_tie_count, const double* d_partials, int n_rows, double* d_sums_out,
-                        int with_scale, double* d_state);
+// r3d_icp.hip: last kernel of a sums pass (partial rows -> 18 sums [-> solve + ICP state])
+int r3d_icp_sums_finish(r3d_ctx* ctx, const double* d_partials, int n_rows, double* d_sums_out, int with_scale, double* d_state);
 // r3d_nnindex.hip: presorted culled query + fused sums + device solve (one iteration's worth, used by r3d_icp_iterate)
 int r3d_nn_index_query_solve(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
                              float max_d2, double* d_sums_out, int with_scale, double* d_state);

@@ -18,8 +18,10 @@
 //       ride into LDS with the tile) cannot improve any lane: at 500k x 500k near alignment 15 tiles are swept per
 //       workgroup but only ~940 targets evaluated per source (brute force: 500,000), 0.32 ms per query.
 //   resolve: the winning group is re-evaluated exactly; equal distances pick the lowest original index.  A source
-//       that saw the SAME minimum in two different groups (an exact tie across groups) is handed to a small exact
-//       fallback kernel that scans all targets in original order.
+//       that sees the SAME minimum again in another group (an exact tie across groups) looks through that group on the
+//       spot and remembers the lowest original index among its equal targets, so the lowest index overall still wins
+//       (round 2 handed such sources to a fallback kernel in which ONE wave rescanned every target: a single tie cost
+//       more than a millisecond at 300k targets -- 70 % of a point-to-plane iteration on organised clouds).
 #include <cmath>
 
 #include "r3d_icp_sums.h"
@@ -248,11 +250,10 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
                                                            const float* __restrict__ group_box,
                                                            const float* __restrict__ super_box,
                                                            const uint64_t* __restrict__ tile_code,
+                                                           const float* __restrict__ tgt_orig,
                                                            uint32_t* __restrict__ idx_out, float* __restrict__ d2_out,
-                                                           uint32_t* __restrict__ tie_list, unsigned* __restrict__ tie_count,
                                                            unsigned long long* __restrict__ stats,
-                                                           double* __restrict__ partials, unsigned char* __restrict__ tie_flag,
-                                                           float max_d2, float dead_zone) {
+                                                           double* __restrict__ partials, float max_d2, float dead_zone) {
   __shared__ __attribute__((aligned(16))) float tx[kTile];
   __shared__ __attribute__((aligned(16))) float ty[kTile];
   __shared__ __attribute__((aligned(16))) float tz[kTile];
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
   const uint32_t tid = threadIdx.x;
   const int64_t s_base = (int64_t)blockIdx.x * (kThreads * S);
   float sx[S], sy[S], sz[S], best[S];
-  uint32_t best_group[S];
-  bool tie[S], ok[S];
+  uint32_t best_group[S], tie_idx[S];   // tie_idx: lowest original index among equal-distance targets of OTHER groups
+  bool ok[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int64_t i = s_base + (int64_t)s * kThreads + tid;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
     }
     best[s] = INFINITY;
     best_group[s] = 0;
-    tie[s] = false;
+    tie_idx[s] = 0xffffffffu;
   }
   if (tid == 0) {
     // tile whose Morton range holds this workgroup's first source: last tile with first code <= code
@@ -399,9 +400,16 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
           if (gmin[s] < best[s]) {
             best[s] = gmin[s];
             best_group[s] = group0 + g;
-            tie[s] = false;
-          } else if (gmin[s] == best[s] && best_group[s] != group0 + g) {
-            tie[s] = true;  // the same minimum in another group: original-index order must decide
+            tie_idx[s] = 0xffffffffu;
+          } else if (gmin[s] == best[s] && best_group[s] != group0 + g && gmin[s] < INFINITY) {
+            // the same minimum in another group (rare): original-index order must decide -- note the lowest original
+            // index among this group's equal targets now
+            const float4* gp = tgt4 + (int64_t)(group0 + g) * kGroup;
+            for (int k = 0; k < kGroup; ++k) {
+              const float4 p = gp[k];
+              const float dx = sx[s] - p.x, dy = sy[s] - p.y, dz = sz[s] - p.z;
+              if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) == best[s] && __float_as_uint(p.w) < tie_idx[s]) tie_idx[s] = __float_as_uint(p.w);
+            }
           }
         }
       }
@@ -412,8 +420,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
 
   // resolve inside the winning group: exact distance, lowest original index among equals.  With `partials` the
   // 18 fp64 pair sums of the Umeyama fit are taken right here (p = this source, q = its winner): the ICP loop
-  // needs no separate gather pass over (src, idx, tgt).  Sources handed to the exact fallback are flagged and
-  // summed by a small follow-up pass once their winners are known.
+  // needs no separate gather pass over (src, idx, tgt).
   double acc[r3d_icp::kSums];
   if (partials) {
 #pragma unroll
@@ -436,10 +443,15 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
         qx = p.x; qy = p.y; qz = p.z;
       }
     }
-    const bool to_fallback = found == 0xffffffffu || tie[s];
-    if (to_fallback) {
-      // no finite distance at all (NaN input) or a cross-group tie: the exact fallback scans everything
-      tie_list[atomicAdd(tie_count, 1u)] = orig;
+    if (tie_idx[s] < found) {   // an equal-distance target of another group has the lower original index
+      found = tie_idx[s];
+      const P3 q = reinterpret_cast<const P3*>(tgt_orig)[found];
+      qx = q.x; qy = q.y; qz = q.z;
+    }
+    if (!(best[s] < INFINITY) || found == 0xffffffffu) {
+      // no finite distance at all (the source, or every target, has a NaN / inf coordinate): index 0, d2 = +inf, no pair
+      idx_out[orig] = 0u;
+      if (d2_out) d2_out[orig] = INFINITY;
     } else {
       idx_out[orig] = found;
       if (d2_out) d2_out[orig] = best[s];
@@ -449,7 +461,6 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
         r3d_icp::pair_accumulate(acc, r3d_icp::pair_weight(best[s], dead_zone), p3, q3);
       }
     }
-    if (tie_flag) tie_flag[orig] = to_fallback ? 1 : 0;
   }
   if (partials) {
     __shared__ double red[kThreads / 64][r3d_icp::kSums];
@@ -457,42 +468,6 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
   }
   if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)swept);
   if ((tid & 63) == 0 && stats) atomicAdd(&stats[1], (unsigned long long)groups_done);  // 32-target groups evaluated, per wave
-}
-
-// one wave per listed source: all targets in ORIGINAL order, strict < per lane (ascending indices), then
-// (distance, index) lexicographic minimum across the wave == r3d_icp_nn's answer
-__global__ __launch_bounds__(64) void nn_tie_fallback_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                             int64_t n_tgt, const uint32_t* __restrict__ tie_list,
-                                                             const unsigned* __restrict__ tie_count,
-                                                             uint32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
-  const unsigned n_list = *tie_count;
-  for (unsigned e = blockIdx.x; e < n_list; e += gridDim.x) {
-    const uint32_t i = tie_list[e];
-    const float sx = src[(int64_t)i * 3], sy = src[(int64_t)i * 3 + 1], sz = src[(int64_t)i * 3 + 2];
-    float best = INFINITY;
-    uint32_t bi = 0xffffffffu;
-    for (int64_t t = threadIdx.x; t < n_tgt; t += 64) {
-      const float dx = sx - tgt[t * 3], dy = sy - tgt[t * 3 + 1], dz = sz - tgt[t * 3 + 2];
-      const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      if (d < best) {
-        best = d;
-        bi = (uint32_t)t;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ob = __shfl_down(best, off, 64);
-      const uint32_t oi = __shfl_down(bi, off, 64);
-      if (ob < best || (ob == best && oi < bi)) {
-        best = ob;
-        bi = oi;
-      }
-    }
-    if (threadIdx.x == 0) {
-      idx_out[i] = bi == 0xffffffffu ? 0u : bi;  // all-NaN row: r3d_icp_nn reports index 0 too
-      if (d2_out) d2_out[i] = best;
-    }
-  }
 }
 
 int bits_for(int64_t n) {
@@ -649,12 +624,9 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
     hipLaunchKernelGGL(gather4_kernel, dim3((unsigned)((n_src + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, d_src,
                        (const uint64_t*)keys, n_src, n_src, src_idx_bits, (float4*)src4);
   }
-  if ((rc = r3d_scratch(ctx, 5, (size_t)n_src * 5 + 64, &misc))) return rc;
-  unsigned long long* stats = static_cast<unsigned long long*>(misc);  // [0] tile sweeps
-  unsigned* tie_count = reinterpret_cast<unsigned*>(stats + 2);
-  uint32_t* tie_list = reinterpret_cast<uint32_t*>(stats + 4);
-  unsigned char* tie_flag = want_sums ? reinterpret_cast<unsigned char*>(tie_list + n_src) : nullptr;
-  R3D_HIP(hipMemsetAsync(misc, 0, 32, st));
+  if ((rc = r3d_scratch(ctx, 5, 64, &misc))) return rc;
+  unsigned long long* stats = static_cast<unsigned long long*>(misc);  // [0] tile sweeps, [1] groups evaluated
+  if (h_tiles_swept) R3D_HIP(hipMemsetAsync(misc, 0, 32, st));
   int S = ctx->nn_variant;
   if (S != 1 && S != 2 && S != 4) S = 1;
   const int64_t per_block = (int64_t)kThreads * S;
@@ -668,8 +640,8 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
 #define R3D_LAUNCH_CULL(SS, FMT, PTR)                                                                                  \
   hipLaunchKernelGGL((nn_cull_kernel<SS, FMT>), dim3(blocks), dim3(kThreads), 0, st, (const void*)(PTR), n_src,        \
                      (const float*)ix->d_frame, ix->axis_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box,         \
-                     ix->d_sub_box, ix->d_group_box, ix->d_super_box, ix->d_tile_code, d_idx_out, d_d2_out, tie_list, tie_count, stats,   \
-                     partials, tie_flag, max_d2, dead_zone)
+                     ix->d_sub_box, ix->d_group_box, ix->d_super_box, ix->d_tile_code, (const float*)ix->d_tgt, d_idx_out, d_d2_out,     \
+                     h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone)
   if (presorted) {
     if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
     else if (S == 2) R3D_LAUNCH_CULL(2, false, d_src);
@@ -680,12 +652,9 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
     else R3D_LAUNCH_CULL(4, true, src4);
   }
 #undef R3D_LAUNCH_CULL
-  hipLaunchKernelGGL(nn_tie_fallback_kernel, dim3(ctx->num_cus * 4), dim3(64), 0, st, d_src, ix->d_tgt, ix->n, tie_list,
-                     tie_count, d_idx_out, d_d2_out);
   R3D_HIP(hipGetLastError());
   if (want_sums &&
-      (rc = r3d_icp_sums_finish(ctx, d_src, n_src, ix->d_tgt, d_idx_out, d_d2_out, max_d2, dead_zone, tie_flag, tie_count,
-                                partials, (int)blocks, d_sums_out, with_scale, d_state)))
+      (rc = r3d_icp_sums_finish(ctx, partials, (int)blocks, d_sums_out, with_scale, d_state)))
     return rc;
   if (h_tiles_swept) {
     unsigned long long v[2] = {0, 0};

@@ -3,18 +3,20 @@
 # the headline kernel (HBM traffic), and stats of every kernel at BASELINE sizes.  Output: gpurun_out/prof_$1/...
 # Summaries are made afterwards with tools/summarise_profile.py and committed under profiles/.
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
-echo "== kernel trace of: $BENCH"
+# the PMC passes must not start another program from a profiled process (the regimes child): --no-regimes
+BENCH_PMC="$BENCH --no-regimes"
+echo "== kernel trace of: $BENCH   (the regimes child process is traced into its own <pid>_ files)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || echo "trace rc=$?"
 tail -c 600 $OUT/trace.log
 echo "== PMC FETCH_SIZE"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH_PMC > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch rc=$?"
 echo "== PMC WRITE_SIZE"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || echo "pmc write rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH_PMC > $OUT/pmc_write.log 2>&1 || echo "pmc write rc=$?"
 echo "== all kernels (tools/profile_all.py)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/all -- python3 tools/profile_all.py > $OUT/all.log 2>&1 || echo "all rc=$?"
 tail -c 300 $OUT/all.log
