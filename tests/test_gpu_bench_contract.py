@@ -47,7 +47,8 @@ def test_headline_line_is_complete_and_self_consistent():
     assert abs(d["value"] - 100 * 384 * 1280 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
     assert d["value_shards_resident"] == d["value"]
     assert 0.5 < rf["frac"] < 1.0
-    assert rf["traffic"] is None or 0.99 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.02
+    # PMC traffic per step: the staging sweep reads the 49 MB raster once more (+7.7 %), the fused kernel itself is at 1.001
+    assert rf["traffic"] is None or 0.99 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.09
     # the line MEASURES (in this run) what the same launch does when its raster is not in the Infinity Cache: 16 rotating
     # rasters plain / staged / library default, the launch right after an H2D upload, and config 4's 1000 frames at once
     cold = rf["cold_inputs"]
