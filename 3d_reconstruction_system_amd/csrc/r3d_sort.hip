@@ -5,8 +5,8 @@
 // scatter = 24 B/key/pass; 6 passes cover 48 bits.
 //
 //   digit_histogram_kernel  tile of 4096 keys per workgroup -> 256-bin LDS histogram -> hist[bin][workgroup]
-//   digit_scan_kernel       one wave per bin: exclusive prefix over workgroups (wave shuffle scan), bin totals;
-//                           a final single-wave pass turns totals into bin bases
+//   digit_scan_kernel       one workgroup per bin: exclusive prefix over workgroups (contiguous chunk per thread, wave
+//                           shuffle scan, LDS across waves), bin totals; a final single-wave pass turns totals into bin bases
 //   digit_scatter_kernel    re-reads the tile in 16 rounds of 256 keys; inside a round every lane finds the lanes of
 //                           its wave with the same digit by 8 ballots, the rank among them by popcount, waves are
 //                           ordered through a [4][256] LDS count table; destination = bin base + workgroup prefix +
@@ -44,19 +44,29 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
   return v;
 }
 
-// grid = kBins workgroups of one wave: bin b's counts over the workgroups become exclusive prefixes in place
-__global__ __launch_bounds__(64) void digit_scan_kernel(uint32_t* __restrict__ hist, int n_blocks, uint32_t* __restrict__ totals) {
-  const int lane = threadIdx.x;
+// grid = kBins workgroups of 256 threads: bin b's counts over the workgroups become exclusive prefixes in place.  Every
+// thread owns a CONTIGUOUS chunk of the row (local sum -> wave shuffle scan -> LDS across the 4 waves -> local rescan):
+// two passes over the row instead of a chain of 64-wide scans (one wave per bin walked 11.8 k counters of a 48 M-key sort
+// in 185 dependent steps: 95 us per pass).
+__global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restrict__ hist, int n_blocks, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_sum[kThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* row = hist + (int64_t)blockIdx.x * n_blocks;
-  uint32_t running = 0;
-  for (int b0 = 0; b0 < n_blocks; b0 += 64) {
-    const int b = b0 + lane;
-    const uint32_t v = b < n_blocks ? row[b] : 0;
-    const uint32_t inc = wave_inclusive_scan(v, lane);
-    if (b < n_blocks) row[b] = running + inc - v;
-    running += __shfl(inc, 63, 64);
+  const int per = (n_blocks + kThreads - 1) / kThreads;
+  const int lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+  uint32_t mine = 0;
+  for (int b = lo; b < hi; ++b) mine += row[b];
+  const uint32_t inc = wave_inclusive_scan(mine, lane);
+  if (lane == 63) wave_sum[wave] = inc;
+  __syncthreads();
+  uint32_t before = inc - mine;
+  for (int w = 0; w < wave; ++w) before += wave_sum[w];
+  for (int b = lo; b < hi; ++b) {
+    const uint32_t v = row[b];
+    row[b] = before;
+    before += v;
   }
-  if (lane == 0) totals[blockIdx.x] = running;
+  if (threadIdx.x == kThreads - 1) totals[blockIdx.x] = before;   // the last chunk ends at the row's total (empty chunks pass it on)
 }
 
 // one wave: totals[256] -> exclusive bases[256]
@@ -138,7 +148,7 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
   for (int p = 0; p < passes; ++p) {
     const int shift = 8 * p;
     hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
-    hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(64), 0, ctx->stream, hist, n_blocks, totals);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, totals);
     hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, ctx->stream, totals, bases);
     hipLaunchKernelGGL(digit_scatter_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks,
                        bases, dst);

@@ -124,6 +124,59 @@ int main(void) {
     CK(r3d_dev_free(ctx, d_xyz));
     CK(r3d_dev_free(ctx, d_rgba));
   }
+  /* the registration the reference left to CloudCompare (readme.md:25): a 48x64 single view of a room corner (two walls and
+   * the floor) against a copy of itself moved by a known small rigid motion -- normals from the raster, index, ten
+   * point-to-plane iterations enqueued without a host round trip, then the pose is read back from the ICP state */
+  {
+    enum { RH = 48, RW = 64, RN = RH * RW };
+    static float tgt[RN * 3], src[RN * 3];
+    double st[R3D_ICP_STATE_DOUBLES];
+    const double a = 2.0 * 3.14159265358979323846 / 180.0, ca = cos(a), sa = sin(a);
+    const double Rm[9] = {ca, 0, sa, 0, 1, 0, -sa, 0, ca}, tv[3] = {0.03, -0.02, 0.04};
+    void *d_tgt = NULL, *d_src = NULL, *d_src0 = NULL, *d_nrm = NULL, *d_idx = NULL, *d_d2 = NULL, *d_state = NULL;
+    r3d_nn_index* ix = NULL;
+    double worst = 0.0;
+    for (j = 0; j < RH; ++j)
+      for (i = 0; i < RW; ++i) {
+        const double u = (i - 20.0) / 50.0, v = (j - 14.0) / 50.0;
+        double z = 3.0; /* wall z = 3; wall x = 2 where u > 0; floor y = 1.2 where v > 0 */
+        float* q = tgt + (size_t)(j * RW + i) * 3;
+        float* p = src + (size_t)(j * RW + i) * 3;
+        double d[3];
+        if (u > 0 && 2.0 / u < z) z = 2.0 / u;
+        if (v > 0 && 1.2 / v < z) z = 1.2 / v;
+        q[0] = (float)(u * z); q[1] = (float)(v * z); q[2] = (float)z;
+        d[0] = q[0] - tv[0]; d[1] = q[1] - tv[1]; d[2] = q[2] - tv[2];          /* src = R^T (tgt - t): T maps src onto tgt */
+        for (k = 0; k < 3; ++k) p[k] = (float)(Rm[0 + k] * d[0] + Rm[3 + k] * d[1] + Rm[6 + k] * d[2]);
+      }
+    CK(r3d_dev_alloc(ctx, sizeof(tgt), &d_tgt));
+    CK(r3d_dev_alloc(ctx, sizeof(src), &d_src));
+    CK(r3d_dev_alloc(ctx, sizeof(src), &d_src0));
+    CK(r3d_dev_alloc(ctx, sizeof(tgt), &d_nrm));
+    CK(r3d_dev_alloc(ctx, RN * 4, &d_idx));
+    CK(r3d_dev_alloc(ctx, RN * 4, &d_d2));
+    CK(r3d_dev_alloc(ctx, sizeof(st), &d_state));
+    CK(r3d_memcpy_h2d(ctx, d_tgt, tgt, sizeof(tgt)));
+    CK(r3d_memcpy_h2d(ctx, d_src, src, sizeof(src)));
+    CK(r3d_normals_organized(ctx, (const float*)d_tgt, 1, RH, RW, 0.05f, NULL, (float*)d_nrm));
+    CK(r3d_nn_index_create(ctx, (const float*)d_tgt, RN, &ix));
+    CK(r3d_nn_index_sort_cloud(ix, (float*)d_src, RN, NULL));
+    CK(r3d_memcpy_d2d(ctx, d_src0, d_src, sizeof(src)));
+    CK(r3d_icp_state_reset(ctx, (double*)d_state));
+    CK(r3d_icp_iterate_plane(ctx, ix, (const float*)d_src0, (float*)d_src, RN, (const float*)d_nrm, (uint32_t*)d_idx, (float*)d_d2, 10,
+                             0.5f, 20.0f, -1.0f, (double*)d_state));
+    CK(r3d_memcpy_d2h(ctx, st, d_state, sizeof(st)));
+    CK(r3d_ctx_sync(ctx));
+    for (j = 0; j < 3; ++j) {
+      for (i = 0; i < 3; ++i) if (fabs(st[4 * j + i] - Rm[3 * j + i]) > worst) worst = fabs(st[4 * j + i] - Rm[3 * j + i]);
+      if (fabs(st[4 * j + 3] - tv[j]) > worst) worst = fabs(st[4 * j + 3] - tv[j]);
+    }
+    printf("point-to-plane: %d iterations, status %g, |T - T_true| max %.2e\n", (int)st[32], st[33], worst);
+    if (st[32] != 10.0 || st[33] != 0.0 || worst > 1e-3) { fprintf(stderr, "two-view registration did not come back\n"); return 1; }
+    CK(r3d_nn_index_destroy(ix));
+    CK(r3d_dev_free(ctx, d_tgt)); CK(r3d_dev_free(ctx, d_src)); CK(r3d_dev_free(ctx, d_src0)); CK(r3d_dev_free(ctx, d_nrm));
+    CK(r3d_dev_free(ctx, d_idx)); CK(r3d_dev_free(ctx, d_d2)); CK(r3d_dev_free(ctx, d_state));
+  }
   /* error convention: bad arguments come back as codes with a message, nothing aborts */
   if (r3d_fuse_frames_host(ctx, cam, NULL, R3D_DEPTH_U8, F, 1.0, pose, xyz, R3D_F32) != R3D_ERR_INVALID) return 1;
   if (r3d_ctx_set_tuning(ctx, "no_such_knob", 1) != R3D_ERR_INVALID) return 1;

@@ -263,6 +263,33 @@ def test_two_partially_overlapping_views_are_registered(icp, S, ctx, yaw, baseli
     np.testing.assert_array_equal(T, T4)
 
 
+def test_uint8_depth_rasters_as_the_reference_reads_them(icp, S, ctx):
+    """The reference's depth maps are 8-bit PNGs (`cv.imread(..., IMREAD_GRAYSCALE)`, c2w:160): Z is an INTEGER 0..255, the
+    clouds are staircases of fronto-parallel layers.  Same two views with depth rounded to units of 2.5 cm (85..190 of the 255
+    levels in use), unprojected by the library exactly like pixel_to_camera.py does: the pose still comes back -- rotation to
+    1e-3, translation to a fraction of ONE depth level."""
+    R = _r3d()
+    h, w = 480, 640
+    v = S.two_views(h, w, yaw_deg=15.0, baseline=(0.35, 0.05, -0.2), seed=1)
+    unit = 40.0
+    da = np.clip(np.round(v["depth_a"] * unit), 0, 255).astype(np.uint8)
+    db = np.clip(np.round(v["depth_b"] * unit), 0, 255).astype(np.uint8)
+    pa, pb = R.unproject(da, v["K"], ctx=ctx), R.unproject(db, v["K"], ctx=ctx)
+    T_true = v["T_ab"].copy()
+    T_true[:3, 3] *= unit
+    T0 = rough(v["T_ab"])
+    T0[:3, 3] *= unit
+    T, info = icp.icp_point_to_plane(pb, pa, tgt_shape=(h, w), init=T0, ctx=ctx)
+    assert np.abs(T[:3, :3] - T_true[:3, :3]).max() <= 1e-3 and np.abs(T[:3, 3] - T_true[:3, 3]).max() <= 0.25, np.abs(T - T_true).max()
+    # a quarter of the raster without depth (Z = 0 pixels are emitted like any other, p2c:24-44): still registered
+    db2 = db.copy()
+    db2[: h // 2, : w // 2] = 0
+    pb2 = R.unproject(db2, v["K"], ctx=ctx)
+    T2, info2 = icp.icp_point_to_plane(pb2, pa, tgt_shape=(h, w), init=T0, ctx=ctx)
+    assert info2["source_points_used"] == h * w - (h // 2) * (w // 2)
+    assert np.abs(T2[:3, :3] - T_true[:3, :3]).max() <= 2e-3 and np.abs(T2[:3, 3] - T_true[:3, 3]).max() <= 0.4
+
+
 def test_gpu_estimate_equals_an_independent_scipy_implementation(icp, S, ctx):
     h, w = 240, 320
     v, pa, pb = scene(S, h, w, 15.0, (0.35, 0.05, -0.2), noise=0.002)
