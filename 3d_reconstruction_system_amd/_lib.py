@@ -82,6 +82,8 @@ SIGNATURES = {
     "r3d_nn_index_rebuild": (_i, [_vp, _vp, _i64]),
     "r3d_gather_rows_strided": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "r3d_gather_rows": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "r3d_permutation_invert": (_i, [_vp, _vp, _i64, _vp]),
+    "r3d_remap_u32": (_i, [_vp, _vp, _i64, _vp, _i64]),
     "r3d_nn_index_query": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "r3d_nn_index_sort_cloud": (_i, [_vp, _vp, _i64, _vp]),
     "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),

@@ -199,6 +199,23 @@ __global__ __launch_bounds__(kThreads) void apply_pair_kernel(const ApplyArgs a)
   }
 }
 
+// k copies of one small f32 cloud, copy blockIdx.y moved by the blockIdx.y-th 4x4 of a table in HBM (the candidate poses of a
+// multi-start): the same arithmetic as apply_lane_kernel (out_row), one launch instead of k
+__global__ __launch_bounds__(kThreads) void apply_many_kernel(const float* __restrict__ in, uint64_t n, const double* __restrict__ Ts,
+                                                              float* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const double* M = Ts + (uint64_t)blockIdx.y * 16;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = M[k];
+  const double p[3] = {(double)in[i * 3], (double)in[i * 3 + 1], (double)in[i * 3 + 2]};
+  float* o = out + ((uint64_t)blockIdx.y * n + i) * 3;
+  o[0] = (float)out_row<false>(T, 0, p, p);
+  o[1] = (float)out_row<false>(T, 1, p, p);
+  o[2] = (float)out_row<false>(T, 2, p, p);
+}
+
 template <typename IT, bool SE3>
 void launch(const ApplyArgs& a, int out_dtype, int blocks, hipStream_t s) {
   if (out_dtype == R3D_F32)
@@ -298,13 +315,30 @@ int r3d_apply_T_host(r3d_ctx* ctx, const void* h_xyz_in, int in_dtype, int64_t n
 
 int r3d_apply_T_many(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* h_Ts, int n_transforms,
                      void* d_xyz_out, int out_dtype) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
   R3D_REQUIRE(n_transforms >= 0 && (n_transforms == 0 || h_Ts != nullptr), "bad transform list");
+  R3D_REQUIRE(in_dtype == R3D_F32 || in_dtype == R3D_F64, "unknown input dtype %d", in_dtype);
   R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
-  R3D_REQUIRE(n_transforms == 0 || d_xyz_in != d_xyz_out, "the copies cannot be written over the cloud they are made from");
-  const size_t block = (size_t)(n_points > 0 ? n_points : 0) * 3 * r3d_xyz_size(out_dtype);
+  R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
+  if (n_transforms == 0 || n_points == 0) return R3D_OK;
+  R3D_REQUIRE(d_xyz_in && d_xyz_out && d_xyz_in != d_xyz_out, "NULL device pointer, or the copies would overwrite the cloud they are made from");
+  if (in_dtype == R3D_F32 && out_dtype == R3D_F32 && n_transforms <= 65535) {
+    // the table of matrices travels through a scratch slot; the copy is enqueued from a staging copy that outlives the call
+    void* d_T = nullptr;
+    if ((rc = r3d_scratch(ctx, 4, (size_t)n_transforms * 16 * sizeof(double), &d_T))) return rc;
+    R3D_HIP(hipMemcpyAsync(d_T, h_Ts, (size_t)n_transforms * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    R3D_HIP(hipStreamSynchronize(ctx->stream));   // h_Ts is the caller's (pageable) memory
+    hipLaunchKernelGGL(apply_many_kernel, dim3((unsigned)((n_points + kThreads - 1) / kThreads), (unsigned)n_transforms), dim3(kThreads),
+                       0, ctx->stream, static_cast<const float*>(d_xyz_in), (uint64_t)n_points, static_cast<const double*>(d_T),
+                       static_cast<float*>(d_xyz_out));
+    R3D_HIP(hipGetLastError());
+    return R3D_OK;
+  }
+  const size_t block = (size_t)n_points * 3 * r3d_xyz_size(out_dtype);
   for (int k = 0; k < n_transforms; ++k) {
-    const int rc = apply_common<false>(ctx, d_xyz_in, in_dtype, n_points, h_Ts + 16 * (size_t)k,
-                                       static_cast<char*>(d_xyz_out) + block * (size_t)k, out_dtype);
+    rc = apply_common<false>(ctx, d_xyz_in, in_dtype, n_points, h_Ts + 16 * (size_t)k, static_cast<char*>(d_xyz_out) + block * (size_t)k,
+                             out_dtype);
     if (rc) return rc;
   }
   return R3D_OK;

@@ -482,7 +482,8 @@ int sorted_keys(r3d_ctx* ctx, const float* d_xyz, int64_t n, const float* d_fram
   hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz, n,
                      d_frame, axis_bits, idx_bits, d_keys);
   R3D_HIP(hipGetLastError());
-  return r3d_radix_sort_u64(ctx, d_keys, d_tmp, n, 3 * axis_bits + idx_bits);
+  // the low idx_bits hold the row number, which already ascends in the input: the stable sort skips those digits
+  return r3d_radix_sort_u64(ctx, d_keys, d_tmp, n, 3 * axis_bits + idx_bits, idx_bits);
 }
 
 }  // namespace
@@ -732,6 +733,47 @@ __global__ __launch_bounds__(kThreads) void rows_strided_kernel(const float* __r
   const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (j >= n_out) return;
   reinterpret_cast<P3*>(out)[j] = reinterpret_cast<const P3*>(xyz)[first + j * step];
+}
+
+// inverse of a permutation: inv[perm[j]] = j
+__global__ __launch_bounds__(kThreads) void perm_invert_kernel(const uint32_t* __restrict__ perm, int64_t n, uint32_t* __restrict__ inv) {
+  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = perm[j];
+  if ((int64_t)i < n) inv[i] = (uint32_t)j;
+}
+
+// values[k] <- table[values[k]] (0xffffffff where values[k] is outside the table)
+__global__ __launch_bounds__(kThreads) void remap_kernel(uint32_t* __restrict__ values, int64_t n, const uint32_t* __restrict__ table,
+                                                         int64_t n_table) {
+  const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t v = values[k];
+  values[k] = (int64_t)v < n_table ? table[v] : 0xffffffffu;
+}
+
+int r3d_permutation_invert(r3d_ctx* ctx, const uint32_t* d_perm, int64_t n, uint32_t* d_inverse_out) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return R3D_OK;
+  R3D_REQUIRE(d_perm && d_inverse_out && d_perm != d_inverse_out, "NULL or aliased device pointer");
+  hipLaunchKernelGGL(perm_invert_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_perm, n,
+                     d_inverse_out);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+int r3d_remap_u32(r3d_ctx* ctx, uint32_t* d_values, int64_t n, const uint32_t* d_table, int64_t n_table) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n >= 0 && n_table >= 0, "negative size");
+  if (n == 0) return R3D_OK;
+  R3D_REQUIRE(d_values && d_table, "NULL device pointer");
+  hipLaunchKernelGGL(remap_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_values, n, d_table,
+                     n_table);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
 }
 
 // rows perm[0], perm[1], ... of an xyz cloud

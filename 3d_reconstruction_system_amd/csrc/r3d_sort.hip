@@ -128,11 +128,14 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
 
 }  // namespace
 
-// Sorts d_keys[0..n) ascending by their low `bits` bits (bits rounded up to a multiple of 8, <= 64).
+// Sorts d_keys[0..n) ascending by their bits [first_bit, bits) (the span rounded up to whole 8-bit digits, <= 64), STABLY:
+// keys that agree on those bits keep their input order -- so a caller whose low bits already ascend (an index packed under
+// a Morton code) skips the passes over them.
 // d_tmp: scratch of n keys.  The result is in d_keys when the number of passes is even, else it is copied back.
-int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits) {
+int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit) {
   if (n <= 1) return R3D_OK;
-  const int passes = (bits + 7) / 8;
+  if (first_bit < 0 || first_bit >= bits) first_bit = 0;
+  const int passes = (bits - first_bit + 7) / 8;
   const int64_t n_blocks64 = (n + kTile - 1) / kTile;
   R3D_REQUIRE(n_blocks64 < ((int64_t)1 << 31), "too many keys for one sort");
   const int n_blocks = (int)n_blocks64;
@@ -146,7 +149,7 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
   uint64_t* src = d_keys;
   uint64_t* dst = d_tmp;
   for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
+    const int shift = first_bit + 8 * p;
     hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, totals);
     hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, ctx->stream, totals, bases);
@@ -172,7 +175,7 @@ int r3d_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, int64_t n_keys, int key_bits) {
   R3D_REQUIRE(d_keys != nullptr, "NULL device pointer");
   void* tmp = nullptr;
   if ((rc = r3d_scratch(ctx, 2, (size_t)n_keys * sizeof(uint64_t), &tmp))) return rc;
-  return r3d_radix_sort_u64(ctx, d_keys, static_cast<uint64_t*>(tmp), n_keys, key_bits);
+  return r3d_radix_sort_u64(ctx, d_keys, static_cast<uint64_t*>(tmp), n_keys, key_bits, 0);
 }
 
 }  // extern "C"

@@ -231,11 +231,20 @@ class IcpDevice:
         self._spacing = None
         self._spacing_pending, self._probe_index = False, None
         self.trace = None            # a list: _tick(name) then syncs and appends (name, seconds) -- icp_similarity(profile=True)
-        if self.index is not None and self.n:
-            # put the source cloud into the index's Morton order ONCE: rigid / similarity moves keep every
-            # workgroup's 256 sources a compact blob, so no later query needs to sort.  d_perm maps back.
-            self.d_perm = take(self.n * 4)
-            self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
+        self._src_index_rows = None  # "upload": the source index was built before sort_source() rearranged d_src; "sorted": after
+        self.d_inv = None            # inverse of d_perm (upload row -> current row), made when the back search needs it
+        self._take = take
+
+    def sort_source(self):
+        """Put the source cloud, WHERE IT LIES NOW, into the target index's Morton order -- once: rigid / similarity moves keep
+        every workgroup's 256 sources a compact blob, so no later query needs to sort.  d_perm maps back to the upload order.
+        The estimator calls this after its initial move: sorted where it was uploaded (another unit, another place: most
+        coordinates clamp to the target's quantisation frame) the cloud is NOT coherent, and every later query swept twice the
+        tiles (0.73 instead of 0.33 ms per iteration at 500k, found in round 3).  nn() / iterate() call it if nobody has."""
+        if self.index is None or not self.n or self.d_perm is not None:
+            return
+        self.d_perm = self._take(self.n * 4)
+        self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
 
     def _tick(self, name):
         if self.trace is not None:
@@ -255,10 +264,12 @@ class IcpDevice:
         """Index of the source cloud as it was uploaded (call before the first move, or not at all)."""
         if self._src_index is None:
             self._src_index = NNIndex(self.ctx, self.d_src.ptr, self.n)
+            self._src_index_rows = "upload" if self.d_perm is None else "sorted"
         return self._src_index
 
     def nn(self, want_stats=False):
         c = self.ctx
+        self.sort_source()
         if self.index is not None:
             return self.index.query(self.d_src.ptr, self.n, self.d_idx.ptr, self.d_d2.ptr, want_stats, presorted=True)
         L.check(c.lib.r3d_icp_nn(c.handle, self.d_src.ptr, self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr,
@@ -280,6 +291,7 @@ class IcpDevice:
     def nn_sums(self, max_d2=-1.0, dead_zone=0.0):
         """Nearest neighbours AND the 18 sums in one pass (culled index: sums taken in the query kernel's epilogue)."""
         c = self.ctx
+        self.sort_source()
         if self.index is not None:
             L.check(c.lib.r3d_nn_index_query_sums(self.index.handle, self.d_src.ptr, self.n, self.d_idx.ptr,
                                                   self.d_d2.ptr, 1, float(max_d2), float(dead_zone), self.d_sums.ptr))
@@ -390,6 +402,11 @@ class IcpDevice:
         L.check(c.lib.r3d_apply_T(c.handle, self.d_tgt.ptr, L.F32, self.m, T_inv.ctypes.data, d_moved.ptr, L.F32))
         ix.sort_cloud(d_moved.ptr, self.m, d_perm.ptr)
         L.check(c.lib.r3d_gather_rows(c.handle, self.d_tgt.ptr, self.m, d_perm.ptr, self.m, d_tgt_b.ptr))
+        self.sort_source()
+        if self._src_index_rows == "upload" and self.d_perm is not None and self.d_inv is None:
+            # the index reports rows of the cloud as uploaded; d_src has been rearranged since: upload row -> current row
+            self.d_inv = self._take(self.n * 4)
+            L.check(c.lib.r3d_permutation_invert(c.handle, self.d_perm.ptr, self.n, self.d_inv.ptr))
         self._back = {"index": ix, "tgt": d_tgt_b, "moved": d_moved, "idx": self._buf("bk_idx", self.m * 4),
                       "d2": self._buf("bk_d2", self.m * 4), "sums": self._buf("bk_sums", 18 * 8)}
 
@@ -410,6 +427,8 @@ class IcpDevice:
         L.check(c.lib.r3d_apply_T(c.handle, b["tgt"].ptr, L.F32, self.m, T_inv.ctypes.data, b["moved"].ptr, L.F32))
         self._tick("back.move")
         b["index"].query(b["moved"].ptr, self.m, b["idx"].ptr, b["d2"].ptr, presorted=True)
+        if self.d_inv is not None and self._src_index_rows == "upload":
+            L.check(c.lib.r3d_remap_u32(c.handle, b["idx"].ptr, self.m, self.d_inv.ptr, self.n))
         self._tick("back.query")
         gate = -1.0
         if trim is not None and trim < 1.0:
@@ -431,6 +450,7 @@ class IcpDevice:
 
     def iterate(self, n_iters, with_scale=True, max_d2=-1.0):
         c = self.ctx
+        self.sort_source()
         L.check(c.lib.r3d_icp_iterate(c.handle, self.index.handle if self.index is not None else None, self.d_src.ptr,
                                       self.n, self.d_tgt.ptr, self.m, self.d_idx.ptr, self.d_d2.ptr, int(n_iters),
                                       1 if with_scale else 0, float(max_d2), self.d_state.ptr))
@@ -586,6 +606,7 @@ def icp_similarity(src, tgt, max_iter=60, tol=1e-7, with_scale=True, trim_d2=Non
                 info["init_choice"] = best
                 T_total = cands[best][1]
             dev.move_source(T_total)
+        dev.sort_source()                    # where the source lies NOW (after the initial move), once
         mark("init")
         if mode == "auto" and dev.index is not None:
             mu = mom_t[1:4] / mom_t[0]
@@ -712,7 +733,9 @@ def select_quantile(d_values_ptr, n, q, ctx=None):
 class PlaneIcpDevice:
     """Source cloud + organised target cloud (with its normals) resident on one GPU for point-to-plane ICP."""
 
-    def __init__(self, src, tgt, tgt_shape=None, tgt_normals=None, max_jump=0.05, ctx=None):
+    def __init__(self, src, tgt, tgt_shape=None, tgt_normals=None, max_jump=0.05, ctx=None, init=None):
+        """init: 4x4 applied to the source BEFORE it is put into the index's Morton order (the order has to be taken where the
+        cloud lies when the queries run; rigid moves afterwards preserve it)."""
         self.ctx = c = ctx or default_context()
         src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
         tgt = np.ascontiguousarray(tgt, dtype=np.float32).reshape(-1, 3)
@@ -739,6 +762,8 @@ class PlaneIcpDevice:
         self.d_state = c.alloc(STATE_DOUBLES * 8)
         self.index = NNIndex(c, self.d_tgt.ptr, self.m)
         self.d_perm = c.alloc(self.n * 4)
+        if init is not None:
+            self.move_source(init)
         self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
 
     def move_source(self, T):
@@ -802,11 +827,9 @@ def icp_point_to_plane(src, tgt, tgt_shape=None, tgt_normals=None, init=None, ma
     src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
     keep = np.isfinite(src).all(axis=1) & np.any(src != 0, axis=1)
     src = src[keep]
-    dev = PlaneIcpDevice(src, tgt, tgt_shape, tgt_normals, max_jump, ctx)
+    T0 = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
+    dev = PlaneIcpDevice(src, tgt, tgt_shape, tgt_normals, max_jump, ctx, init=None if init is None else T0)
     try:
-        T0 = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
-        if init is not None:
-            dev.move_source(T0)
         dev.state_reset()
         extent = float(np.sqrt(np.mean(np.sum((src - src.mean(0)) ** 2, axis=1)))) or 1.0
         max_d2 = -1.0 if max_dist is None else float(max_dist) ** 2

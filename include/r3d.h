@@ -218,6 +218,11 @@ int r3d_nn_index_rebuild(r3d_nn_index* index, const float* d_tgt, int64_t n_tgt)
 /* Rows d_rows[0], d_rows[1], ... (n_out uint32 row numbers; a number >= n_points yields a NaN row) of a device xyz cloud into
  * d_xyz_out -- e.g. the permutation r3d_nn_index_sort_cloud reports, applied to a second cloud.  Asynchronous. */
 int r3d_gather_rows(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, const uint32_t* d_rows, int64_t n_out, float* d_xyz_out);
+/* d_inverse_out[d_perm[j]] = j for a permutation of 0..n-1 (uint32), and d_values[k] <- d_table[d_values[k]] in place
+ * (0xffffffff where d_values[k] >= n_table): row numbers reported against one ordering of a cloud, re-expressed in another --
+ * e.g. neighbours found through an index built before r3d_nn_index_sort_cloud rearranged the cloud.  Asynchronous. */
+int r3d_permutation_invert(r3d_ctx* ctx, const uint32_t* d_perm, int64_t n, uint32_t* d_inverse_out);
+int r3d_remap_u32(r3d_ctx* ctx, uint32_t* d_values, int64_t n, const uint32_t* d_table, int64_t n_table);
 /* Rows first, first + step, ... (n_out of them) of a device xyz cloud into d_xyz_out: strided samples without a trip to the
  * host.  Asynchronous. */
 int r3d_gather_rows_strided(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, int64_t first, int64_t step, int64_t n_out,
