@@ -204,6 +204,37 @@ def test_camera_to_world_script_frame_sharded_over_ranks(tmp_path, golden_dir, m
     assert got.shape == want.shape and (np.abs(got - want) / (1 + np.linalg.norm(want, axis=1, keepdims=True))).max() <= 1e-12
 
 
+@pytest.mark.parametrize("fault", ["missing", "other_size"])
+def test_sharded_dropin_fails_on_every_rank_instead_of_hanging(tmp_path, golden_dir, mock_rccl, fault):
+    """A rank whose depth frames cannot be read, or have another raster size than its peers', must not leave the others
+    waiting in a collective that has no timeout: the ranks agree on (ok, H, W, bytes per value) first and ALL raise.  Three
+    ranks, the fault in the LAST rank's block; the job has to come back non-zero well inside the deadline."""
+    import time
+    from PIL import Image
+    scene = os.path.join(golden_dir, "scene3")
+    for d in ("depth", "camera_pose"):
+        shutil.copytree(os.path.join(scene, d), tmp_path / d)
+    for d in ("point", "point_world", "ply"):
+        os.makedirs(tmp_path / d)
+    names, _q, _t = _r3d().read_pose_file(str(tmp_path / "camera_pose" / "image_colmap_simi_2.txt"))
+    victim = tmp_path / "depth" / names[-1]
+    if fault == "missing":
+        os.remove(victim)
+    else:
+        Image.fromarray(np.zeros((10, 12), np.uint8), mode="L").save(victim)
+    port = 29780 + (os.getpid() + (7 if fault == "missing" else 13)) % 100
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(SCRIPTS, "transfer", "camera_to_world.py")]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", R3D_RCCL_PATH=mock_rccl,
+                                R3D_SHARE_GPU="1"))
+    assert r.returncode != 0 and time.time() - t0 < 120, (r.returncode, time.time() - t0)
+    text = r.stdout + r.stderr
+    assert ("could not read their depth frames" in text) if fault == "missing" else ("depth rasters differ" in text), text[-3000:]
+    assert not (tmp_path / "ply" / "small_035_p8.ply").exists()
+
+
 def test_pixel_to_camera_script_writes_the_coloured_ply_when_the_image_exists(tmp_path):
     """p2c:136 calls its writer with (points, ./img/24.png, ply path) -- the coloured writer's signature.  With ./img/24.png
     present the drop-in's main() writes `x y z R G B 0` rows under the uchar header of p2c:71-87; the oracle's formatter
