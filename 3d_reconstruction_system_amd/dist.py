@@ -262,7 +262,7 @@ def all_gather_voxel_codes(codes, group=None):
     return np.unique(merged.numpy().view(np.uint64))
 
 
-def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm, everywhere=False, algo=0):
+def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm, everywhere=False, algo=0, pose_scale=1.0):
     """BASELINE config 4 as the drop-in runs it: the pose file's frames in contiguous blocks, one block per rank
     (camera_to_world.py:149-172 carries no state between frames).  Every rank decodes ITS depth PNGs, fuses them with one
     launch straight into its slot of the world cloud in HBM, and one all-gather over the C ABI (r3d_allgather_xyz: RCCL,
@@ -321,7 +321,7 @@ def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm,
         if hi > lo:
             cam = ctx.camera(h, w, *intrinsics)
             d_depth = ctx.alloc(depths.nbytes).upload(depths)
-            table = pose_table(quats[lo:hi], ts[lo:hi])
+            table = pose_table(quats[lo:hi], ts[lo:hi] * float(pose_scale))
             d_pose = ctx.alloc(table.nbytes).upload(table)
             bufs += [d_depth, d_pose]
             fuse_frames_device(ctx, cam, d_depth.ptr, depths.dtype, hi - lo, d_pose.ptr, mine, out_dtype)

@@ -6,6 +6,9 @@ Environment (all optional; the defaults are the reference's hard-coded values):
   R3D_FX R3D_FY R3D_CX R3D_CY   pinhole intrinsics        (p2c:25-28, c2w:68-71)
   R3D_DEVICE                    GPU index                 (default 0)
   R3D_SKIP_INTERMEDIATE=1       do not write ./point/<stem>.txt and ./point_world/*.txt
+  R3D_POSE_SCALE                a number, or the path of a file holding one (e.g. the ./scale.txt that
+                                `transfer_T_icp.py --estimate-rigid --colmap ...` writes): every pose translation is multiplied
+                                by it -- COLMAP's unit brought to the depth maps' unit (readme.md:25).  Default 1 = the reference.
   WORLD_SIZE RANK LOCAL_RANK    set by a one-process-per-GPU launcher (torch.distributed.run ...): frames are sharded
 """
 import importlib
@@ -41,6 +44,17 @@ def intrinsics():
 
 def context():
     return package().default_context(int(os.environ.get("R3D_DEVICE", "0")))
+
+
+def pose_scale():
+    v = os.environ.get("R3D_POSE_SCALE")
+    if not v:
+        return 1.0
+    try:
+        return float(v)
+    except ValueError:
+        with open(v) as f:
+            return float(f.read().split()[0])
 
 
 def skip_intermediate():

@@ -119,6 +119,7 @@ def fuse_pose_file(qt_path, depth_dir='./depth/', out_dtype=np.float64):
     if not names:
         return names, np.empty((0, 0, 0), np.uint8), np.empty((0, 3), out_dtype)
     depths = r3d.cloud_io.read_depth_batch([os.path.join(depth_dir, n) for n in names])
+    ts = ts * _common.pose_scale()               # 1 unless R3D_POSE_SCALE says otherwise (COLMAP unit -> depth unit)
     world = r3d.fuse_frames(depths, quats, ts, intrinsics=_common.intrinsics(), out_dtype=out_dtype,
                             ctx=_common.context())
     return names, depths, world
@@ -144,23 +145,26 @@ def _get_file_name_sharded(qt_path):
     if comm.rank == 0:
         print('data start transfer')
     t1 = time.time()
-    names, lo, hi, depths, world = D.fuse_pose_file_sharded(qt_path, './depth/', _common.intrinsics(), np.float64, ctx, comm)
+    names, lo, hi, depths, world = D.fuse_pose_file_sharded(qt_path, './depth/', _common.intrinsics(), np.float64, ctx, comm,
+                                                            pose_scale=_common.pose_scale())
     n_frames = len(names)
-    if n_frames and not _common.skip_intermediate():
-        if hi > lo:
-            per = depths.shape[1] * depths.shape[2]
-            cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=ctx)
-            _write_camera_txts(names[lo:hi], cam, depths, per)          # this rank's frames only
+    try:        # a rank that fails while writing its files must still meet the others at the barrier, then raise
+        if n_frames and not _common.skip_intermediate():
+            if hi > lo:
+                per = depths.shape[1] * depths.shape[2]
+                cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=ctx)
+                _write_camera_txts(names[lo:hi], cam, depths, per)          # this rank's frames only
+            if comm.rank == 0:
+                per = world.shape[0] // n_frames
+                r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
+        t2 = time.time()
         if comm.rank == 0:
-            per = world.shape[0] // n_frames
-            r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
-    t2 = time.time()
-    if comm.rank == 0:
-        print('##################')
-        print("%d frames cost ." % n_frames, t2 - t1)
-        genply(world, './ply/small_035_p8.ply', world.shape[0])
-    comm.barrier()                             # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
-    comm.close()
+            print('##################')
+            print("%d frames cost ." % n_frames, t2 - t1)
+            genply(world, './ply/small_035_p8.ply', world.shape[0])
+    finally:
+        comm.barrier()                         # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
+        comm.close()
 
 
 def get_file_name(qt_path):

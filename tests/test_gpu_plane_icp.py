@@ -380,3 +380,45 @@ def test_dropin_estimates_T_data_from_two_camera_txt_files(icp, S, tmp_path):
     assert merged.shape == (2 * h * w, 3)
     want_b = pb.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
     np.testing.assert_allclose(merged[h * w:], want_b, atol=6e-5 + 1e-4)          # %.4f text
+
+
+def test_scale_correction_pipeline_through_the_scripts(S, tmp_path):
+    """The pipeline the readme describes (readme.md:15-34), run with the drop-in scripts only: 8-bit depth PNGs of two images +
+    COLMAP poses in COLMAP's own unit -> camera_to_world.py leaves ./point/0.txt and ./point/24.txt -> transfer_T_icp.py
+    --estimate-rigid --colmap finds the relative pose and the unit ratio -> camera_to_world.py with R3D_POSE_SCALE=./scale.txt
+    fuses both frames into ONE consistent world cloud: every point back on a wall of the room (to a depth level or so)."""
+    from PIL import Image
+    R = _r3d()
+    h, w, unit, s_true = 240, 320, 40.0, 3.0
+    v = S.two_views(h, w, yaw_deg=12.0, baseline=(0.25, 0.03, -0.1), seed=1)
+    for d in ("depth", "camera_pose", "point", "point_world", "ply/icp"):
+        os.makedirs(tmp_path / d)
+    for name, z in (("0.png", v["depth_a"]), ("24.png", v["depth_b"])):
+        Image.fromarray(np.clip(np.round(z * unit), 0, 255).astype(np.uint8), mode="L").save(tmp_path / "depth" / name)
+    with open(tmp_path / "camera_pose" / "image_colmap_simi_2.txt", "w") as f:
+        f.write("id,tx,ty,tz,qx,qy,qz,qw,name,extra\n")
+        for k, (name, (q, t)) in enumerate((("0.png", v["pose_a"]), ("24.png", v["pose_b"]))):
+            f.write(",".join([str(k)] + [repr(float(x)) for x in (t * unit / s_true)] + [repr(float(x)) for x in q] + [name, "x"]) + "\n")
+    fx, fy, cx, cy = v["K"]
+    env = dict(os.environ, R3D_FX=repr(float(fx)), R3D_FY=repr(float(fy)), R3D_CX=repr(float(cx)), R3D_CY=repr(float(cy)))
+
+    def script(rel, *args, **extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, PKG, rel)] + list(args), cwd=str(tmp_path), capture_output=True,
+                           text=True, timeout=600, env=dict(env, **extra))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stdout
+
+    def wall_distance(ply):
+        pts = R.cloud_io.read_ply(ply)
+        lo, hi = S.ROOM_LO * unit, S.ROOM_HI * unit
+        return np.minimum(np.abs(pts - lo), np.abs(pts - hi)).min(axis=1)
+
+    script("transfer/camera_to_world.py")                                   # COLMAP's unit as it comes: the two frames disagree
+    before = wall_distance(str(tmp_path / "ply" / "small_035_p8.ply"))
+    out = script("other_tools/transfer_T_icp.py", "--estimate-rigid", "--colmap", "camera_pose/image_colmap_simi_2.txt", "0.png",
+                 "24.png", "--colmap-scale", "2.5")
+    scale = float(open(tmp_path / "scale.txt").read())
+    assert abs(scale - s_true) / s_true <= 1e-2, (scale, out)
+    script("transfer/camera_to_world.py", R3D_POSE_SCALE="./scale.txt")
+    after = wall_distance(str(tmp_path / "ply" / "small_035_p8.ply"))
+    assert np.quantile(after, 0.99) <= 1.5 and np.quantile(before, 0.5) > 5.0, (np.quantile(after, 0.99), np.quantile(before, 0.5))
