@@ -742,10 +742,12 @@ class PlaneIcpDevice:
         if tgt.shape[0] < 1 or src.shape[0] < 6:
             raise ValueError("need a target cloud and at least 6 source points")
         self.n, self.m = src.shape[0], tgt.shape[0]
-        self.d_src = c.alloc(src.nbytes).upload(src)         # moved cloud, index order
-        self.d_src0 = c.alloc(src.nbytes)                    # the cloud as it was at the last state reset
-        self.d_tgt = c.alloc(tgt.nbytes).upload(tgt)
-        self.d_nrm = c.alloc(tgt.nbytes)
+        self._arena = _Arena(c, 36 * self.n + 24 * self.m + (1 << 16))      # one block for everything below
+        take = self._arena.take
+        self.d_src = take(src.nbytes).upload(src)            # moved cloud, index order
+        self.d_src0 = take(src.nbytes)                       # the cloud as it was at the last state reset
+        self.d_tgt = take(tgt.nbytes).upload(tgt)
+        self.d_nrm = take(tgt.nbytes)
         if tgt_normals is not None:
             nrm = np.ascontiguousarray(tgt_normals, dtype=np.float32).reshape(-1, 3)
             if nrm.shape != tgt.shape:
@@ -757,11 +759,11 @@ class PlaneIcpDevice:
                                  "(or pass tgt_normals)")
             L.check(c.lib.r3d_normals_organized(c.handle, self.d_tgt.ptr, 1, int(tgt_shape[0]), int(tgt_shape[1]),
                                                 float(max_jump), None, self.d_nrm.ptr))
-        self.d_idx, self.d_d2 = c.alloc(self.n * 4), c.alloc(self.n * 4)
-        self.d_sums = c.alloc(PLANE_SUMS * 8)
-        self.d_state = c.alloc(STATE_DOUBLES * 8)
+        self.d_idx, self.d_d2 = take(self.n * 4), take(self.n * 4)
+        self.d_sums = take(PLANE_SUMS * 8)
+        self.d_state = take(STATE_DOUBLES * 8)
         self.index = NNIndex(c, self.d_tgt.ptr, self.m)
-        self.d_perm = c.alloc(self.n * 4)
+        self.d_perm = take(self.n * 4)
         if init is not None:
             self.move_source(init)
         self.index.sort_cloud(self.d_src.ptr, self.n, self.d_perm.ptr)
@@ -804,8 +806,8 @@ class PlaneIcpDevice:
 
     def free(self):
         self.index.close()
-        for b in (self.d_src, self.d_src0, self.d_tgt, self.d_nrm, self.d_idx, self.d_d2, self.d_sums, self.d_state, self.d_perm):
-            b.free()
+        self.ctx.sync()
+        self._arena.free()
 
 
 def icp_point_to_plane(src, tgt, tgt_shape=None, tgt_normals=None, init=None, max_iter=60, trim=0.5, gate_scale=20.0,
@@ -825,13 +827,18 @@ def icp_point_to_plane(src, tgt, tgt_shape=None, tgt_normals=None, init=None, ma
     less than `tol` x the cloud's size, or after max_iter.
     max_dist: pairs farther apart than this (point to point) never take part."""
     src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
-    keep = np.isfinite(src).all(axis=1) & np.any(src != 0, axis=1)
-    src = src[keep]
+    # rows at the camera origin (Z = 0 pixels) and non-finite rows are no points: one pass each, and no copy when all are good
+    # (this host step was a third of the wall time before it was written this way)
+    with np.errstate(invalid="ignore", over="ignore"):
+        keep = np.isfinite(src.sum(axis=1, dtype=np.float64)) & ((src[:, 2] != 0) | (src[:, 0] != 0) | (src[:, 1] != 0))
+    if not keep.all():
+        src = src[keep]
     T0 = np.eye(4) if init is None else np.array(init, dtype=np.float64).reshape(4, 4)
     dev = PlaneIcpDevice(src, tgt, tgt_shape, tgt_normals, max_jump, ctx, init=None if init is None else T0)
     try:
         dev.state_reset()
-        extent = float(np.sqrt(np.mean(np.sum((src - src.mean(0)) ** 2, axis=1)))) or 1.0
+        sample = src[::max(1, src.shape[0] // 8192)].astype(np.float64)          # the cloud's size, for the stopping rule only
+        extent = float(np.sqrt(((sample - sample.mean(0)) ** 2).sum(axis=1).mean())) or 1.0
         max_d2 = -1.0 if max_dist is None else float(max_dist) ** 2
         done, converged = 0, None
         while done < max_iter and converged is None:

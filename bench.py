@@ -176,6 +176,16 @@ def regimes(a):
         ctx.set_tuning("fuse_prefetch", knob)
         ms = median_ms(fuse_rotating)
         out[key + "_ms"], out[key + "_frac"] = round(ms, 5), frac(ms)
+    # for the record, what the library's default costs where it is NOT needed: ONE raster re-read every launch (the parent's
+    # bench loop), staging off = the fused kernel alone on cached inputs (rounds 1-2 measured this) / library default
+    def fuse_same():
+        r3d.fuse_frames_device(ctx, cam, copies[0].ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
+    same = {}
+    for key, knob in (("staging_off", 1), ("auto", 0)):
+        ctx.set_tuning("fuse_prefetch", knob)
+        ms = median_ms(fuse_same, groups=8, per=50, warm=100)
+        same[key + "_ms"], same[key + "_frac"] = round(ms, 5), frac(ms)
+    out["same_raster_every_launch"] = same
     # (2) fuse right after an H2D upload of fresh frames (pinned host memory -> the same device raster every time)
     host = ctx.pinned_empty((F, H, W), np.uint8)
     host[...] = raster

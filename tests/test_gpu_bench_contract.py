@@ -56,6 +56,8 @@ def test_headline_line_is_complete_and_self_consistent():
     assert cold["raster_copies"] * 49152000 > 2 * 256 * 2 ** 20
     assert 0.3 < cold["plain_frac"] < cold["staged_frac"] <= rf["frac"] + 0.02, cold
     assert cold["auto_frac"] >= cold["plain_frac"] - 0.02
+    same = cold["same_raster_every_launch"]            # the cost of the staging default where it is not needed, on the record
+    assert 0.8 < same["staging_off_frac"] < 1.0 and abs(same["auto_frac"] - rf["sustained"]["frac"]) < 0.03, (same, rf["sustained"])
     h2d = cold["after_h2d_upload"]
     assert 0.3 < h2d["plain_frac"] < 1.0 and 0.3 < h2d["staged_frac"] < 1.0 and h2d["auto_frac"] >= min(h2d["plain_frac"], h2d["staged_frac"]) - 0.03
     c4 = cold["c4_1000_frames_one_gpu"]

@@ -36,8 +36,16 @@ ALGO = {
 }
 
 
+def fresh(hits):
+    """gpurun merges every collection into the same local directory: keep the files of the NEWEST run only."""
+    if not hits:
+        return hits
+    newest = max(os.path.getmtime(h) for h in hits)
+    return [h for h in hits if newest - os.path.getmtime(h) < 900]
+
+
 def one(pattern):
-    hits = glob.glob(pattern, recursive=True)
+    hits = fresh(glob.glob(pattern, recursive=True))
     if not hits:
         raise SystemExit("nothing matches " + pattern)
     return hits[0]
@@ -47,7 +55,7 @@ def most_calls(pattern, kernel):
     """Of several <pid>_kernel_stats.csv files (bench.py's regimes child is traced too) the one whose process launched
     `kernel` most often: the bench process itself."""
     best, best_calls = None, -1
-    for f in glob.glob(pattern, recursive=True):
+    for f in fresh(glob.glob(pattern, recursive=True)):
         calls = sum(int(r["Calls"]) for r in csv.DictReader(open(f)) if kernel in r["Name"])
         if calls > best_calls:
             best, best_calls = f, calls
@@ -97,7 +105,7 @@ def main():
         summary["algorithmic_TBps_at_kernel_average"] = N_C2 * 13 / float(row["AverageNs"]) / 1e3
         summary["algorithmic_TBps_at_step_average"] = N_C2 * 13 / summary["step_average_ns_sweep_plus_fuse"] / 1e3
     # the regimes child (same kernel symbols, other regimes): kept apart on purpose
-    child = [f for f in glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True) if f != stats]
+    child = [f for f in fresh(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)) if f != stats]
     if child:
         shutil.copy(child[0], os.path.join(dst, "%s_fuse_regimes_child_kernel_stats.csv" % a.round))
     for line in open(os.path.join(src, "trace.log")):
