@@ -45,38 +45,66 @@ struct __attribute__((packed, aligned(4))) P3 {
   float x, y, z;
 };
 
-__device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 16 bits -> every third bit
-  uint64_t x = v & 0xffffu;
-  x = (x | x << 16) & 0x0000ff0000ffull;
-  x = (x | x << 8) & 0x00f00f00f00full;
-  x = (x | x << 4) & 0x0c30c30c30c3ull;
-  x = (x | x << 2) & 0x249249249249ull;
+// 8 bits -> every third bit of 24, in 32-bit registers (the 64-bit spread costs two instructions per step)
+__device__ __forceinline__ uint32_t spread3_byte(uint32_t x) {
+  x = (x | (x << 8)) & 0x0000f00fu;
+  x = (x | (x << 4)) & 0x000c30c3u;
+  x = (x | (x << 2)) & 0x00249249u;
   return x;
 }
 
+// 48-bit Morton code of three 16-bit keys (x lowest): low bytes -> bits 0..23, high bytes -> bits 24..47
+__device__ __forceinline__ uint64_t morton48(uint32_t ix, uint32_t iy, uint32_t iz) {
+  const uint32_t lo = spread3_byte(ix & 0xffu) | (spread3_byte(iy & 0xffu) << 1) | (spread3_byte(iz & 0xffu) << 2);
+  const uint32_t hi = spread3_byte(ix >> 8) | (spread3_byte(iy >> 8) << 1) | (spread3_byte(iz >> 8) << 2);
+  return (uint64_t)lo | ((uint64_t)hi << 24);
+}
+
+// Keys in fp64 exactly as OcTreeBaseImpl::coordToKey computes them.  (An exact fp32 formulation -- t = round(x f), r = fma(x, f,
+// -t), floor(t) corrected when t is an integer and r < 0; valid when 1/res is exactly a float -- passed every face / ulp /
+// denormal test in round 3 and was 4 % SLOWER on the scan benchmark: the kernel does not wait for its ALUs.  Not shipped.)
 __device__ __forceinline__ bool voxel_code(const P3& p, double factor, uint64_t* code) {
-  const double kx = floor(factor * (double)p.x), ky = floor(factor * (double)p.y), kz = floor(factor * (double)p.z);
+  const double dx = floor(factor * (double)p.x), dy = floor(factor * (double)p.y), dz = floor(factor * (double)p.z);
   // rejects NaN/inf and anything outside the 2^16 key range
-  const bool ok = kx >= -(double)kTreeMaxVal && kx < (double)kTreeMaxVal && ky >= -(double)kTreeMaxVal &&
-                  ky < (double)kTreeMaxVal && kz >= -(double)kTreeMaxVal && kz < (double)kTreeMaxVal;
+  const bool ok = dx >= -(double)kTreeMaxVal && dx < (double)kTreeMaxVal && dy >= -(double)kTreeMaxVal &&
+                  dy < (double)kTreeMaxVal && dz >= -(double)kTreeMaxVal && dz < (double)kTreeMaxVal;
   if (!ok) return false;
-  const uint32_t ix = (uint32_t)((int)kx + kTreeMaxVal), iy = (uint32_t)((int)ky + kTreeMaxVal),
-                 iz = (uint32_t)((int)kz + kTreeMaxVal);
-  *code = spread3(ix) | (spread3(iy) << 1) | (spread3(iz) << 2);
+  *code = morton48((uint32_t)((int)dx + kTreeMaxVal), (uint32_t)((int)dy + kTreeMaxVal), (uint32_t)((int)dz + kTreeMaxVal));
   return true;
+}
+
+// the value the previous lane of the wave holds (lane 0: its own), by DPP wave_shr:1 -- one VALU move per 32 bits instead of a
+// ds_bpermute round trip through the LDS crossbar (__shfl_up compiles to two of those for a 64-bit value)
+__device__ __forceinline__ uint64_t prev_lane_u64(uint64_t v) {
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
 }
 
 constexpr int kLdsSlots = 2048;     // per-workgroup dedupe table (16 KB)
 constexpr int kLdsKeepBelow = 512;   // it survives from tile to tile while it holds fewer codes than this (then <= 75 % full)
 
-// DEDUPE: a workgroup funnels its codes through a small LDS hash set; only the first lane to claim a code goes on to the
-// global table.  Real clouds put tens to hundreds of points into one 10 cm voxel, and neighbouring image rows fall into
-// the SAME voxels.  In-kernel clocks on such a cloud (late round 2) put 46 % of the wave time into the returning global
-// atomics and 29 % into the loads -- with few atomics per tile: it is the SAME table words being hit from many compute
-// units at once.  So a workgroup walks a CONTIGUOUS run of tiles (neighbouring rows, the same voxels) and KEEPS its LDS
-// set from tile to tile: a code found there was sent to the global table by whoever claimed it, in this tile or an
-// earlier one.  The set is wiped once it has collected kLdsKeepBelow codes (every tile on all-distinct data, rarely on
-// a scan).
+// One code into the global open-addressing table (64-bit CAS, linear probing).  Returns 1 new, 0 already there, -1 no slot.
+__device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64_t mask, int log2cap, uint64_t code) {
+  uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+  for (uint64_t probe = 0; probe <= mask; ++probe) {
+    const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
+                                   (unsigned long long)code);
+    if (old == kEmpty) return 1;
+    if (old == code) return 0;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+// DEDUPE: a workgroup funnels its codes through a small LDS hash set and walks a CONTIGUOUS run of tiles (neighbouring
+// image rows fall into the SAME voxels), keeping the set from tile to tile.  Round 2 sent every newly claimed code to the
+// global table on the spot: a handful of returning global atomics per tile, each a ~2 us round trip that the whole wave sat
+// out (PMC: waves waiting 85 % of their cycles, 109 VALU instructions per 64 points; in-kernel clocks: 46 % in those atomics).
+// Round 3: while it walks its tiles a workgroup touches LDS only -- a claimed code simply STAYS in the set -- and the set is
+// flushed to the global table as a whole, all 256 lanes inserting in parallel, when it has collected kLdsKeepBelow codes and
+// at the end of the run: the round trips are paid once per ~512 codes instead of once per tile.  A code that finds the set full
+// (cannot happen below 75 % load) goes to the global table directly.
 template <bool DEDUPE>
 __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __restrict__ xyz, int64_t n, double factor,
                                                                 uint64_t* __restrict__ table, int log2cap,
@@ -84,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
   __shared__ unsigned long long local_set[DEDUPE ? kLdsSlots : 1];
   // codes gained per tile, three counters in rotation: tile j adds into [j % 3], everyone reads it after the next barrier,
   // thread 0 zeroes [(j + 1) % 3] there -- whose last readers all passed that barrier -- so the running total every thread
-  // keeps in a register is the same in all of them and the decision to wipe is workgroup-uniform
+  // keeps in a register is the same in all of them and the decision to flush is workgroup-uniform
   __shared__ unsigned local_fill[3];
   const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
   const int lane = threadIdx.x & 63;
@@ -98,24 +126,53 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
     for (int k = threadIdx.x; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
     if (threadIdx.x < 3) local_fill[threadIdx.x] = 0;
   }
+  // every code of the set into the global table, the set emptied: all lanes at once, kLdsSlots / kThreads slots each
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < kLdsSlots / kThreads; ++k) {
+      const int s = k * kThreads + threadIdx.x;
+      const uint64_t code = local_set[s];
+      if (code != kEmpty) {
+        local_set[s] = kEmpty;
+        const int r = table_insert(table, mask, log2cap, code);
+        n_new += r > 0 ? 1u : 0u;
+        n_over += r < 0 ? 1u : 0u;
+      }
+    }
+  };
   unsigned total = 0, j = 0;  // codes in the set (same value in every thread), tiles done by this workgroup
+  P3 pn[4];                   // the next tile's points, in flight
+  if (tile_lo < tile_hi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = tile_lo * (kThreads * 4) + threadIdx.x + (int64_t)r * kThreads;
+      pn[r] = reinterpret_cast<const P3*>(xyz)[i < n ? i : n - 1];
+    }
+  }
   for (int64_t tile = tile_lo; tile < tile_hi; ++tile, ++j) {
     if (DEDUPE) {
       __syncthreads();  // the previous tile's lookups and its count are done (first tile: the wipe above has landed)
       if (j > 0) total += local_fill[(j - 1) % 3];
       if (threadIdx.x == 0) local_fill[(j + 1) % 3] = 0;
       if (total >= (unsigned)kLdsKeepBelow) {  // workgroup-uniform
-        for (int k = threadIdx.x; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
+        flush();
         total = 0;
         __syncthreads();
       }
     }
     const int64_t base = tile * (kThreads * 4) + threadIdx.x;
+    // the NEXT tile's points are requested before this tile's are worked on (clamped addresses: unconditional loads), so
+    // that the HBM round trip of tile k+1 runs under the key arithmetic and the LDS lookups of tile k
     P3 p[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + (int64_t)r * kThreads;
-      if (i < n) p[r] = reinterpret_cast<const P3*>(xyz)[i];
+    for (int r = 0; r < 4; ++r) p[r] = pn[r];
+    if (tile + 1 < tile_hi) {
+      const int64_t nbase = base + kThreads * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = nbase + (int64_t)r * kThreads;
+        pn[r] = reinterpret_cast<const P3*>(xyz)[i < n ? i : n - 1];
+      }
     }
     unsigned claimed = 0;
 #pragma unroll
@@ -130,41 +187,32 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       }
       // neighbouring pixels mostly fall into the same voxel: a lane whose predecessor carries the same
       // code leaves the insert to it
-      const uint64_t prev = __shfl_up(code, 1, 64);
+      const uint64_t prev = prev_lane_u64(code);
       if (live && lane > 0 && prev == code) live = false;
       if (DEDUPE && live) {
         uint32_t slot = (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
         bool mine = false, done = false;
+        // most codes of a scan are already in the set (the previous rows put them there): a plain LDS read settles those
+        // without a compare-and-swap
+        if (local_set[slot] == code) done = true;
         for (int probe = 0; probe < kLdsSlots && !done; ++probe) {
           const unsigned long long old = atomicCAS(&local_set[slot], (unsigned long long)kEmpty, (unsigned long long)code);
           if (old == kEmpty) {
             mine = true;
             done = true;
           } else if (old == code) {
-            done = true;  // a lane of this workgroup already carries (or carried) it to the global table
+            done = true;  // already in the set: it reaches the global table with the next flush
           } else {
             slot = (slot + 1) & (kLdsSlots - 1);
           }
         }
         claimed += mine ? 1u : 0u;
-        live = mine || !done;  // a full local table (cannot happen: < 512 + 1024 codes in 2048 slots) would fall through
+        live = !done;  // a full set (cannot happen: < 512 + 1024 codes in 2048 slots) sends the code on directly
       }
       if (live) {
-        uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
-        bool done = false;
-        for (uint64_t probe = 0; probe <= mask && !done; ++probe) {
-          const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
-                                         (unsigned long long)code);
-          if (old == kEmpty) {
-            ++n_new;
-            done = true;
-          } else if (old == code) {
-            done = true;
-          } else {
-            slot = (slot + 1) & mask;
-          }
-        }
-        if (!done) ++n_over;
+        const int r2 = table_insert(table, mask, log2cap, code);
+        n_new += r2 > 0 ? 1u : 0u;
+        n_over += r2 < 0 ? 1u : 0u;
       }
     }
     if (DEDUPE) {  // one LDS add per wave: how many codes the set gained in this tile
@@ -172,6 +220,10 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       for (int off = 32; off > 0; off >>= 1) claimed += __shfl_down(claimed, off, 64);
       if (lane == 0 && claimed) atomicAdd(&local_fill[j % 3], claimed);
     }
+  }
+  if (DEDUPE) {
+    __syncthreads();   // every lane's last lookups have landed
+    flush();
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -194,9 +194,9 @@ def test_keys_of_points_on_and_next_to_voxel_faces(V, ctx, res):
     xyz = np.concatenate([xyz, (rng.normal(size=(50000, 3)) * 50).astype(np.float32),
                           np.array([[-32768 * res, 0, 0], [32768 * res, 0, 0], [np.nextafter(np.float32(32768 * res), np.float32(0)), 0, 0],
                                     [1e30, 0, 0], [-1e30, 0, 0], [0, np.nan, 0], [0, 0, np.inf]], np.float32)])
+    want, dropped = OM.occupied_set(xyz, res)
     vs = V.VoxelSet(res, 1 << 21, ctx)
     vs.insert(xyz)
-    want, dropped = OM.occupied_set(xyz, res)
     st = vs.stats()
     assert st["overflow"] == 0 and st["ignored_points"] == dropped
     np.testing.assert_array_equal(vs.codes(), want)
