@@ -49,6 +49,7 @@ SIGNATURES = {
     "r3d_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "r3d_download": (_i, [_vp, _vp, _vp, _sz]),
     "r3d_memset": (_i, [_vp, _vp, _i, _sz]),
     "r3d_cache_prefetch": (_i, [_vp, _vp, _sz]),
     "r3d_host_alloc": (_i, [_vp, _sz, _pvp]),

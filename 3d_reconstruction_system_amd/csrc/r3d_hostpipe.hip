@@ -159,6 +159,53 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
   return R3D_OK;
 }
 
+// Device -> pageable host memory at the pinned PCIe rate: 32 MiB chunks through the two pinned staging buffers of the
+// pipeline's first output array, the pageable copy of chunk c spread over host threads while chunk c+1 crosses the bus.
+// Synchronous.  (A plain hipMemcpy into a fresh NumPy array runs at ~12 GB/s: 31 of the 36 ms of a 48 M-code voxel list.)
+int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (bytes == 0) return R3D_OK;
+  if (bytes < ((size_t)8 << 20) || is_pinned(h_dst)) {
+    R3D_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+  }
+  int rc;
+  unsigned n_threads = std::thread::hardware_concurrency();
+  n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
+  const size_t chunk = (size_t)32 << 20;
+  void* pin[2] = {};
+  for (int b = 0; b < 2; ++b)
+    if ((rc = pinned_slot(ctx, (1 * r3d_ctx::kPipeBufs + 0) * 2 + b, chunk, &pin[b]))) return rc;
+  if (!ctx->ev_pipe[0]) {
+    for (int k = 0; k < 6; ++k) R3D_HIP(hipEventCreateWithFlags(&ctx->ev_pipe[k], hipEventDisableTiming));
+    R3D_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+  }
+  const size_t n_chunks = (bytes + chunk - 1) / chunk;
+  auto drain = [&](size_t c) -> int {
+    const size_t lo = c * chunk, n = std::min(chunk, bytes - lo);
+    const hipError_t e = hipEventSynchronize(ctx->ev_pipe[c & 1]);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return r3d_fail_hip(e, "download", __FILE__, __LINE__);
+    }
+    parallel_memcpy(static_cast<char*>(h_dst) + lo, pin[c & 1], n, n_threads);
+    return R3D_OK;
+  };
+  for (size_t c = 0; c < n_chunks; ++c) {
+    if (c >= 2 && (rc = drain(c - 2))) return rc;
+    const size_t lo = c * chunk, n = std::min(chunk, bytes - lo);
+    hipError_t e = hipMemcpyAsync(pin[c & 1], static_cast<const char*>(d_src) + lo, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_pipe[c & 1], ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return r3d_fail_hip(e, "download", __FILE__, __LINE__);
+    }
+  }
+  for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c)
+    if ((rc = drain(c))) return rc;
+  return R3D_OK;
+}
+
 int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_t out_item_bytes, const void* h_in,
                       void* h_out, void* d_in, void* d_out, const std::function<int(int64_t, int64_t)>& launch) {
   const r3d_pipe_buf in{const_cast<void*>(h_in), d_in, in_item_bytes}, out{h_out, d_out, out_item_bytes};
@@ -166,6 +213,14 @@ int r3d_host_pipeline(r3d_ctx* ctx, int64_t n_items, size_t in_item_bytes, size_
 }
 
 extern "C" {
+
+int r3d_download(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  if (bytes == 0) return R3D_OK;
+  R3D_REQUIRE(h_dst && d_src, "NULL pointer with bytes > 0");
+  return r3d_download_pageable(ctx, h_dst, d_src, bytes);
+}
 
 int r3d_host_alloc(r3d_ctx* ctx, size_t bytes, void** h_ptr_out) {
   int rc = r3d_ctx_enter(ctx);

@@ -95,6 +95,9 @@ struct r3d_pipe_buf {
 int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* ins, int n_in, const r3d_pipe_buf* outs,
                             int n_out, const std::function<int(int64_t, int64_t)>& launch);
 
+// Device -> pageable host memory through pinned staging chunks (r3d_hostpipe.hip); synchronous.
+int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
 // Stable LSD radix sort of 64-bit keys by their bits [first_bit, bits) (r3d_sort.hip); d_tmp holds n keys.
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit = 0);
 

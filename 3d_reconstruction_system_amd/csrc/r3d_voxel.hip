@@ -705,9 +705,7 @@ int r3d_voxelset_codes(r3d_voxelset* vs, uint64_t* h_codes_sorted, int64_t cap, 
   if (rc) return rc;
   R3D_REQUIRE(cap >= n, "buffer holds %lld codes, set has %lld", (long long)cap, (long long)n);
   if (n == 0) return R3D_OK;
-  R3D_HIP(hipMemcpyAsync(h_codes_sorted, d_list, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, vs->ctx->stream));
-  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
-  return R3D_OK;
+  return r3d_download_pageable(vs->ctx, h_codes_sorted, d_list, (size_t)n * sizeof(uint64_t));
 }
 
 int r3d_octree_format_bt(const uint64_t* h_codes_sorted, int64_t n_codes, double resolution, char* h_buf,

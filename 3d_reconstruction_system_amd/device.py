@@ -66,8 +66,7 @@ class DeviceBuffer:
     def download(self, dtype, count):
         out = np.empty(count, dtype=dtype)
         assert out.nbytes <= self.nbytes
-        L.check(self.ctx.lib.r3d_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
-        self.ctx.sync()
+        L.check(self.ctx.lib.r3d_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))   # synchronous
         return out
 
     def free(self):

@@ -92,6 +92,10 @@ int r3d_dev_free(r3d_ctx* ctx, void* d_ptr);
 int r3d_memcpy_h2d(r3d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* async on ctx stream */
 int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on ctx stream */
 int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes); /* async on ctx stream */
+/* Synchronous device -> host copy that reaches the pinned PCIe rate into PAGEABLE memory (a NumPy array): 32 MiB chunks through
+ * pinned staging buffers, the pageable copies spread over host threads (a plain copy runs at ~12 GB/s on this host).  Returns
+ * when h_dst holds the data; everything enqueued on the ctx stream before it has completed by then. */
+int r3d_download(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
 /* Pinned (page-locked) host memory.  The *_host entry points detect pinned buffers and DMA straight from/to them;
  * pageable buffers go through the library's own pinned staging ring with multi-threaded copies. */
