@@ -34,7 +34,7 @@ struct r3d_nn_index {
   int64_t capacity = 0;  // target points the allocations can hold (r3d_nn_index_rebuild reuses them)
   int64_t n_tiles = 0;
   int idx_bits = 1, axis_bits = 16;
-  float* d_tgt = nullptr;      // [n][3] original order (fallback scan)
+  float* d_tgt = nullptr;      // [n][3] original order (tie winners of other groups, pair sums, the plane kernels' gathers)
   float4* d_tgt4 = nullptr;    // [n_tiles*1024] sorted, w = original index bits; padding has x = +inf
   float* d_tile_box = nullptr; // [n_tiles][6] lo xyz, hi xyz
   float* d_sub_box = nullptr;  // [n_tiles*4][6] boxes of the 256-target quarters of every tile

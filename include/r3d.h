@@ -199,7 +199,7 @@ int r3d_apply_T_many(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n
  * r3d_icp_nn: for each source point the index of the nearest target point under squared L2
  * computed in fp32 as d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx)) with dx = sx-tx, dy = sy-ty, dz = sz-tz (one rounding
  * for dx*dx, one per fused multiply-add; no other contraction), lowest index wins exact ties.  This expression IS
- * the specification: brute force, culled index, fallback and oracle all evaluate exactly it.
+ * the specification: brute force, culled index and oracle all evaluate exactly it.
  * Non-finite input: a pair whose d2 is NaN or +inf never wins; a source with no finite d2 at all (it, or every target,
  * has a NaN / inf coordinate) gets index 0 and d2 = +inf; the pair sums leave rows with non-finite coordinates out.
  * src/tgt are float32 xyz AoS.  d_idx_out [n_src] uint32, d_d2_out [n_src] float32 (may be NULL). */
@@ -210,7 +210,8 @@ int r3d_icp_nn_host(r3d_ctx* ctx, const float* h_src, int64_t n_src, const float
 /* The same answer as r3d_icp_nn with spatial culling: the target cloud is Morton-sorted once into 1024-point tiles
  * with bounding boxes; a query sorts its sources the same way and sweeps only tiles whose box can still hold a
  * closer point.  Exactness is kept: identical fp32 distance expression, lowest original target index on ties
- * (cross-tile ties go through an exact fallback).  create synchronises; query is asynchronous on the ctx stream
+ * (a source that meets its minimum again in another group of targets looks through that group on the spot).  create and query
+ * are asynchronous on the ctx stream
  * unless h_tiles_swept != NULL (then it synchronises and reports how many tile sweeps all workgroups did). */
 typedef struct r3d_nn_index r3d_nn_index;
 int r3d_nn_index_create(r3d_ctx* ctx, const float* d_tgt, int64_t n_tgt, r3d_nn_index** index_out);
