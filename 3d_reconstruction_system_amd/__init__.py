@@ -13,7 +13,8 @@ from ._lib import (R3DError, R3DLibraryMissing, LIB_PATH, load as load_library, 
                    DEPTH_U8, DEPTH_U16, DEPTH_F32, F32, F64)
 from .device import Context, Camera, DeviceBuffer, default_context  # noqa: F401
 from .fusion import (REF_INTRINSICS, unproject, fuse_frames, fuse_frames_rgb, se3_apply, apply_T,  # noqa: F401
-                     unproject_device, fuse_frames_device, fuse_frames_rgb_device, apply_T_device)
+                     unproject_device, fuse_frames_device, fuse_frames_rgb_device, fuse_frames_voxel_device,
+                     apply_T_device)
 from .poses import (scipy_transfer, get_r, pose_table, pose_to_T, read_pose_file, get_T, write_T,  # noqa: F401
                     str_tofloat)
 from . import cloud_io  # noqa: F401

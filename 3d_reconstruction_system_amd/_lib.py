@@ -125,6 +125,7 @@ SIGNATURES = {
     "r3d_voxelset_clear": (_i, [_vp]),
     "r3d_voxelset_insert": (_i, [_vp, _vp, _i64]),
     "r3d_voxelset_insert_host": (_i, [_vp, _vp, _i64]),
+    "r3d_fuse_frames_voxel": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "r3d_voxelset_insert_codes": (_i, [_vp, _vp, _i64]),
     "r3d_voxelset_union": (_i, [_vp, _vp]),
     "r3d_voxelset_stats": (_i, [_vp, _vp, _vp, _vp]),

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void apply_lane_kernel(const ApplyArgs a)
           d[2] = p[2] - T[11];
         }
         const f32x3 w = {(float)out_row<SE3>(T, 0, p, d), (float)out_row<SE3>(T, 1, p, d), (float)out_row<SE3>(T, 2, p, d)};
-        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + i * 3), "v"(w) : "memory");
+        asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + i * 3), "v"(w) : "memory");
       }
     }
   }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void apply_pair_kernel(const ApplyArgs a)
         const uint32_t alo = (uint32_t)__double2loint(a_), ahi = (uint32_t)__double2hiint(a_);
         const uint32_t blo = (uint32_t)__double2loint(b_), bhi = (uint32_t)__double2hiint(b_);
         const u32x3 val = odd ? u32x3{ahi, blo, bhi} : u32x3{alo, ahi, blo};
-        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + p0 * 6 + (uint64_t)q * 3), "v"(val) : "memory");
+        asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + p0 * 6 + (uint64_t)q * 3), "v"(val) : "memory");
       }
     }
   }

@@ -30,10 +30,12 @@
 //         pixel leaves one nontemporal dword (r | g<<8 | b<<16, alpha 0).  7.1-7.3 TB/s = 0.89-0.91 of peak at
 //         20 B/point when the inputs sit in the 256 MiB Infinity Cache between launches (C2), 5.3-6.0 TB/s when
 //         depth + colour really stream from HBM (config 5: 1080p f32 depth, 23 B/point).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 #include "r3d_internal.h"
+#include "r3d_voxel_dev.h"
 
 namespace {
 
@@ -98,12 +100,16 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
-// one global_store_dwordx3 with the nontemporal hint (4-byte alignment suffices on gfx950)
+// one global_store_dwordx3 with the nontemporal hint (4-byte alignment suffices on gfx950).
+// The s_nop is part of the store: a VMEM store of more than 64 bits reads its data registers up to two cycles after issue
+// and a VALU write to them in that window lands in the stored value (gfx940+ hazard; the compiler pads its own stores, it
+// cannot see into an asm).  Found in round 3 when fuse_voxel_kernel's key arithmetic reused the registers right behind the
+// store: lanes 12-15 of every row stored halves of the next doubles.  Every dwordx3 asm store in the library carries it.
 __device__ __forceinline__ void store_x3_nt(void* dst, f32x3 v) {
-  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_x3_nt(void* dst, u32x3 v) {
-  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 
 // ---- f32 xyz: lane-per-pixel rounds ----------------------------------------------------------------------------
@@ -307,6 +313,142 @@ __global__ __launch_bounds__(kThreads) void fuse_rgb_kernel(const DT* __restrict
   }
 }
 
+// ---- f32 xyz (+ colour) AND the occupied-voxel set in one pass ---------------------------------------------------
+// Config 5 builds the cloud and the voxel map of the same points: fuse_rgb_kernel writes 16 B/point, voxel_insert_kernel
+// reads 12 of them back.  This kernel is fuse_rgb_kernel's body with voxel_insert_kernel<true>'s per-point work appended
+// while the world point is still in registers: the key comes from the SAME three floats the store writes (so the set equals
+// the one r3d_voxelset_insert builds from the cloud, bit for bit), neighbour-lane filter, claim in the workgroup's LDS set,
+// the set flushed to the global table by all lanes when it holds kLdsKeepBelow codes and at the end of the run.  A workgroup
+// walks a CONTIGUOUS run of tiles (neighbouring rows hit the same voxels); the cloud is not read back.
+constexpr uint64_t kVoxelRun = 64;  // tiles per workgroup of fuse_voxel_kernel on big batches
+
+struct VoxelView {
+  uint64_t* table;
+  unsigned long long* counters;
+  double factor;
+  int log2cap;
+};
+
+template <typename DT, bool POSE, bool RGB>
+__global__ __launch_bounds__(kThreads) void fuse_voxel_kernel(const DT* __restrict__ depth, const uint8_t* __restrict__ rgb,
+                                                              float* __restrict__ out, uint32_t* __restrict__ rgba_out,
+                                                              const double* __restrict__ u, const double* __restrict__ v,
+                                                              const double* __restrict__ pose, const FuseDims dm,
+                                                              const VoxelView vv) {
+  using namespace r3d_vox;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[RGB ? kTile * 3 : 16];
+  __shared__ unsigned long long local_set[kLdsSlots];
+  __shared__ unsigned local_fill[3];  // codes gained per tile, in rotation (see voxel_insert_kernel)
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63;
+  const uint64_t mask = ((uint64_t)1 << vv.log2cap) - 1;
+  unsigned n_new = 0, n_ignored = 0, n_over = 0;
+  const uint32_t per_wg = (dm.total_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo64 = (uint64_t)blockIdx.x * per_wg;
+  const uint32_t tile_lo = lo64 < dm.total_tiles ? (uint32_t)lo64 : dm.total_tiles;
+  const uint32_t tile_hi = dm.total_tiles - tile_lo < per_wg ? dm.total_tiles : tile_lo + per_wg;
+  for (int k = tid; k < kLdsSlots; k += kThreads) local_set[k] = kEmpty;
+  if (tid < 3) local_fill[tid] = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < kLdsSlots / kThreads; ++k) {
+      const int s = k * kThreads + tid;
+      const uint64_t code = local_set[s];
+      if (code != kEmpty) {
+        local_set[s] = kEmpty;
+        const int r = table_insert(vv.table, mask, vv.log2cap, code);
+        n_new += r > 0 ? 1u : 0u;
+        n_over += r < 0 ? 1u : 0u;
+      }
+    }
+  };
+  unsigned total = 0, j = 0;
+  for (uint32_t tile = tile_lo; tile < tile_hi; ++tile, ++j) {
+    // the previous tile's lookups, its count and its colour reads are done (first tile: the wipe above has landed)
+    lds_settle();
+    __syncthreads();
+    if (j > 0) total += local_fill[(j - 1) % 3];
+    if (tid == 0) local_fill[(j + 1) % 3] = 0;
+    // No barrier of its own: the one in front of the tile's claims (below) is taken by every wave on every tile, whatever
+    // `total` says -- a wave that flushed its slots while another did not leaves every code in the set or in the table.
+    if (total >= (unsigned)kLdsKeepBelow) {
+      flush();
+      total = 0;
+    }
+    const uint32_t frame = magic_div(tile, dm.t_magic, dm.t_shift);
+    const uint32_t tf = tile - frame * dm.tiles_per_frame;
+    Pose P;
+    load_pose<POSE>(pose, frame, P);
+    const uint64_t fbase = (uint64_t)frame * dm.hw;
+    const bool staged = RGB && dm.rgb_vec_ok && (tf + 1) * kTile <= dm.hw;
+    DT raw[kPx];
+    load_tile<DT, kPx, 0, true>(depth, dm, tile, tid, raw);
+    if (RGB && staged && tid < kTile * 3 / 16)
+      reinterpret_cast<u32x4*>(lds)[tid] = reinterpret_cast<const u32x4*>(rgb + (fbase + (uint64_t)tf * kTile) * 3)[tid];
+    lds_settle();
+    __syncthreads();  // the tile's colour bytes are in LDS; nobody is flushing any more
+    unsigned claimed = 0;
+#pragma unroll
+    for (int r = 0; r < kPx; ++r) {
+      const uint32_t l = r * kThreads + tid;
+      const uint32_t p = tf * kTile + l;
+      uint64_t code = kEmpty;
+      bool live = p < dm.hw;
+      if (live) {
+        const uint32_t jrow = magic_div(p, dm.w_magic, dm.w_shift);
+        const uint32_t i = p - jrow * dm.width;
+        double w[3];
+        point<POSE>((double)raw[r] * dm.scale, u[i], v[jrow], P, w);
+        const float fx = (float)w[0], fy = (float)w[1], fz = (float)w[2];
+        store_x3_nt(out + (fbase + p) * 3, f32x3{fx, fy, fz});
+        if (RGB) {
+          uint32_t c;
+          if (staged) {
+            c = (uint32_t)lds[l * 3] | ((uint32_t)lds[l * 3 + 1] << 8) | ((uint32_t)lds[l * 3 + 2] << 16);
+          } else {
+            const uint8_t* sp = rgb + (fbase + p) * 3;
+            c = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16);
+          }
+          __builtin_nontemporal_store(c, rgba_out + fbase + p);
+        }
+        if (!voxel_code(fx, fy, fz, vv.factor, &code)) {
+          ++n_ignored;
+          live = false;
+          code = kEmpty;
+        }
+      }
+      const uint64_t prev = prev_lane_u64(code);
+      if (live && lane > 0 && prev == code) live = false;
+      if (live) {
+        bool mine = false;
+        const bool done = lds_set_claim(local_set, code, &mine);
+        claimed += mine ? 1u : 0u;
+        if (!done) {
+          const int r2 = table_insert(vv.table, mask, vv.log2cap, code);
+          n_new += r2 > 0 ? 1u : 0u;
+          n_over += r2 < 0 ? 1u : 0u;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) claimed += __shfl_down(claimed, off, 64);
+    if (lane == 0 && claimed) atomicAdd(&local_fill[j % 3], claimed);
+  }
+  __syncthreads();
+  flush();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_ignored += __shfl_down(n_ignored, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  if (lane == 0) {
+    if (n_new) atomicAdd(&vv.counters[0], (unsigned long long)n_new);
+    if (n_ignored) atomicAdd(&vv.counters[1], (unsigned long long)n_ignored);
+    if (n_over) atomicAdd(&vv.counters[2], (unsigned long long)n_over);
+  }
+}
+
 // colour only: [n][3] uint8 -> [n] rgba dwords, for clouds whose xyz was made elsewhere (f64 xyz path)
 __global__ __launch_bounds__(kThreads) void rgb_expand_kernel(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgba_out,
                                                               uint64_t n, uint32_t vec_ok) {
@@ -416,6 +558,30 @@ void launch_depth(const FusePtrs& p, const FuseDims& dm, int depth_dtype, int ou
   }
 }
 
+template <typename DT>
+void launch_voxel_typed(const FusePtrs& p, const FuseDims& dm, const VoxelView& vv, bool with_pose, int blocks, hipStream_t s) {
+  const DT* d = static_cast<const DT*>(p.depth);
+  float* o = static_cast<float*>(p.out);
+#define R3D_LAUNCH_FV(POSE, RGB)                                                                                         \
+  hipLaunchKernelGGL((fuse_voxel_kernel<DT, POSE, RGB>), dim3(blocks), dim3(kThreads), 0, s, d, p.rgb, o, p.rgba, p.u, p.v, \
+                     p.pose, dm, vv)
+  if (with_pose) {
+    if (p.rgb) R3D_LAUNCH_FV(true, true); else R3D_LAUNCH_FV(true, false);
+  } else {
+    if (p.rgb) R3D_LAUNCH_FV(false, true); else R3D_LAUNCH_FV(false, false);
+  }
+#undef R3D_LAUNCH_FV
+}
+
+void launch_voxel(const FusePtrs& p, const FuseDims& dm, const VoxelView& vv, int depth_dtype, bool with_pose, int blocks,
+                  hipStream_t s) {
+  switch (depth_dtype) {
+    case R3D_DEPTH_U8: launch_voxel_typed<uint8_t>(p, dm, vv, with_pose, blocks, s); break;
+    case R3D_DEPTH_U16: launch_voxel_typed<uint16_t>(p, dm, vv, with_pose, blocks, s); break;
+    default: launch_voxel_typed<float>(p, dm, vv, with_pose, blocks, s); break;
+  }
+}
+
 // Magic number for floor(x / d), exact for every x < 2^31 and d >= 1 (round-up method):
 //   s = ceil(log2 d), m = floor(2^(31+s) / d) + 1 (< 2^32), x / d = (x * m) >> (31 + s).
 // m*d - 2^(31+s) lies in (0, d] <= 2^s, which is the exactness condition for 31-bit x.
@@ -428,10 +594,17 @@ void make_magic(uint32_t d, uint32_t* magic, uint32_t* shift) {
 
 int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
                 double depth_scale, const double* d_pose, bool with_pose, void* d_out, int out_dtype,
-                const uint8_t* d_rgb = nullptr, uint32_t* d_rgba = nullptr) {
+                const uint8_t* d_rgb = nullptr, uint32_t* d_rgba = nullptr, r3d_voxelset* vs = nullptr) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(cam != nullptr, "camera is NULL");
+  VoxelView vv{nullptr, nullptr, 0.0, 0};
+  if (vs) {
+    r3d_ctx* vctx = nullptr;
+    if ((rc = r3d_voxelset_device_view(vs, &vctx, &vv.factor, &vv.table, &vv.log2cap, &vv.counters))) return rc;
+    R3D_REQUIRE(vctx == ctx, "voxel set belongs to a different ctx");
+    R3D_REQUIRE(out_dtype == R3D_F32, "the voxel keys are taken from the f32 cloud: out_dtype must be R3D_F32");
+  }
   R3D_REQUIRE(cam->ctx == ctx, "camera belongs to a different ctx");
   R3D_REQUIRE(depth_dtype >= R3D_DEPTH_U8 && depth_dtype <= R3D_DEPTH_F32, "unknown depth dtype %d", depth_dtype);
   R3D_REQUIRE(out_dtype == R3D_F32 || out_dtype == R3D_F64, "unknown output dtype %d", out_dtype);
@@ -494,7 +667,14 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
     const bool stride8 = !wave && !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
     uint64_t blocks = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks : stride8 ? (uint64_t)ctx->num_cus * 8 : total_tiles;
     if (blocks > total_tiles) blocks = total_tiles;
-    if (with_pose)
+    if (vs) {
+      // contiguous runs of tiles per workgroup: fuse_blocks > 0 sets the grid, else runs of kVoxelRun tiles but no fewer than
+      // 8 workgroups per CU (measured on 2000 x 1080p frames: 8/CU 36.1 ms, 4096 workgroups 30.9, 16384 28.0, 65536 27.2)
+      uint64_t g = ctx->fuse_blocks > 0 ? (uint64_t)ctx->fuse_blocks
+                                         : std::max<uint64_t>((uint64_t)ctx->num_cus * 8, (total_tiles + kVoxelRun - 1) / kVoxelRun);
+      if (g > total_tiles) g = total_tiles;
+      launch_voxel(p, dm, vv, depth_dtype, with_pose, (int)g, ctx->stream);
+    } else if (with_pose)
       launch_depth<true>(p, dm, depth_dtype, out_dtype, (int)blocks, wave, ctx->stream);
     else
       launch_depth<false>(p, dm, depth_dtype, out_dtype, (int)blocks, wave, ctx->stream);
@@ -630,6 +810,15 @@ int r3d_fuse_frames_rgb(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth
   R3D_REQUIRE(n_frames == 0 || (d_rgb && d_rgba_out), "colour plane / rgba output is NULL");
   return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, d_pose, d_pose != nullptr, d_xyz_out, out_dtype,
                      d_rgb, d_rgba_out);
+}
+
+int r3d_fuse_frames_voxel(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
+                          double depth_scale, const double* d_pose, const unsigned char* d_rgb, float* d_xyz_out,
+                          uint32_t* d_rgba_out, r3d_voxelset* vs) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  R3D_REQUIRE((d_rgb == nullptr) == (d_rgba_out == nullptr), "colour needs both the rgb plane and the rgba output");
+  return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, d_pose, d_pose != nullptr, d_xyz_out, R3D_F32,
+                     d_rgb, d_rgba_out, vs);
 }
 
 int r3d_fuse_frames_rgb_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,

@@ -95,6 +95,10 @@ struct r3d_pipe_buf {
 int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* ins, int n_in, const r3d_pipe_buf* outs,
                             int n_out, const std::function<int(int64_t, int64_t)>& launch);
 
+// r3d_voxel.hip: what a kernel outside that file needs to insert into a voxel set (r3d_fuse.hip's fused RGBD + voxel launch)
+int r3d_voxelset_device_view(r3d_voxelset* vs, r3d_ctx** ctx, double* factor, uint64_t** d_table, int* log2cap,
+                             unsigned long long** d_counters);
+
 // Device -> pageable host memory through pinned staging chunks (r3d_hostpipe.hip); synchronous.
 int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 

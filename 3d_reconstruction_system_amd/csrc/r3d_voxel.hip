@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "r3d_internal.h"
+#include "r3d_voxel_dev.h"
 
 struct r3d_voxelset {
   r3d_ctx* ctx = nullptr;
@@ -38,64 +39,16 @@ struct r3d_voxelset {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr uint64_t kEmpty = ~0ull;
-constexpr int kTreeMaxVal = 32768;
+using r3d_vox::kEmpty;
+using r3d_vox::kLdsKeepBelow;
+using r3d_vox::kLdsSlots;
+using r3d_vox::lds_set_claim;
+using r3d_vox::prev_lane_u64;
+using r3d_vox::table_insert;
 
 struct __attribute__((packed, aligned(4))) P3 {
   float x, y, z;
 };
-
-// 8 bits -> every third bit of 24, in 32-bit registers (the 64-bit spread costs two instructions per step)
-__device__ __forceinline__ uint32_t spread3_byte(uint32_t x) {
-  x = (x | (x << 8)) & 0x0000f00fu;
-  x = (x | (x << 4)) & 0x000c30c3u;
-  x = (x | (x << 2)) & 0x00249249u;
-  return x;
-}
-
-// 48-bit Morton code of three 16-bit keys (x lowest): low bytes -> bits 0..23, high bytes -> bits 24..47
-__device__ __forceinline__ uint64_t morton48(uint32_t ix, uint32_t iy, uint32_t iz) {
-  const uint32_t lo = spread3_byte(ix & 0xffu) | (spread3_byte(iy & 0xffu) << 1) | (spread3_byte(iz & 0xffu) << 2);
-  const uint32_t hi = spread3_byte(ix >> 8) | (spread3_byte(iy >> 8) << 1) | (spread3_byte(iz >> 8) << 2);
-  return (uint64_t)lo | ((uint64_t)hi << 24);
-}
-
-// Keys in fp64 exactly as OcTreeBaseImpl::coordToKey computes them.  (An exact fp32 formulation -- t = round(x f), r = fma(x, f,
-// -t), floor(t) corrected when t is an integer and r < 0; valid when 1/res is exactly a float -- passed every face / ulp /
-// denormal test in round 3 and was 4 % SLOWER on the scan benchmark: the kernel does not wait for its ALUs.  Not shipped.)
-__device__ __forceinline__ bool voxel_code(const P3& p, double factor, uint64_t* code) {
-  const double dx = floor(factor * (double)p.x), dy = floor(factor * (double)p.y), dz = floor(factor * (double)p.z);
-  // rejects NaN/inf and anything outside the 2^16 key range
-  const bool ok = dx >= -(double)kTreeMaxVal && dx < (double)kTreeMaxVal && dy >= -(double)kTreeMaxVal &&
-                  dy < (double)kTreeMaxVal && dz >= -(double)kTreeMaxVal && dz < (double)kTreeMaxVal;
-  if (!ok) return false;
-  *code = morton48((uint32_t)((int)dx + kTreeMaxVal), (uint32_t)((int)dy + kTreeMaxVal), (uint32_t)((int)dz + kTreeMaxVal));
-  return true;
-}
-
-// the value the previous lane of the wave holds (lane 0: its own), by DPP wave_shr:1 -- one VALU move per 32 bits instead of a
-// ds_bpermute round trip through the LDS crossbar (__shfl_up compiles to two of those for a 64-bit value)
-__device__ __forceinline__ uint64_t prev_lane_u64(uint64_t v) {
-  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
-  return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
-}
-
-constexpr int kLdsSlots = 2048;     // per-workgroup dedupe table (16 KB)
-constexpr int kLdsKeepBelow = 512;   // it survives from tile to tile while it holds fewer codes than this (then <= 75 % full)
-
-// One code into the global open-addressing table (64-bit CAS, linear probing).  Returns 1 new, 0 already there, -1 no slot.
-__device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64_t mask, int log2cap, uint64_t code) {
-  uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
-  for (uint64_t probe = 0; probe <= mask; ++probe) {
-    const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
-                                   (unsigned long long)code);
-    if (old == kEmpty) return 1;
-    if (old == code) return 0;
-    slot = (slot + 1) & mask;
-  }
-  return -1;
-}
 
 // DEDUPE: a workgroup funnels its codes through a small LDS hash set and walks a CONTIGUOUS run of tiles (neighbouring
 // image rows fall into the SAME voxels), keeping the set from tile to tile.  Round 2 sent every newly claimed code to the
@@ -105,7 +58,7 @@ __device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64
 // flushed to the global table as a whole, all 256 lanes inserting in parallel, when it has collected kLdsKeepBelow codes and
 // at the end of the run: the round trips are paid once per ~512 codes instead of once per tile.  A code that finds the set full
 // (cannot happen below 75 % load) goes to the global table directly.
-template <bool DEDUPE>
+template <bool DEDUPE, bool COND_BARRIER = false>
 __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __restrict__ xyz, int64_t n, double factor,
                                                                 uint64_t* __restrict__ table, int log2cap,
                                                                 unsigned long long* __restrict__ counters) {
@@ -151,12 +104,22 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
   }
   for (int64_t tile = tile_lo; tile < tile_hi; ++tile, ++j) {
     if (DEDUPE) {
+      r3d_vox::lds_settle();
       __syncthreads();  // the previous tile's lookups and its count are done (first tile: the wipe above has landed)
       if (j > 0) total += local_fill[(j - 1) % 3];
       if (threadIdx.x == 0) local_fill[(j + 1) % 3] = 0;
-      if (total >= (unsigned)kLdsKeepBelow) {  // workgroup-uniform
-        flush();
-        total = 0;
+      if (COND_BARRIER) {
+        if (total >= (unsigned)kLdsKeepBelow) {  // workgroup-uniform
+          flush();
+          total = 0;
+          __syncthreads();
+        }
+      } else {
+        if (total >= (unsigned)kLdsKeepBelow) {
+          flush();
+          total = 0;
+        }
+        r3d_vox::lds_settle();
         __syncthreads();
       }
     }
@@ -180,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       const int64_t i = base + (int64_t)r * kThreads;
       uint64_t code = kEmpty;
       bool live = i < n;
-      if (live && !voxel_code(p[r], factor, &code)) {
+      if (live && !r3d_vox::voxel_code(p[r].x, p[r].y, p[r].z, factor, &code)) {
         ++n_ignored;
         live = false;
         code = kEmpty;
@@ -190,22 +153,8 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       const uint64_t prev = prev_lane_u64(code);
       if (live && lane > 0 && prev == code) live = false;
       if (DEDUPE && live) {
-        uint32_t slot = (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
-        bool mine = false, done = false;
-        // most codes of a scan are already in the set (the previous rows put them there): a plain LDS read settles those
-        // without a compare-and-swap
-        if (local_set[slot] == code) done = true;
-        for (int probe = 0; probe < kLdsSlots && !done; ++probe) {
-          const unsigned long long old = atomicCAS(&local_set[slot], (unsigned long long)kEmpty, (unsigned long long)code);
-          if (old == kEmpty) {
-            mine = true;
-            done = true;
-          } else if (old == code) {
-            done = true;  // already in the set: it reaches the global table with the next flush
-          } else {
-            slot = (slot + 1) & (kLdsSlots - 1);
-          }
-        }
+        bool mine = false;
+        const bool done = lds_set_claim(local_set, code, &mine);
         claimed += mine ? 1u : 0u;
         live = !done;  // a full set (cannot happen: < 512 + 1024 codes in 2048 slots) sends the code on directly
       }
@@ -501,6 +450,18 @@ int build_bt(const uint64_t* codes, int64_t n, double res, std::string* out, int
 
 }  // namespace
 
+int r3d_voxelset_device_view(r3d_voxelset* vs, r3d_ctx** ctx, double* factor, uint64_t** d_table, int* log2cap,
+                             unsigned long long** d_counters) {
+  R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
+  *ctx = vs->ctx;
+  *factor = vs->factor;
+  *d_table = vs->d_table;
+  *log2cap = vs->log2cap;
+  *d_counters = vs->d_counters;
+  return R3D_OK;
+}
+
+
 extern "C" {
 
 int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_voxelset** vs_out) {
@@ -563,7 +524,10 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
   int blocks = vs->ctx->num_cus * 8;
   if ((int64_t)blocks > n_tiles) blocks = (int)n_tiles;
-  if (vs->ctx->voxel_dedupe != 1)  // 0 auto / 2 on: LDS dedupe; 1: off
+  if (vs->ctx->voxel_dedupe == 3)
+    hipLaunchKernelGGL((voxel_insert_kernel<true, true>), dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, d_xyz, n_points,
+                       vs->factor, vs->d_table, vs->log2cap, vs->d_counters);
+  else if (vs->ctx->voxel_dedupe != 1)  // 0 auto / 2 on: LDS dedupe; 1: off
     hipLaunchKernelGGL(voxel_insert_kernel<true>, dim3(blocks), dim3(kThreads), 0, vs->ctx->stream, d_xyz, n_points,
                        vs->factor, vs->d_table, vs->log2cap, vs->d_counters);
   else

@@ -1,0 +1,99 @@
+// Device-side pieces of the occupied-voxel set shared by r3d_voxel.hip (insert from a cloud in HBM) and r3d_fuse.hip (insert
+// straight from the fused launch's registers): OctoMap's key arithmetic, the 48-bit Morton code, the global open-addressing
+// table, the neighbour-lane test.  See r3d_voxel.hip for the semantics and their sources.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace r3d_vox {
+
+constexpr uint64_t kEmpty = ~0ull;
+constexpr int kTreeMaxVal = 32768;
+constexpr int kLdsSlots = 2048;      // per-workgroup dedupe table (16 KB)
+constexpr int kLdsKeepBelow = 512;   // it is flushed to the global table once it holds this many codes (then <= 75 % full)
+
+// 8 bits -> every third bit of 24, in 32-bit registers (the 64-bit spread costs two instructions per step)
+__device__ __forceinline__ uint32_t spread3_byte(uint32_t x) {
+  x = (x | (x << 8)) & 0x0000f00fu;
+  x = (x | (x << 4)) & 0x000c30c3u;
+  x = (x | (x << 2)) & 0x00249249u;
+  return x;
+}
+
+// 48-bit Morton code of three 16-bit keys (x lowest): low bytes -> bits 0..23, high bytes -> bits 24..47
+__device__ __forceinline__ uint64_t morton48(uint32_t ix, uint32_t iy, uint32_t iz) {
+  const uint32_t lo = spread3_byte(ix & 0xffu) | (spread3_byte(iy & 0xffu) << 1) | (spread3_byte(iz & 0xffu) << 2);
+  const uint32_t hi = spread3_byte(ix >> 8) | (spread3_byte(iy >> 8) << 1) | (spread3_byte(iz >> 8) << 2);
+  return (uint64_t)lo | ((uint64_t)hi << 24);
+}
+
+// Keys in fp64 exactly as OcTreeBaseImpl::coordToKey computes them from FLOAT coordinates.  (An exact fp32 formulation -- t =
+// round(x f), r = fma(x, f, -t), floor(t) corrected when t is an integer and r < 0; valid when 1/res is exactly a float --
+// passed every face / ulp / denormal test in round 3 and was 4 % SLOWER on the scan benchmark: the kernel does not wait for
+// its ALUs.  Not shipped.)
+__device__ __forceinline__ bool voxel_code(float x, float y, float z, double factor, uint64_t* code) {
+  const double dx = floor(factor * (double)x), dy = floor(factor * (double)y), dz = floor(factor * (double)z);
+  // rejects NaN/inf and anything outside the 2^16 key range
+  const bool ok = dx >= -(double)kTreeMaxVal && dx < (double)kTreeMaxVal && dy >= -(double)kTreeMaxVal &&
+                  dy < (double)kTreeMaxVal && dz >= -(double)kTreeMaxVal && dz < (double)kTreeMaxVal;
+  if (!ok) return false;
+  *code = morton48((uint32_t)((int)dx + kTreeMaxVal), (uint32_t)((int)dy + kTreeMaxVal), (uint32_t)((int)dz + kTreeMaxVal));
+  return true;
+}
+
+// the value the previous lane of the wave holds (lane 0: its own), by DPP wave_shr:1 -- one VALU move per 32 bits instead of a
+// ds_bpermute round trip through the LDS crossbar (__shfl_up compiles to two of those for a 64-bit value)
+__device__ __forceinline__ uint64_t prev_lane_u64(uint64_t v) {
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+}
+
+// Every LDS operation of this wave has been performed.  To be called in front of a __syncthreads() that a result-less LDS
+// atomic (ds_add_u32 ...) can reach along a loop's back edge: hipcc (ROCm 7.2, gfx950) leaves the s_waitcnt of the barrier's
+// release fence out on that path, the add may still sit in its SIMD's LDS queue when another wave's read behind the barrier
+// is served, the waves then disagree about a count that has to be workgroup-uniform and take different numbers of barriers.
+// Seen in round 3 (fuse_voxel_kernel: wrong colour words and lost codes at 20 M points; voxel_insert_kernel had the same
+// hole in its ISA without ever failing a test).  tools/isa_barrier_check.py scans the compiled kernels for the pattern.
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One code into the global open-addressing table (64-bit CAS, linear probing).  Returns 1 new, 0 already there, -1 no slot.
+__device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64_t mask, int log2cap, uint64_t code) {
+  uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+  for (uint64_t probe = 0; probe <= mask; ++probe) {
+    const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
+                                   (unsigned long long)code);
+    if (old == kEmpty) return 1;
+    if (old == code) return 0;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+// One code into a workgroup's LDS set.  *mine: this lane put it there; returns false only when the set is full (the caller
+// then sends the code to the global table directly).  The shape of this loop matters: one exit, a `done` flag -- the same
+// logic written with early returns compiled to a 13 % slower insert kernel (214 -> 186 Gpoints/s on the scan benchmark).
+__device__ __forceinline__ bool lds_set_claim(unsigned long long* local_set, uint64_t code, bool* mine_out) {
+  uint32_t slot = (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
+  bool mine = false, done = false;
+  // most codes of a scan are already in the set (the previous rows put them there): a plain LDS read settles those
+  // without a compare-and-swap
+  if (local_set[slot] == code) done = true;
+  for (int probe = 0; probe < kLdsSlots && !done; ++probe) {
+    const unsigned long long old = atomicCAS(&local_set[slot], (unsigned long long)kEmpty, (unsigned long long)code);
+    if (old == kEmpty) {
+      mine = true;
+      done = true;
+    } else if (old == code) {
+      done = true;  // already in the set: it reaches the global table with the next flush
+    } else {
+      slot = (slot + 1) & (kLdsSlots - 1);
+    }
+  }
+  *mine_out = mine;
+  return done;
+}
+
+}  // namespace r3d_vox

@@ -150,6 +150,13 @@ def fuse_frames_rgb_device(ctx, cam, d_depth, depth_dtype, n_frames, d_pose, d_r
                                         float(depth_scale), d_pose, d_rgb, d_out, xyz_code(out_dtype), d_rgba))
 
 
+def fuse_frames_voxel_device(ctx, cam, d_depth, depth_dtype, n_frames, d_pose, d_rgb, d_out, d_rgba, voxel_set, depth_scale=1.0):
+    """The f32 cloud (d_rgb / d_rgba None = no colour; d_pose None = camera frame) AND its occupied voxels into `voxel_set`
+    (voxelmap.VoxelSet) in one launch: r3d_fuse_frames_rgb + r3d_voxelset_insert without reading the cloud back."""
+    L.check(ctx.lib.r3d_fuse_frames_voxel(ctx.handle, cam.handle, d_depth, depth_code(depth_dtype), int(n_frames),
+                                          float(depth_scale), d_pose, d_rgb, d_out, d_rgba, voxel_set.handle))
+
+
 def apply_T_device(ctx, d_in, in_dtype, n_points, T, d_out, out_dtype):
     T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4))
     L.check(ctx.lib.r3d_apply_T(ctx.handle, d_in, xyz_code(in_dtype), int(n_points), T.ctypes.data, d_out,

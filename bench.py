@@ -394,9 +394,17 @@ def secondary(a):
         def both():
             vs.clear()
             vs.insert_device(d_xyz.ptr, n)
-        ms_v = timed(both, 5) - timed(vs.clear, 5)
+        ms_clear = timed(vs.clear, 5)
+        ms_v = timed(both, 5) - ms_clear
         both()
         st_all = vs.stats()
+
+        def one_launch():   # the cloud and the map from one kernel (r3d_fuse_frames_voxel): the cloud is not read back
+            vs.clear()
+            r3d.fuse_frames_voxel_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, d_rgba.ptr, vs)
+        ms_one = timed(one_launch, 5) - ms_clear
+        one_launch()
+        st_one = vs.stats()
         # a checkable digest of the map's voxel half: the occupied set of the first k frames' cloud (the test suite forms the
         # same set with the oracle and compares count, ignored points and two order-independent digests of the codes)
         k_chk = min(F, 3)
@@ -413,6 +421,8 @@ def secondary(a):
         line = {"metric": "Mpoints/s fused RGBD (1920x1080 f32 depth + RGB -> f32 xyz + rgba), %d frames" % F,
                 "value": round(n / ms / 1e3, 1), "unit": "Mpoints/s", "voxel_insert_ms": round(ms_v, 3),
                 "fuse_plus_voxel_Mpoints_s": round(n / (ms + ms_v) / 1e3, 1), "voxels": st_all["voxels"],
+                "one_launch_cloud_and_voxels": {"ms": round(ms_one, 3), "Mpoints_s": round(n / ms_one / 1e3, 1),
+                                                "same_counters_as_two_calls": st_one == st_all},
                 "voxel_check": voxel_check,
                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "fuse_rgb_kernel<f32,pose>",

@@ -432,6 +432,13 @@ int r3d_voxelset_destroy(r3d_voxelset* vs);
 int r3d_voxelset_clear(r3d_voxelset* vs);
 /* insert float32 xyz points (asynchronous on the ctx stream; may be called once per frame batch) */
 int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points);
+/* The cloud AND the map in one launch: r3d_fuse_frames_rgb (f32 xyz; d_pose NULL = camera frame; d_rgb and d_rgba_out both
+ * NULL = no colour) followed by r3d_voxelset_insert of the points it wrote, without reading them back: the keys are taken
+ * from the very floats the store writes.  Same cloud bytes, same set, same counters as the two calls.  (camera_to_world.py
+ * :77-86 feeding txt_transfer_octomap.py:16-26 in the reference.) */
+int r3d_fuse_frames_voxel(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
+                          double depth_scale, const double* d_pose, const unsigned char* d_rgb, float* d_xyz_out,
+                          uint32_t* d_rgba_out, r3d_voxelset* vs);
 int r3d_voxelset_insert_host(r3d_voxelset* vs, const float* h_xyz, int64_t n_points);
 /* synchronises; any pointer may be NULL.  n_ignored = points outside the 2^16 key range or non-finite
  * (OctoMap drops them); n_overflow > 0 means the table was too small and the set is incomplete. */

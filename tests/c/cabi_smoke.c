@@ -118,6 +118,32 @@ int main(void) {
         fprintf(stderr, "colour of point %d wrong\n", k);
         return 1;
       }
+    /* config 5's pair in one launch: the same cloud and colours, and the occupied voxels of exactly that cloud */
+    {
+      r3d_voxelset *two = NULL, *one = NULL;
+      int64_t v2 = 0, i2 = 0, o2 = 0, v1 = 0, i1 = 0, o1 = 0;
+      float first[N * 3], again[N * 3];
+      CK(r3d_voxelset_create(ctx, 0.1, 1 << 12, &two));
+      CK(r3d_voxelset_create(ctx, 0.1, 1 << 12, &one));
+      CK(r3d_memcpy_d2h(ctx, first, d_xyz, N * 12));
+      CK(r3d_voxelset_insert(two, (const float*)d_xyz, N));
+      CK(r3d_memset(ctx, d_xyz, 0, N * 12));
+      CK(r3d_memset(ctx, d_rgba, 0, N * 4));
+      CK(r3d_fuse_frames_voxel(ctx, cam, d_depth, R3D_DEPTH_U8, F, 1.0, (const double*)d_pose, (const unsigned char*)d_rgb, (float*)d_xyz,
+                               (uint32_t*)d_rgba, one));
+      CK(r3d_memcpy_d2h(ctx, again, d_xyz, N * 12));
+      CK(r3d_memcpy_d2h(ctx, rgba, d_rgba, N * 4));
+      CK(r3d_voxelset_stats(two, &v2, &i2, &o2));
+      CK(r3d_voxelset_stats(one, &v1, &i1, &o1));
+      if (memcmp(first, again, sizeof(first)) != 0 || v1 != v2 || i1 != i2 || o1 != o2 || v1 < 1 ||
+          rgba[N - 1] != ((unsigned)rgb[3 * N - 3] | ((unsigned)rgb[3 * N - 2] << 8) | ((unsigned)rgb[3 * N - 1] << 16))) {
+        fprintf(stderr, "one-launch cloud + voxels differs from the two calls (%lld vs %lld voxels)\n", (long long)v1, (long long)v2);
+        return 1;
+      }
+      printf("cloud + map in one launch: %lld voxels, same as the two calls\n", (long long)v1);
+      CK(r3d_voxelset_destroy(two));
+      CK(r3d_voxelset_destroy(one));
+    }
     CK(r3d_dev_free(ctx, d_depth));
     CK(r3d_dev_free(ctx, d_pose));
     CK(r3d_dev_free(ctx, d_rgb));

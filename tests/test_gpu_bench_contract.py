@@ -105,6 +105,8 @@ def test_config5_workload_voxel_half_is_checked_against_the_oracle():
     assert chk["voxels"] == len(want) and chk["ignored_points"] == dropped
     assert chk["codes_xor"] == int(np.bitwise_xor.reduce(want)) and chk["codes_sum_mod_2_64"] == int(np.sum(want, dtype=np.uint64))
     assert d["voxels"] >= chk["voxels"]
+    one = d["one_launch_cloud_and_voxels"]          # r3d_fuse_frames_voxel on the same frames: same three counters
+    assert one["same_counters_as_two_calls"] is True and one["ms"] > 0
 
 
 def test_two_rank_bench_over_the_c_abi_transport(mock_rccl):

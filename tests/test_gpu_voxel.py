@@ -308,3 +308,140 @@ def test_fused_c5_geometry_cloud_to_voxels_matches_oracle(V, ctx, kind):
     if kind == "room":
         assert V.format_bt(want, 0.1)[0] == OM.write_bt_bytes(want, 0.1)[0]
     d_xyz.free()
+
+
+# ---- the cloud AND the map in one launch (r3d_fuse_frames_voxel): same cloud bytes, same rgba words, same set, same counters
+# as r3d_fuse_frames_rgb followed by r3d_voxelset_insert -- and the set equal to the oracle's of that very cloud.
+
+def fused_vs_two_calls(V, ctx, depth, q, t, K, rgb, res, capacity, depth_scale=1.0, oracle=True, overflowing=False):
+    R = _r3d()
+    F, H, W = depth.shape
+    n = F * H * W
+    cam = ctx.camera(H, W, *K)
+    d_depth = ctx.alloc(depth.nbytes).upload(depth)
+    d_pose = None
+    if q is not None:
+        tab = R.pose_table(q, t)
+        d_pose = ctx.alloc(tab.nbytes).upload(tab)
+    d_rgb = ctx.alloc(rgb.nbytes).upload(rgb) if rgb is not None else None
+    bufs = []
+    for fused in (False, True):
+        d_xyz, d_rgba = ctx.alloc(n * 12), (ctx.alloc(n * 4) if rgb is not None else None)
+        L_ = importlib.import_module(PKG + "._lib")
+        L_.check(ctx.lib.r3d_memset(ctx.handle, d_xyz.ptr, 0xa5, n * 12))
+        vs = V.VoxelSet(res, capacity, ctx)
+        pose_ptr = d_pose.ptr if d_pose is not None else None
+        if fused:
+            R.fuse_frames_voxel_device(ctx, cam, d_depth.ptr, depth.dtype.type, F, pose_ptr, d_rgb.ptr if d_rgb else None, d_xyz.ptr,
+                                       d_rgba.ptr if d_rgba else None, vs, depth_scale)
+        else:
+            if rgb is not None:
+                R.fuse_frames_rgb_device(ctx, cam, d_depth.ptr, depth.dtype.type, F, pose_ptr, d_rgb.ptr, d_xyz.ptr, np.float32,
+                                         d_rgba.ptr, depth_scale)
+            elif d_pose is not None:
+                R.fuse_frames_device(ctx, cam, d_depth.ptr, depth.dtype.type, F, pose_ptr, d_xyz.ptr, np.float32, depth_scale)
+            else:
+                R.unproject_device(ctx, cam, d_depth.ptr, depth.dtype.type, F, d_xyz.ptr, np.float32, depth_scale)
+            vs.insert_device(d_xyz.ptr, n)
+        cloud = d_xyz.download(np.uint32, n * 3)
+        words = d_rgba.download(np.uint32, n) if d_rgba else None
+        bufs.append((cloud, words, vs.stats(), None if overflowing else vs.codes()))
+        vs.close()
+        d_xyz.free()
+        if d_rgba:
+            d_rgba.free()
+    (c0, w0, s0, k0), (c1, w1, s1, k1) = bufs
+    np.testing.assert_array_equal(c1, c0)
+    if rgb is not None:
+        np.testing.assert_array_equal(w1, w0)
+    if overflowing:   # which codes found no slot depends on the order of arrival: only the full table and the fact are common
+        assert s1["voxels"] == s0["voxels"] == capacity and s1["overflow"] > 0 and s0["overflow"] > 0, (s1, s0)
+        assert s1["ignored_points"] == s0["ignored_points"]
+    else:
+        assert s1 == s0, (s1, s0)
+        np.testing.assert_array_equal(k1, k0)
+    if oracle:
+        want, dropped = OM.occupied_set(c1.view(np.float32).reshape(-1, 3), res)
+        assert s1 == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}
+        np.testing.assert_array_equal(k1, want)
+    for b in (d_depth, d_pose, d_rgb):
+        if b is not None:
+            b.free()
+    return s1
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("pose", [True, False])
+@pytest.mark.parametrize("colour", [True, False])
+@pytest.mark.parametrize("hw", [(48, 64), (37, 53), (1, 1), (33, 1024)])
+def test_fused_cloud_and_voxels_equal_the_two_calls(V, ctx, dtype, pose, colour, hw):
+    """whole tiles, ragged tiles (37 x 53: colour plane neither 16-byte aligned per frame nor a whole tile), one pixel; every depth
+    type; with and without pose and colour"""
+    H, W = hw
+    F = 5
+    rng = np.random.default_rng(H * 1000 + W)
+    if dtype == np.float32:
+        depth = (rng.random((F, H, W), dtype=np.float32) * 9.5 + 0.5)
+        scale = 1.0
+    elif dtype == np.uint16:
+        depth = rng.integers(0, 65536, size=(F, H, W), dtype=np.uint16)
+        scale = 1.0 / 5000.0
+    else:
+        depth = rng.integers(0, 256, size=(F, H, W), dtype=np.uint8)
+        scale = 0.05
+    q, t = (rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 3) if pose else (None, None)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8) if colour else None
+    K = (W * 0.6, W * 0.6, (W - 1) / 2.0, (H - 1) / 2.0)
+    st = fused_vs_two_calls(V, ctx, depth, q, t, K, rgb, 0.1, 1 << 19, scale)
+    assert st["voxels"] >= 1
+
+
+def test_fused_cloud_and_voxels_nonfinite_and_far_points_are_ignored(V, ctx):
+    F, H, W = 3, 64, 128
+    rng = np.random.default_rng(11)
+    depth = rng.random((F, H, W), dtype=np.float32) * 5 + 0.5
+    depth[0, :4] = np.nan
+    depth[1, 10:12] = np.inf
+    depth[2, 30:33] = 3.0e5                                   # far outside the +-3276.8 m key range at 0.1 m
+    q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3))
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    st = fused_vs_two_calls(V, ctx, depth, q, t, (80.0, 80.0, 63.5, 31.5), rgb, 0.1, 1 << 16)
+    assert st["ignored_points"] >= (4 + 2 + 3) * W
+
+
+def test_fused_cloud_and_voxels_overflow_is_reported(V, ctx):
+    F, H, W = 2, 128, 256
+    rng = np.random.default_rng(12)
+    depth = rng.random((F, H, W), dtype=np.float32) * 50 + 0.5
+    st = fused_vs_two_calls(V, ctx, depth, None, None, (200.0, 200.0, 127.5, 63.5), None, 0.05, 1 << 12, oracle=False, overflowing=True)
+    assert st["overflow"] > 0 and st["voxels"] == 1 << 12
+
+
+@pytest.mark.parametrize("kind,res", [("room", 0.1), ("room", 0.02), ("room", 0.005), ("random", 0.1)])
+def test_fused_cloud_and_voxels_c5_geometry_20M_points(V, ctx, kind, res):
+    """config 5's geometry, 10 frames = 20.7 M points = 10 tiles per workgroup: set persisting (0.1 m), wiped mid-run (0.02 m), wiped
+    nearly every tile (0.005 m, random depth)"""
+    F, H, W = 10, 1080, 1920
+    rng = np.random.default_rng(6)
+    if kind == "room":
+        depth, q, t, K = room_views(F, H, W, seed=6)
+    else:
+        depth = rng.random((F, H, W), dtype=np.float32) * 99.5 + 0.5
+        q, t, K = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10, (960.0, 960.0, 959.5, 539.5)
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    st = fused_vs_two_calls(V, ctx, depth, q, t, K, rgb, res, 1 << 26)
+    assert st["voxels"] > 10_000
+
+
+def test_fused_cloud_and_voxels_staged_in_chunks(V, ctx):
+    """inputs above the staging threshold go chunk by chunk (one launch per chunk, each with its own runs): same results"""
+    F, H, W = 40, 384, 1280
+    rng = np.random.default_rng(13)
+    depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
+    q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 5
+    ctx.set_tuning("fuse_chunk_mb", 4)
+    try:
+        st = fused_vs_two_calls(V, ctx, depth, q, t, (721.5, 721.5, 609.5, 172.8), None, 0.1, 1 << 24, 0.1, oracle=False)
+    finally:
+        ctx.set_tuning("fuse_chunk_mb", 0)
+    assert st["voxels"] > 1000

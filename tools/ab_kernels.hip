@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void fuse32_lane(const uint8_t* __restric
         const uint32_t j = p / dm.width, i = p - j * dm.width;
         double w[3];
         point((double)raw[r], u[i], v[j], P, w);
-        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + (fbase + p) * 3),
+        asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + (fbase + p) * 3),
                      "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]})
                      : "memory");
       }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void fuse64_pair(const uint8_t* __restric
         // even: x_lo x_hi y_lo   odd: y_hi z_lo z_hi  (odd lane: a = y, b = z)
         const u32x3 val = odd ? u32x3{ahi, blo, bhi} : u32x3{alo, ahi, blo};
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + fbase * 3) + (uint64_t)(tf * tile_px) * 6 + (uint64_t)q * 3;
-        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(val) : "memory");
+        asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
       }
     }
   }
@@ -264,7 +264,7 @@ __device__ __forceinline__ void aff(const Aff& a, const P3& p, float* dst) {
   double w[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) w[c] = fma(a.T[4 * c + 2], z, fma(a.T[4 * c + 1], y, a.T[4 * c + 0] * x)) + a.T[4 * c + 3];
-  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]}) : "memory");
+  asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]}) : "memory");
 }
 // persistent: grid-stride over tiles, the NEXT tile's 4 loads are in flight while the current tile is computed/stored
 template <int PTS>
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void fuse_rgb(const uint8_t* __restrict__
         const uint32_t j = p / dm.width, i = p - j * dm.width;
         double w[3];
         point((double)raw[r], u[i], v[j], P, w);
-        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + (fbase + p) * 3),
+        asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + (fbase + p) * 3),
                      "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]})
                      : "memory");
         uint32_t c;

@@ -79,6 +79,24 @@ ms_v = ctx.timer_stop()
 st = vs.stats()
 print("voxel insert of all %.3f G points: %.1f ms = %.1f Gpoints/s -> %d occupied voxels (ignored %d, overflow %d); fuse + insert = %.1f ms"
       % (n / 1e9, ms_v, n / ms_v / 1e6, st["voxels"], st["ignored_points"], st["overflow"], ms + ms_v), flush=True)
+# ... and the two in ONE launch (r3d_fuse_frames_voxel): the keys come from the registers the cloud is stored from
+xyz_digest = None
+for blocks in (0, 2048, 16384, 65536, 262144):
+    ctx.set_tuning("fuse_blocks", blocks)
+    times_f = []
+    for _ in range(3):
+        vs.clear()
+        ctx.sync()
+        ctx.timer_start()
+        r3d.fuse_frames_voxel_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_rgb.ptr, d_xyz.ptr, d_rgba.ptr, vs)
+        times_f.append(ctx.timer_stop())
+    st_f = vs.stats()
+    print("fused cloud + voxels, grid %s: %s ms (median %.1f) -> %d voxels (ignored %d, overflow %d)%s"
+          % (blocks or "default", " ".join("%.1f" % x for x in times_f), sorted(times_f)[1], st_f["voxels"], st_f["ignored_points"],
+             st_f["overflow"], "" if st_f == st else "   != the two calls' " + str(st)), flush=True)
+    if st_f != st:
+        bad += 1
+ctx.set_tuning("fuse_blocks", 0)
 vs.close()
 ctx.close()
 sys.exit(1 if bad else 0)

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void fuse_pf(const uint8_t* __restrict__ 
       const uint32_t j = p / width, i = p - j * width;
       double w[3];
       point((double)z8, u[i], v[j], P, w);
-      asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + (fbase + p) * 3), "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]})
+      asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + (fbase + p) * 3), "v"(f32x3{(float)w[0], (float)w[1], (float)w[2]})
                    : "memory");
     }
   }

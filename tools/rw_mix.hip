@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k(const typename In<B>::T* __restrict__ i
       const uint64_t p = tile * 256 * PX + r * 256 + threadIdx.x;
       if (p < n) {
         const float z = In<B>::f(raw[r]);
-        asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + p * 3), "v"(f32x3{z, z * 2.f, z + 1.f}) : "memory");
+        asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + p * 3), "v"(f32x3{z, z * 2.f, z + 1.f}) : "memory");
       }
     }
   }

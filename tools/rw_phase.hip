@@ -17,7 +17,7 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void store_point(float* xyz, uint32_t* rgba, uint64_t p, f32x2 v) {
-  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(xyz + p * 3), "v"(f32x3{v.x, v.x * 2.f, v.y + 1.f}) : "memory");
+  asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(xyz + p * 3), "v"(f32x3{v.x, v.x * 2.f, v.y + 1.f}) : "memory");
   asm volatile("global_store_dword %0, %1, off nt" ::"v"(rgba + p), "v"(__float_as_uint(v.y)) : "memory");
 }
 
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void writes_only(float* __restrict__ xyz, uint
 // tile owns pixels 4t .. 4t+3 of it for the colour stream; the xyz stream keeps its 12 B-per-lane shape)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_xyz(float* xyz, uint64_t p, f32x2 v) {
-  asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(xyz + p * 3), "v"(f32x3{v.x, v.x * 2.f, v.y + 1.f}) : "memory");
+  asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(xyz + p * 3), "v"(f32x3{v.x, v.x * 2.f, v.y + 1.f}) : "memory");
 }
 __device__ __forceinline__ void store_rgba4(uint32_t* rgba, uint64_t p4, uint64_t n, f32x2 a, f32x2 b) {
   if (p4 + 3 < n) {

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_x3nt(float* __restrict__ out, long n_pt
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* dst = out + (t * 1024 + r * 256 + threadIdx.x) * 3;
-      asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
+      asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
     }
   }
 }
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_x3nt8(float* __restrict__ out, long n_p
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float* dst = out + (t * 2048 + r * 256 + threadIdx.x) * 3;
-      asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
+      asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
     }
   }
 }
@@ -89,9 +89,9 @@ __global__ __launch_bounds__(256) void k_flat3(float* __restrict__ out, long n_p
   for (; i + (UNROLL - 1) * stride < n_pts; i += UNROLL * stride) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
-      asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + (i + u * stride) * 3), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
+      asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + (i + u * stride) * 3), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
   }
-  for (; i < n_pts; i += stride) asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(out + i * 3), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
+  for (; i < n_pts; i += stride) asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(out + i * 3), "v"(f32x3{1.f, 2.f, 3.f}) : "memory");
 }
 int main() {
   const long n_pts = 49152000;

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 r3d = importlib.import_module("3d_reconstruction_system_amd")
 L = importlib.import_module("3d_reconstruction_system_amd._lib")
+if os.environ.get("R3D_LIB"):          # A/B against another build of the library
+    L.LIB_PATH = os.path.abspath(os.environ["R3D_LIB"])
 V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
 ctx = r3d.Context(0)
 F, H, W = 300, 1080, 1920
@@ -24,6 +26,8 @@ cam = ctx.camera(H, W, 960.0, 960.0, 959.5, 539.5)
 d_xyz = ctx.alloc(n * 12)
 r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.float32, F, d_pose.ptr, d_xyz.ptr, np.float32)
 vs = V.VoxelSet(0.1, 1 << 26, ctx)
+if len(sys.argv) > 1:
+    ctx.set_tuning("voxel_dedupe", int(sys.argv[1]))
 for _ in range(3):
     vs.clear()
     ctx.sync()
