@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void fuse_voxel_kernel(const DT* __restri
           }
           __builtin_nontemporal_store(c, rgba_out + fbase + p);
         }
-        if (!voxel_code(fx, fy, fz, vv.factor, &code)) {
+        if (!voxel_key(fx, fy, fz, vv.factor, &code)) {
           ++n_ignored;
           live = false;
           code = kEmpty;

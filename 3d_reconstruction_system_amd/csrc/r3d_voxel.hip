@@ -7,12 +7,12 @@
 //
 // A hits-only tree written with writeBinary() depends only on the SET of voxels that received a point
 // (toMaxLikelihood makes every hit leaf "occupied"), so the GPU's job is a set insert:
-//   * voxel_insert_kernel (HBM-bound, 12 B/point read): lane-per-point 12-byte loads, key per axis
-//     = (int)floor((1/res) * (double)x) + 32768 in fp64 like OcTreeBaseImpl::coordToKey, 16-bit keys
-//     interleaved to a 48-bit Morton code (x lowest, as OctoMap's child index), lanes whose predecessor
-//     lane holds the same code drop out, the rest go into an open-addressing hash set in HBM
-//     (64-bit atomicCAS, multiplicative hash, linear probing).
-//   * voxel_compact_kernel: table -> dense list of codes.
+//   * voxel_insert_kernel (12 B/point read): lane-per-point 12-byte loads, key per axis
+//     = (int)floor((1/res) * (double)x) + 32768 in fp64 like OcTreeBaseImpl::coordToKey, the three 16-bit keys
+//     packed into one word, lanes whose predecessor lane holds the same word drop out, the rest go into an
+//     open-addressing hash set in HBM (64-bit atomicCAS, multiplicative hash, linear probing).
+//   * voxel_compact_kernel: table -> dense list of 48-bit Morton codes (x lowest, as OctoMap's child index): the
+//     interleave is paid per distinct voxel here, not per point in the insert (r3d_voxel_dev.h).
 // The distinct codes are radix-sorted on the GPU (r3d_sort.hip); the host emits the pruned octree depth-first:
 // a child subtree is a pruned leaf exactly when its code range holds 8^(levels below) codes.
 #include <algorithm>
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
       const int64_t i = base + (int64_t)r * kThreads;
       uint64_t code = kEmpty;
       bool live = i < n;
-      if (live && !r3d_vox::voxel_code(p[r].x, p[r].y, p[r].z, factor, &code)) {
+      if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &code)) {
         ++n_ignored;
         live = false;
         code = kEmpty;
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_codes_kernel(const uint
     const uint64_t prev = __shfl_up(code, 1, 64);
     if (live && lane > 0 && prev == code) live = false;  // sorted inputs repeat a code in neighbouring lanes
     if (live) {
+      code = r3d_vox::key_of_morton(code);  // the table holds packed keys (r3d_voxel_dev.h)
       uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
       bool done = false;
       for (uint64_t probe = 0; probe <= mask && !done; ++probe) {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_codes_kernel(const uint
   }
 }
 
-// table -> dense list of its codes (order irrelevant: the radix sort follows).  One cursor bump per WORKGROUP-STEP of
+// table (packed keys) -> dense list of Morton codes (order irrelevant: the radix sort follows).  One cursor bump per WORKGROUP-STEP of
 // kCompactSlots table words held in registers (round 2 bumped the one global cursor once per wave per 64 words: ~2 M
 // same-address returning atomics for a 1 GB table = 25 ms = 0.8 % of HBM; a same-address returning atomic completes at
 // ~0.09 G/s, so the count per bump decides everything).  Steps that hold no code skip the atomic.
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void voxel_compact_kernel(const uint64_t*
       for (int k = 0; k < kCompactPerThread; ++k) {
         const bool hit = v[k] != kEmpty;
         const unsigned long long ballot = __ballot(hit);
-        if (hit) out[at + __popcll(ballot & below)] = v[k];
+        if (hit) out[at + __popcll(ballot & below)] = r3d_vox::morton_of_key(v[k]);  // packed key -> Morton code on the way out
         at += __popcll(ballot);
       }
     }

@@ -1,6 +1,11 @@
 // Device-side pieces of the occupied-voxel set shared by r3d_voxel.hip (insert from a cloud in HBM) and r3d_fuse.hip (insert
-// straight from the fused launch's registers): OctoMap's key arithmetic, the 48-bit Morton code, the global open-addressing
-// table, the neighbour-lane test.  See r3d_voxel.hip for the semantics and their sources.
+// straight from the fused launch's registers): OctoMap's key arithmetic, the global open-addressing table, the neighbour-lane
+// test, the 48-bit Morton code.  See r3d_voxel.hip for the semantics and their sources.
+//
+// What the sets hold: the three 16-bit OctoMap keys PACKED (x | y << 16 | z << 32), not their Morton code.  The Morton
+// interleave costs ~45 vector instructions and was paid per POINT (of 123 per 64 points in voxel_insert_kernel, which PMC shows
+// two-thirds VALU-busy); a set only needs an injective code, so the interleave moved to where codes leave the table
+// (voxel_compact_kernel: per distinct VOXEL, tens of times fewer) and its inverse to where ready-made codes enter it.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,17 +34,39 @@ __device__ __forceinline__ uint64_t morton48(uint32_t ix, uint32_t iy, uint32_t 
   return (uint64_t)lo | ((uint64_t)hi << 24);
 }
 
+// 24 bits, every third one -> 8 bits (inverse of spread3_byte)
+__device__ __forceinline__ uint32_t compact3_byte(uint32_t x) {
+  x &= 0x00249249u;
+  x = (x | (x >> 2)) & 0x000c30c3u;
+  x = (x | (x >> 4)) & 0x0000f00fu;
+  x = (x | (x >> 8)) & 0x000000ffu;
+  return x;
+}
+
+// packed keys (x | y << 16 | z << 32) <-> 48-bit Morton code
+__device__ __forceinline__ uint64_t morton_of_key(uint64_t key) {
+  return morton48((uint32_t)key & 0xffffu, ((uint32_t)key >> 16) & 0xffffu, (uint32_t)(key >> 32) & 0xffffu);
+}
+__device__ __forceinline__ uint64_t key_of_morton(uint64_t code) {
+  const uint32_t lo = (uint32_t)code & 0xffffffu, hi = (uint32_t)(code >> 24) & 0xffffffu;
+  const uint32_t ix = compact3_byte(lo) | (compact3_byte(hi) << 8);
+  const uint32_t iy = compact3_byte(lo >> 1) | (compact3_byte(hi >> 1) << 8);
+  const uint32_t iz = compact3_byte(lo >> 2) | (compact3_byte(hi >> 2) << 8);
+  return (uint64_t)(ix | (iy << 16)) | ((uint64_t)iz << 32);
+}
+
 // Keys in fp64 exactly as OcTreeBaseImpl::coordToKey computes them from FLOAT coordinates.  (An exact fp32 formulation -- t =
 // round(x f), r = fma(x, f, -t), floor(t) corrected when t is an integer and r < 0; valid when 1/res is exactly a float --
 // passed every face / ulp / denormal test in round 3 and was 4 % SLOWER on the scan benchmark: the kernel does not wait for
 // its ALUs.  Not shipped.)
-__device__ __forceinline__ bool voxel_code(float x, float y, float z, double factor, uint64_t* code) {
+__device__ __forceinline__ bool voxel_key(float x, float y, float z, double factor, uint64_t* key) {
   const double dx = floor(factor * (double)x), dy = floor(factor * (double)y), dz = floor(factor * (double)z);
   // rejects NaN/inf and anything outside the 2^16 key range
   const bool ok = dx >= -(double)kTreeMaxVal && dx < (double)kTreeMaxVal && dy >= -(double)kTreeMaxVal &&
                   dy < (double)kTreeMaxVal && dz >= -(double)kTreeMaxVal && dz < (double)kTreeMaxVal;
   if (!ok) return false;
-  *code = morton48((uint32_t)((int)dx + kTreeMaxVal), (uint32_t)((int)dy + kTreeMaxVal), (uint32_t)((int)dz + kTreeMaxVal));
+  const uint32_t ix = (uint32_t)((int)dx + kTreeMaxVal), iy = (uint32_t)((int)dy + kTreeMaxVal), iz = (uint32_t)((int)dz + kTreeMaxVal);
+  *key = (uint64_t)(ix | (iy << 16)) | ((uint64_t)iz << 32);
   return true;
 }
 
@@ -73,10 +100,14 @@ __device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64
 }
 
 // One code into a workgroup's LDS set.  *mine: this lane put it there; returns false only when the set is full (the caller
-// then sends the code to the global table directly).  The shape of this loop matters: one exit, a `done` flag -- the same
-// logic written with early returns compiled to a 13 % slower insert kernel (214 -> 186 Gpoints/s on the scan benchmark).
+// then sends the code to the global table directly).  The shape of this code matters more than its instruction count:
+//  * one exit and a `done` flag -- the same logic with early returns compiled to a 13 % slower insert kernel (214 -> 186
+//    Gpoints/s on the scan benchmark);
+//  * one round at a time -- reading the four rounds' first slots back to back (one LDS round trip per tile instead of four)
+//    and resolving them afterwards LOST 14 % on scans (222 -> 188) and 11 % on the worst case (15.1 -> 13.4 G inserts/s).
 __device__ __forceinline__ bool lds_set_claim(unsigned long long* local_set, uint64_t code, bool* mine_out) {
-  uint32_t slot = (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
+  // 11 bits from two 32-bit multiplicative hashes of the packed key's halves (a 64-bit multiply is five instructions)
+  uint32_t slot = (((uint32_t)code * 0x9E3779B1u) ^ ((uint32_t)(code >> 32) * 0x85EBCA77u)) >> 21;
   bool mine = false, done = false;
   // most codes of a scan are already in the set (the previous rows put them there): a plain LDS read settles those
   // without a compare-and-swap

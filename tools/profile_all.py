@@ -119,6 +119,13 @@ def main():
     out["voxel_insert"] = {"ms": ms_both - ms_clear, "Gpts": n / (ms_both - ms_clear) / 1e6, "voxels": st["voxels"],
                            "bound": "scattered 64-bit atomics (19 G/s measured ceiling)",
                            "Gatomics": st["voxels"] / (ms_both - ms_clear) / 1e6}
+    # the cloud and its voxels from one launch (r3d_fuse_frames_voxel) on the same frames: the worst case for it (random depth)
+    def one_launch():
+        vs.clear()
+        r3d.fuse_frames_voxel_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, None, d_xyz2.ptr, None, vs)
+    ms_one = timed(ctx, one_launch, 10) - ms_clear
+    out["fuse_voxel_one_launch"] = {"ms": ms_one, "Gpts": n / ms_one / 1e6, "voxels": vs.stats()["voxels"],
+                                    "two_calls_ms": out["fuse_u8_f32"]["ms"] + out["voxel_insert"]["ms"] if "fuse_u8_f32" in out else None}
     vs.close()
     d_xyz2.free()
     # C3: ICP on two 500k clouds

@@ -26,7 +26,9 @@ ALGO = {
     "fuse_rgb_kernel<unsigned char, true>": ("fused + colour, u8 depth + rgb -> f32 xyz + rgba", N_C2 * 20),
     "apply_lane_kernel<float, false>": ("apply-T 4x4, f32 -> f32", N_C2 * 24),
     "nn_cull_kernel<1, false>": ("culled exact NN + fused 18 sums, 500k x 500k (min bytes 12(N+M)+8N)", 500000 * (24 + 8)),
-    "voxel_insert_kernel<true>": ("voxel insert of the C2 cloud (12 B/point read; scattered 8-B atomics)", N_C2 * 12),
+    "voxel_insert_kernel<true, false>": ("voxel insert of the C2 cloud (12 B/point read; scattered 8-B atomics)", N_C2 * 12),
+    "fuse_voxel_kernel<unsigned char, true, false>": ("cloud + occupied voxels of the C2 frames in one launch (13 B/point; random depth: ~1 voxel per point, "
+                                                      "the atomics' worst case)", N_C2 * 13),
     "voxel_compact_kernel": ("hash table (2^27 slots, 1.07 GB) -> dense list of its ~48 M codes (read table + write codes)", (1 << 27) * 8 + 48_000_000 * 8),
     "cache_touch_kernel": ("input staging sweep of the C2 raster (read-only, 49 MB)", N_C2),
     "bbox_kernel": ("bounding box of a 500k-point cloud (two-stage, no atomics; 6 MB read)", 500000 * 12),
