@@ -155,6 +155,7 @@ static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "fuse_chunk_mb")) return &ctx->fuse_chunk_mb;
   if (!strcmp(key, "fuse_stage_auto_mb")) return &ctx->fuse_stage_auto_mb;
   if (!strcmp(key, "nn_variant")) return &ctx->nn_variant;
+  if (!strcmp(key, "nn_warm")) return &ctx->nn_warm;
   if (!strcmp(key, "nn_blocks")) return &ctx->nn_blocks;
   if (!strcmp(key, "apply_blocks")) return &ctx->apply_blocks;
   if (!strcmp(key, "voxel_dedupe")) return &ctx->voxel_dedupe;

@@ -28,9 +28,11 @@ struct r3d_ctx {
   // staging a raster that IS cached costs 4 %.  Below ~8 MB the extra launch eats the gain.
   int fuse_stage_auto_mb = 8;
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
+  int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances; 1 off
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
-  int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set
+  int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set; 3: on, with the
+                          // flush barrier inside its `if` (A/B against DESIGN 4.5b's finding only)
   // HIP-event stopwatch
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // grow-only scratch buffers for the *_host entry points and reductions

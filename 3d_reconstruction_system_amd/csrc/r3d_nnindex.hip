@@ -44,6 +44,10 @@ struct r3d_nn_index {
   float* d_frame = nullptr;    // [8]: lo xyz, scale xyz, unused: quantisation frame shared by both clouds
   void* d_slab = nullptr;      // ONE allocation holds every table above (eight hipMalloc / hipFree pairs per index were a
                                // measurable share of a 10 ms estimate)
+  // warm start (see nn_cull_kernel): the buffers of the last presorted query against this build of the index
+  const float* warm_src = nullptr;
+  const uint32_t* warm_idx = nullptr;
+  int64_t warm_n = 0;
 };
 
 namespace {
@@ -251,9 +255,10 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
                                                            const float* __restrict__ super_box,
                                                            const uint64_t* __restrict__ tile_code,
                                                            const float* __restrict__ tgt_orig,
-                                                           uint32_t* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                           uint32_t* idx_out, float* __restrict__ d2_out,
                                                            unsigned long long* __restrict__ stats,
-                                                           double* __restrict__ partials, float max_d2, float dead_zone) {
+                                                           double* __restrict__ partials, float max_d2, float dead_zone,
+                                                           const uint32_t* idx_warm) {
   __shared__ __attribute__((aligned(16))) float tx[kTile];
   __shared__ __attribute__((aligned(16))) float ty[kTile];
   __shared__ __attribute__((aligned(16))) float tz[kTile];
@@ -279,6 +284,25 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
     best[s] = INFINITY;
     best_group[s] = 0;
     tie_idx[s] = 0xffffffffu;
+  }
+  // Warm start (ICP iterations: the same sources, moved a little, against the same index): the distance to the target this
+  // source matched LAST time is an upper bound of its nearest-neighbour distance now, whatever the move was -- it is the
+  // distance to SOME target.  Starting from a bound STRICTLY above it (so that the true neighbour still wins the `<` below and
+  // ties are still resolved by the search itself) every level of culling works from the first tile on instead of waiting for
+  // the slowest lane of the workgroup to find something near.  Results are the cold search's, bit for bit; a stale or
+  // meaningless idx_warm (it is the previous content of idx_out, clamped to the target count) only makes the bound useless.
+  if (!SRC4 && idx_warm) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int64_t i = s_base + (int64_t)s * kThreads + tid;
+      if (ok[s]) {
+        const uint32_t j = min(idx_warm[i], (uint32_t)(n_tgt - 1));
+        const P3 q = reinterpret_cast<const P3*>(tgt_orig)[j];
+        const float dx = sx[s] - q.x, dy = sy[s] - q.y, dz = sz[s] - q.z;
+        const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d < INFINITY) best[s] = d * 1.000002f + 1.17549435e-38f;   // NaN / inf: no bound
+      }
+    }
   }
   if (tid == 0) {
     // tile whose Morton range holds this workgroup's first source: last tile with first code <= code
@@ -503,6 +527,9 @@ int r3d_nn_index_destroy(r3d_nn_index* ix) {
 static int nn_index_build(r3d_nn_index* ix, const float* d_tgt, int64_t n_tgt) {
   r3d_ctx* ctx = ix->ctx;
   ix->n = n_tgt;
+  ix->warm_src = nullptr;   // matches against the previous target mean nothing for this one
+  ix->warm_idx = nullptr;
+  ix->warm_n = 0;
   ix->n_tiles = (n_tgt + kTile - 1) / kTile;
   ix->idx_bits = bits_for(n_tgt);
   ix->axis_bits = 10;  // 2^30 cells order any cloud finely enough for tile coherence and leave 34 bits for indices
@@ -638,11 +665,20 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
     if ((rc = r3d_scratch(ctx, 4, (size_t)blocks * r3d_icp::kSums * sizeof(double), &pv))) return rc;
     partials = static_cast<double*>(pv);
   }
+  // same sources buffer, same count, same output buffer as the last presorted query against this build of the index: the
+  // output buffer still holds that query's matches ("nn_warm" = 1 switches the warm start off: A/B, tests)
+  const uint32_t* warm = nullptr;
+  if (presorted && ctx->nn_warm != 1 && ix->warm_src == d_src && ix->warm_idx == d_idx_out && ix->warm_n == n_src) warm = d_idx_out;
+  if (presorted) {
+    ix->warm_src = d_src;
+    ix->warm_idx = d_idx_out;
+    ix->warm_n = n_src;
+  }
 #define R3D_LAUNCH_CULL(SS, FMT, PTR)                                                                                  \
   hipLaunchKernelGGL((nn_cull_kernel<SS, FMT>), dim3(blocks), dim3(kThreads), 0, st, (const void*)(PTR), n_src,        \
                      (const float*)ix->d_frame, ix->axis_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box,         \
                      ix->d_sub_box, ix->d_group_box, ix->d_super_box, ix->d_tile_code, (const float*)ix->d_tgt, d_idx_out, d_d2_out,     \
-                     h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone)
+                     h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone, warm)
   if (presorted) {
     if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
     else if (S == 2) R3D_LAUNCH_CULL(2, false, d_src);

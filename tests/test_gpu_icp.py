@@ -664,3 +664,98 @@ def test_a_square_room_whose_two_long_axes_are_a_coin_toss(icp, ctx):
         src = ((sw - T_true[:3, 3]) @ np.linalg.inv(T_true[:3, :3]).T).astype(np.float32)
         T, info = icp.icp_similarity(src, tgt, ctx=ctx)
         assert np.abs(T - T_true).max() <= 5e-3, (angle, seed, np.abs(T - T_true).max(), info["init_choice"], info["init_candidates"][info["init_choice"]])
+
+
+# ---- warm start of the culled search (repeated presorted queries: the previous matches bound the new search) ----------------
+
+def _warm_vs_cold(icp, ctx, tgt, src_steps, poison=None):
+    """query the same source BUFFER repeatedly (contents replaced by src_steps[k]) warm and cold: identical indices, distances
+    and -- for the last step -- the oracle's; returns the tile sweeps (cold, warm) of the last step"""
+    n = src_steps[0].shape[0]
+    d_tgt = ctx.alloc(tgt.nbytes).upload(tgt)
+    d_src = ctx.alloc(n * 12)
+    out = {}
+    for mode in ("cold", "warm"):
+        ctx.set_tuning("nn_warm", 1 if mode == "cold" else 0)
+        try:
+            ix = icp.NNIndex(ctx, d_tgt.ptr, tgt.shape[0])
+            d_idx, d_d2 = ctx.alloc(n * 4), ctx.alloc(n * 4)
+            res = []
+            for k, s in enumerate(src_steps):
+                d_src.upload(np.ascontiguousarray(s, dtype=np.float32))
+                if poison is not None and k == 1:
+                    d_idx.upload(poison)                         # whatever the buffer holds must not matter
+                swept = ix.query(d_src.ptr, n, d_idx.ptr, d_d2.ptr, want_stats=True, presorted=True)
+                res.append((d_idx.download(np.uint32, n), d_d2.download(np.float32, n), swept))
+            out[mode] = res
+            ix.close()
+            d_idx.free()
+            d_d2.free()
+        finally:
+            ctx.set_tuning("nn_warm", 0)
+    for (ic, dc, _), (iw, dw, _) in zip(out["cold"], out["warm"]):
+        np.testing.assert_array_equal(iw, ic)
+        np.testing.assert_array_equal(dw.view(np.uint32), dc.view(np.uint32))
+    d_tgt.free()
+    d_src.free()
+    return out["cold"][-1], out["warm"][-1]
+
+
+def test_warm_started_search_is_bit_identical_and_sweeps_fewer_tiles(icp, ctx):
+    """an ICP-like sequence: the sources creep towards the targets; every step's warm result equals the cold one and the
+    oracle's, and the warm search visits fewer tiles"""
+    rng = np.random.default_rng(77)
+    tgt = (rng.random((200000, 3)) * 20).astype(np.float32)
+    base = tgt[rng.permutation(200000)[:60000]]
+    base = base[np.lexsort((base[:, 2] // 2, base[:, 1] // 2, base[:, 0] // 2))]       # spatially coherent order
+    steps = [(base * np.float32(1.0 + 0.01 / (k + 1)) + np.float32(0.05 / (k + 1))).astype(np.float32) for k in range(4)]
+    (ic, dc, swept_c), (iw, dw, swept_w) = _warm_vs_cold(icp, ctx, tgt, steps)
+    oi, od = OI.nearest_neighbours(steps[-1], tgt)
+    np.testing.assert_array_equal(iw, oi)
+    np.testing.assert_allclose(dw, od, rtol=2e-7)
+    assert swept_w < 0.7 * swept_c, (swept_w, swept_c)
+
+
+def test_warm_start_ignores_what_the_index_buffer_holds(icp, ctx):
+    """out-of-range, all-equal and random previous 'matches', and a far jump of the sources between two queries"""
+    rng = np.random.default_rng(78)
+    tgt = (rng.random((50000, 3)) * 10).astype(np.float32)
+    src = (rng.random((9000, 3)) * 10).astype(np.float32)
+    far = (src[::-1] * np.float32(0.5) + np.float32(3.0)).astype(np.float32)
+    for poison in (np.full(9000, 0xffffffff, np.uint32), np.zeros(9000, np.uint32), rng.integers(0, 2**32, 9000, dtype=np.uint64).astype(np.uint32)):
+        (ic, dc, _), (iw, dw, _) = _warm_vs_cold(icp, ctx, tgt, [src, far], poison=poison)
+        np.testing.assert_array_equal(iw, OI.nearest_neighbours(far, tgt)[0])
+
+
+def test_warm_start_keeps_the_tie_rule_and_the_non_finite_rule(icp, ctx):
+    rng = np.random.default_rng(79)
+    base = rng.integers(0, 6, (300, 3)).astype(np.float32)
+    tgt = np.tile(base, (20, 1))                                   # every point at 20 original indices, many tiles
+    src = np.concatenate([base + np.float32(0.25), base]).astype(np.float32)
+    src2 = src.copy()
+    src2[::7] = np.nan
+    src2[3::11, 1] = np.inf
+    (ic, dc, _), (iw, dw, _) = _warm_vs_cold(icp, ctx, tgt, [src, src, src2])
+    want = OI.nearest_neighbours(src, tgt)[0]
+    bad = ~np.isfinite(src2).all(1)
+    np.testing.assert_array_equal(iw[~bad], want[~bad])
+    assert (iw[bad] == 0).all() and np.isinf(dw[bad]).all() and iw.max() < 300
+
+
+def test_warm_start_is_dropped_when_the_index_is_rebuilt(icp, ctx):
+    rng = np.random.default_rng(80)
+    tgt_a = (rng.random((40000, 3)) * 10).astype(np.float32)
+    tgt_b = (rng.random((30000, 3)) * 10 + 4).astype(np.float32)
+    src = (rng.random((8000, 3)) * 10).astype(np.float32)
+    d_a, d_b, d_src = ctx.alloc(tgt_a.nbytes).upload(tgt_a), ctx.alloc(tgt_b.nbytes).upload(tgt_b), ctx.alloc(src.nbytes).upload(src)
+    d_idx, d_d2 = ctx.alloc(8000 * 4), ctx.alloc(8000 * 4)
+    ix = icp.NNIndex(ctx, d_a.ptr, 40000)
+    ix.query(d_src.ptr, 8000, d_idx.ptr, d_d2.ptr, presorted=True)
+    ix.rebuild(d_b.ptr, 30000)                                      # indices up to 39999 are now out of range
+    ix.query(d_src.ptr, 8000, d_idx.ptr, d_d2.ptr, presorted=True)
+    np.testing.assert_array_equal(d_idx.download(np.uint32, 8000), OI.nearest_neighbours(src, tgt_b)[0])
+    ix.query(d_src.ptr, 8000, d_idx.ptr, d_d2.ptr, presorted=True)  # warm against the new target
+    np.testing.assert_array_equal(d_idx.download(np.uint32, 8000), OI.nearest_neighbours(src, tgt_b)[0])
+    ix.close()
+    for b in (d_a, d_b, d_src, d_idx, d_d2):
+        b.free()
