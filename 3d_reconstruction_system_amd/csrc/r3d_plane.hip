@@ -78,10 +78,17 @@ __global__ __launch_bounds__(kThreads) void normals_kernel(const float* __restri
 }
 
 // ---- exact order statistics of an fp32 array, per bucket ---------------------------------------------------------
-// Every element belongs to one of n_buckets classes (bucket[i]; NULL = one class).  Per class: the element of rank
-// floor(q (m - 1)) among its m finite values.  Three passes over the keys' 11 / 11 / 10 bit digits; per pass one
-// histogram launch (all classes at once) and one pick launch (one workgroup per class).
-constexpr int kBins = 2048;
+// Every element belongs to one of n_buckets classes (bucket[i]; NULL = contiguous blocks of per_class elements, or one
+// class).  Per class: the element of rank floor(q (m - 1)) among its m finite values.  Four passes over the keys' 8-bit
+// digits, most significant first, ONE launch per pass: every workgroup counts its elements into an LDS histogram of all
+// classes (32 x 256 counters), adds its non-zero counters to the global one, and the workgroup that finishes LAST (a
+// ticket) picks every class's digit -- a wave per class, four bins per lane, one shuffle scan -- narrows the prefixes and
+// clears the histogram for the next pass.
+// (Round 3 until late: three passes of 11 / 11 / 10 bits, counters straight in HBM -- the residuals of one wall fall into a
+// handful of bins, so every wave of the grid wanted the same few words: 38 us per pass for 300k values even with one atomic
+// per distinct counter per wave -- plus a pick launch per pass: a third of a point-to-plane iteration.)
+constexpr int kBins = 256;
+constexpr int kSelectPasses = 4;
 constexpr int kMaxBuckets = 32;
 // per class: state[4] = {rank still to go, key prefix, prefix mask, finite count}
 struct SelectOut {
@@ -94,136 +101,153 @@ __device__ __forceinline__ unsigned order_key(float f) {
   return (u >> 31) ? ~u : (u | 0x80000000u);
 }
 
-// BUCKETED = false: one class, per-workgroup LDS histogram flushed once; true: straight to the class's global histogram
-template <bool BUCKETED>
-__global__ __launch_bounds__(kThreads) void select_hist_kernel(const float* __restrict__ v, const unsigned char* __restrict__ bucket,
-                                                               int64_t per_class, int64_t n, int n_buckets, int shift, int bits,
-                                                               unsigned* __restrict__ hist,
-                                                               const unsigned long long* __restrict__ state) {
-  __shared__ unsigned local[BUCKETED ? 1 : kBins];
+__global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __restrict__ v, const unsigned char* __restrict__ bucket,
+                                                               int64_t per_class, int64_t n, int n_buckets, int pass, double q,
+                                                               unsigned* hist, unsigned long long* state, unsigned* ticket,
+                                                               SelectOut* __restrict__ out_all) {
+  __shared__ unsigned local[kMaxBuckets * kBins];
   __shared__ unsigned s_prefix[kMaxBuckets], s_mask[kMaxBuckets];
-  if (!BUCKETED) {
-    for (int b = threadIdx.x; b < kBins; b += kThreads) local[b] = 0;
-  }
+  __shared__ int s_last;
+  const int shift = 8 * (kSelectPasses - 1 - pass);
+  const int n_slots = n_buckets * kBins;
+  for (int b = threadIdx.x; b < n_slots; b += kThreads) local[b] = 0;
   if (threadIdx.x < n_buckets) {
     s_prefix[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 1];
     s_mask[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 2];
   }
   __syncthreads();
-  const unsigned bin_mask = (1u << bits) - 1u;
   const int lane = threadIdx.x & 63;
-  // whole waves stay in the loop together (the aggregation below votes across the wave)
-  for (int64_t i0 = (int64_t)blockIdx.x * kThreads + (threadIdx.x & ~63); i0 < n; i0 += (int64_t)gridDim.x * kThreads) {
-    const int64_t i = i0 + lane;
-    bool live = i < n;
-    unsigned slot = 0;
-    if (live) {
-      const float f = v[i];
-      live = (__float_as_uint(f) & 0x7f800000u) != 0x7f800000u;   // inf / NaN never count
-      // class of element i: its byte in `bucket`, or (bucket == NULL) the contiguous block of per_class elements it lies in
-      const int c = BUCKETED ? (bucket ? (int)bucket[i] : (int)(i / per_class)) : 0;
-      live = live && c < n_buckets;
-      if (live) {
-        const unsigned key = order_key(f);
-        live = (key & s_mask[c]) == s_prefix[c];
-        slot = (unsigned)c * kBins + ((key >> shift) & bin_mask);
-      }
+  // whole waves stay in the loop together (the aggregation below votes across the wave); four elements per lane are
+  // requested before the first is counted (one memory round trip per four instead of one each: the votes keep the compiler
+  // from overlapping the iterations by itself)
+  constexpr int kAhead = 4;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i0 = (int64_t)blockIdx.x * kThreads + (threadIdx.x & ~63); i0 < n; i0 += stride * kAhead) {
+    float f[kAhead];
+    int cls[kAhead];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) {
+      const int64_t i = i0 + a * stride + lane;
+      const int64_t ic = i < n ? i : n - 1;   // clamped: unconditional loads
+      f[a] = v[ic];
+      // class of element i: its byte in `bucket`, or the contiguous block of per_class elements it lies in, or the only one
+      cls[a] = bucket ? (int)bucket[ic] : per_class > 0 ? (int)(ic / per_class) : 0;
     }
-    if (BUCKETED) {
-      // Wave-aggregated: the residuals of one wall fall into a handful of logarithmic bins, so a wave's 64 lanes mostly
-      // want the same few counters -- one atomic per DISTINCT counter (up to four rounds), plain atomics for what is left
-      // (64 same-address atomics per wave made the first pass 93 us on a 300k-pair cloud).
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) {
+      const int64_t i = i0 + a * stride + lane;
+      bool live = i < n && (__float_as_uint(f[a]) & 0x7f800000u) != 0x7f800000u && cls[a] < n_buckets;   // inf / NaN never count
+      unsigned slot = 0;
+      if (live) {
+        const unsigned key = order_key(f[a]);
+        live = (key & s_mask[cls[a]]) == s_prefix[cls[a]];
+        slot = (unsigned)cls[a] * kBins + ((key >> shift) & (kBins - 1u));
+      }
+      // Wave-aggregated: the residuals of one wall share their leading digits, so a wave's 64 lanes mostly want the same few
+      // counters -- one LDS atomic per DISTINCT counter (up to four rounds), plain atomics for what is left
       unsigned long long todo = __ballot(live);
       for (int round = 0; round < 4 && todo; ++round) {
         const int leader = __ffsll((long long)todo) - 1;
         const unsigned want = __shfl(slot, leader, 64);
         const unsigned long long same = __ballot(live && slot == want);
-        if (lane == leader) atomicAdd(&hist[want], (unsigned)__popcll(same));
+        if (lane == leader) atomicAdd(&local[want], (unsigned)__popcll(same));
         if (live && slot == want) live = false;
         todo &= ~same;
       }
-      if (live) atomicAdd(&hist[slot], 1u);
-    } else if (live) {
-      atomicAdd(&local[slot], 1u);
+      if (live) atomicAdd(&local[slot], 1u);
     }
   }
-  if (!BUCKETED) {
-    __syncthreads();
-    for (int b = threadIdx.x; b < kBins; b += kThreads)
-      if (local[b]) atomicAdd(&hist[b], local[b]);
-  }
-}
-
-// one workgroup per class: find the bin that holds the wanted rank, narrow the prefix, clear the histogram for the next
-// pass; the last pass writes the value
-__global__ __launch_bounds__(kThreads) void select_pick_kernel(unsigned* __restrict__ hist_all, unsigned long long* __restrict__ state_all,
-                                                               int pass, int shift, int bits, double q, int last,
-                                                               SelectOut* __restrict__ out_all) {
-  unsigned* hist = hist_all + (size_t)blockIdx.x * kBins;
-  unsigned long long* state = state_all + (size_t)blockIdx.x * 4;
-  SelectOut* out = out_all + blockIdx.x;
-  __shared__ unsigned long long part[kThreads];
-  __shared__ unsigned long long total_s, k_s;
-  constexpr int per = kBins / kThreads;
-  unsigned c[per];
-  unsigned long long mine = 0;
-#pragma unroll
-  for (int m = 0; m < per; ++m) {
-    c[m] = hist[threadIdx.x * per + m];
-    mine += c[m];
-  }
-  part[threadIdx.x] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {   // 256 values: a serial exclusive scan is a few hundred cycles, once per pass
-    unsigned long long run = 0;
-    for (int t = 0; t < kThreads; ++t) {
-      const unsigned long long x = part[t];
-      part[t] = run;
-      run += x;
+  for (int b = threadIdx.x; b < n_slots; b += kThreads)
+    if (local[b]) atomicAdd(&hist[b], local[b]);
+  // the last workgroup to get here sees every other one's counters (release by the fence, acquire by the ticket)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int wave = threadIdx.x >> 6;
+  const int last = pass == kSelectPasses - 1;
+  // every class of this wave is requested before the first is scanned (a wave has up to eight classes: eight dependent L2
+  // round trips otherwise)
+  constexpr int kWaves = kThreads / 64, kPerWave = kMaxBuckets / kWaves;
+  unsigned cnt_all[kPerWave][4];
+#pragma unroll
+  for (int j = 0; j < kPerWave; ++j) {
+    const int c = wave + j * kWaves;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      cnt_all[j][m] = c < n_buckets ? __hip_atomic_load(&hist[(size_t)c * kBins + lane * 4 + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0u;   // (agent scope: past this CU's L1)
+  }
+#pragma unroll
+  for (int j = 0; j < kPerWave; ++j) {
+    const int c = wave + j * kWaves;
+    if (c >= n_buckets) break;   // wave-uniform
+    unsigned* h = hist + (size_t)c * kBins;
+    unsigned long long* st = state + (size_t)c * 4;
+    unsigned cnt[4];
+    unsigned mine = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      cnt[m] = cnt_all[j][m];
+      mine += cnt[m];
     }
-    total_s = run;
+    unsigned inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    const unsigned long long total = __shfl(inc, 63, 64);
+    unsigned long long k;
     if (pass == 0) {
-      state[3] = run;
       // rank of the q-quantile among the finite values, "lower" rule: floor(q (m - 1))
-      double r = floor(q * (double)(run > 0 ? run - 1 : 0));
+      double r = floor(q * (double)(total > 0 ? total - 1 : 0));
       if (!(r >= 0.0)) r = 0.0;
-      unsigned long long k = (unsigned long long)r;
-      if (run > 0 && k > run - 1) k = run - 1;
-      state[0] = k;
-      k_s = k;
+      k = (unsigned long long)r;
+      if (total > 0 && k > total - 1) k = total - 1;
     } else {
-      k_s = state[0];
+      k = st[0];
     }
-  }
-  __syncthreads();
-  const unsigned long long total = total_s, k = k_s;   // the rank travels through LDS, not through a global word
-  if (total > 0) {
-    unsigned long long before = part[threadIdx.x];
-    if (k >= before && k < before + mine) {   // exactly one thread
+    const unsigned long long old_prefix = st[1], old_mask = st[2], old_count = st[3];
+    if (total > 0) {
+      unsigned long long before = inc - mine;
+      if (k >= before && k < before + mine) {   // exactly one lane
 #pragma unroll
-      for (int m = 0; m < per; ++m) {
-        if (k < before + c[m]) {
-          const unsigned bin = (unsigned)(threadIdx.x * per + m);
-          const unsigned prefix = (unsigned)state[1] | (bin << shift);
-          state[0] = k - before;
-          state[1] = prefix;
-          state[2] = (unsigned)state[2] | (((1u << bits) - 1u) << shift);
-          if (last) {
-            const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
-            out->value = __uint_as_float(u);
-            out->count = (unsigned)state[3];
+        for (int m = 0; m < 4; ++m) {
+          if (k < before + cnt[m]) {
+            const unsigned bin = (unsigned)(lane * 4 + m);
+            const unsigned prefix = (unsigned)old_prefix | (bin << shift);
+            st[0] = k - before;
+            st[1] = prefix;
+            st[2] = (unsigned)old_mask | ((kBins - 1u) << shift);
+            if (pass == 0) st[3] = total;
+            if (last) {
+              const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+              out_all[c].value = __uint_as_float(u);
+              out_all[c].count = (unsigned)(pass == 0 ? total : old_count);
+            }
+            break;
           }
-          break;
+          before += cnt[m];
         }
-        before += c[m];
+      }
+    } else if (lane == 0) {
+      if (pass == 0) {
+        st[0] = 0;
+        st[3] = 0;
+      }
+      if (last) {
+        out_all[c].value = INFINITY;   // no finite value in this class: nothing passes a "<= gate" test anyway
+        out_all[c].count = 0;
       }
     }
-  } else if (threadIdx.x == 0 && last) {
-    out->value = INFINITY;   // no finite value in this class: nothing passes a "<= gate" test anyway
-    out->count = 0;
-  }
 #pragma unroll
-  for (int m = 0; m < per; ++m) hist[threadIdx.x * per + m] = 0;
+    for (int m = 0; m < 4; ++m) h[lane * 4 + m] = 0;
+  }
+  if (threadIdx.x == 0) *ticket = 0;
 }
 
 // ---- point-to-plane pairs ----------------------------------------------------------------------------------
@@ -351,29 +375,32 @@ __global__ __launch_bounds__(kThreads) void plane_finish_kernel(const double* __
   }
 }
 
-// workspace in scratch slot 6: [hist n_buckets x 2048 u32][state n_buckets x 4 u64][SelectOut x n_buckets][pad], then the
-// partial rows
+// workspace in scratch slot 6: [hist n_buckets x 256 u32][state n_buckets x 4 u64][ticket, 64 B][SelectOut x n_buckets][pad],
+// then the partial rows
 struct Workspace {
   unsigned* hist;
   unsigned long long* state;
+  unsigned* ticket;
   SelectOut* out;
   double* rows;
-  size_t clear_bytes;   // hist + state
+  size_t clear_bytes;   // hist + state + ticket
 };
 
 int workspace(r3d_ctx* ctx, int n_buckets, int n_rows, Workspace* ws) {
   void* p = nullptr;
   const size_t hist_b = (size_t)n_buckets * kBins * sizeof(unsigned), state_b = (size_t)n_buckets * 4 * sizeof(unsigned long long);
-  const size_t head = hist_b + state_b + (size_t)n_buckets * sizeof(SelectOut) + 64;
+  const size_t ticket_b = 64;
+  const size_t head = hist_b + state_b + ticket_b + (size_t)n_buckets * sizeof(SelectOut) + 64;
   const size_t head_al = (head + 255) & ~(size_t)255;
   int rc = r3d_scratch(ctx, 6, head_al + (size_t)(n_rows + 1) * kSums * sizeof(double), &p);
   if (rc) return rc;
   char* c = static_cast<char*>(p);
   ws->hist = reinterpret_cast<unsigned*>(c);
   ws->state = reinterpret_cast<unsigned long long*>(c + hist_b);
-  ws->out = reinterpret_cast<SelectOut*>(c + hist_b + state_b);
+  ws->ticket = reinterpret_cast<unsigned*>(c + hist_b + state_b);
+  ws->out = reinterpret_cast<SelectOut*>(c + hist_b + state_b + ticket_b);
   ws->rows = reinterpret_cast<double*>(c + head_al);
-  ws->clear_bytes = hist_b + state_b;
+  ws->clear_bytes = hist_b + state_b + ticket_b;
   return R3D_OK;
 }
 
@@ -384,18 +411,9 @@ int select_enqueue(r3d_ctx* ctx, const float* d_values, const unsigned char* d_b
   R3D_HIP(hipMemsetAsync(ws.hist, 0, ws.clear_bytes, st));
   int blocks = (int)std::min<int64_t>((n + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->num_cus);
   if (blocks < 1) blocks = 1;
-  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-  for (int pass = 0; pass < 3; ++pass) {
-    const bool classes = d_bucket != nullptr || per_class > 0;
-    if (classes)
-      hipLaunchKernelGGL(select_hist_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, per_class, n, n_buckets,
-                         shifts[pass], bits[pass], ws.hist, (const unsigned long long*)ws.state);
-    else
-      hipLaunchKernelGGL(select_hist_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, (int64_t)0, n, 1,
-                         shifts[pass], bits[pass], ws.hist, (const unsigned long long*)ws.state);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(classes ? n_buckets : 1), dim3(kThreads), 0, st, ws.hist, ws.state, pass,
-                       shifts[pass], bits[pass], q, pass == 2 ? 1 : 0, ws.out);
-  }
+  for (int pass = 0; pass < kSelectPasses; ++pass)
+    hipLaunchKernelGGL(select_pass_kernel, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, per_class, n, n_buckets, pass, q,
+                       ws.hist, ws.state, ws.ticket, ws.out);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
