@@ -428,7 +428,7 @@ int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_s
     if (index) {
       // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud): no sort, sums fused
       // (the last kernel of the sums pass also solves the step and updates d_state)
-      if ((rc = r3d_nn_index_query_solve(index, d_src, n_src, d_idx, d_d2, max_d2, d_sums, with_scale, d_state))) return rc;
+      if ((rc = r3d_nn_index_query_solve(index, d_src, n_src, d_idx, d_d2, max_d2, d_sums, with_scale, d_state, it > 0))) return rc;
     } else {
       if ((rc = r3d_icp_nn(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2))) return rc;
       if ((rc = accumulate_impl(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, 0.f, d_sums, with_scale, d_state)))

@@ -28,7 +28,8 @@ struct r3d_ctx {
   // staging a raster that IS cached costs 4 %.  Below ~8 MB the extra launch eats the gain.
   int fuse_stage_auto_mb = 8;
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
-  int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances; 1 off
+  int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances, ICP loops use
+                          // nn_warm_kernel from their second iteration on; 1 off; 2 / 3: never / always nn_warm_kernel (A/B)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
   int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set; 3: on, with the
@@ -113,7 +114,11 @@ int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt
 int r3d_icp_sums_finish(r3d_ctx* ctx, const double* d_partials, int n_rows, double* d_sums_out, int with_scale, double* d_state);
 // r3d_nnindex.hip: presorted culled query + fused sums + device solve (one iteration's worth, used by r3d_icp_iterate)
 int r3d_nn_index_query_solve(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                             float max_d2, double* d_sums_out, int with_scale, double* d_state);
+                             float max_d2, double* d_sums_out, int with_scale, double* d_state, int small_motion);
+// presorted query of an ICP loop; small_motion: the sources moved by one ICP step since this same query ran last (its matches,
+// still in d_idx_out, bound the new search tightly: wave-local kernel)
+int r3d_nn_index_query_step(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                            int small_motion);
 
 static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
 static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

@@ -494,6 +494,198 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
   if ((tid & 63) == 0 && stats) atomicAdd(&stats[1], (unsigned long long)groups_done);  // 32-target groups evaluated, per wave
 }
 
+// ---- warm query: one wave, no LDS, no barrier --------------------------------------------------------------------
+// When every source starts with a tight bound (the warm start above: an ICP iteration after the first) only a handful of
+// 32-target groups can still improve any lane -- staging whole 1024-target tiles in LDS behind workgroup barriers, as
+// nn_cull_kernel does for a search that starts from nothing, is then nearly all overhead (measured on the two-view pair:
+// 6.5 tiles staged per workgroup whether warm or cold).  Here a WAVE is on its own: the boxes of a level are tested in
+// PARALLEL, one per lane, against the wave's own source box inflated by its largest bound (a conservative filter); the
+// survivors are visited one by one with the exact per-lane test of nn_cull_kernel (their box comes from the holding lane by
+// v_readlane, no reload); a group that passes is fetched with ONE coalesced load (lane t holds target t) and its 32 targets
+// are broadcast by v_readlane.  Same candidates-or-better than the cold walk, same `<` / tie rule, same epilogue: the
+// results are the cold search's bit for bit (tests/test_gpu_icp.py::test_warm_*).
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// squared distance between two axis-aligned boxes (0 when they overlap); an empty box (+inf, -inf) is infinitely far
+__device__ __forceinline__ float box_box_d2(const float blo[3], const float bhi[3], const float slo[3], const float shi[3]) {
+  const float ex = fmaxf(fmaxf(blo[0] - shi[0], slo[0] - bhi[0]), 0.f);
+  const float ey = fmaxf(fmaxf(blo[1] - shi[1], slo[1] - bhi[1]), 0.f);
+  const float ez = fmaxf(fmaxf(blo[2] - shi[2], slo[2] - bhi[2]), 0.f);
+  return fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+}
+__device__ __forceinline__ float box_point_d2(float lx, float ly, float lz, float hx, float hy, float hz, float px, float py, float pz) {
+  const float ex = fmaxf(fmaxf(lx - px, px - hx), 0.f);
+  const float ey = fmaxf(fmaxf(ly - py, py - hy), 0.f);
+  const float ez = fmaxf(fmaxf(lz - pz, pz - hz), 0.f);
+  return fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+}
+
+__global__ __launch_bounds__(kThreads) void nn_warm_kernel(const float* __restrict__ src, int64_t n_src,
+                                                           const float4* __restrict__ tgt4, int64_t n_tgt, int64_t n_tiles,
+                                                           const float* __restrict__ tile_box, const float* __restrict__ group_box,
+                                                           const float* __restrict__ super_box, const float* __restrict__ tgt_orig,
+                                                           uint32_t* idx_out, float* __restrict__ d2_out,
+                                                           unsigned long long* __restrict__ stats, double* __restrict__ partials,
+                                                           float max_d2, float dead_zone, const uint32_t* idx_warm) {
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * kThreads + tid;
+  const bool ok = i < n_src;
+  const P3 sp = ok ? reinterpret_cast<const P3*>(src)[i] : P3{0.f, 0.f, 0.f};
+  const float sx = sp.x, sy = sp.y, sz = sp.z;
+  // a source with a NaN / inf coordinate has no finite distance to anything (its answer is "index 0, +inf", as in the cold
+  // search): it takes no part in the culling votes instead of holding every box open for its wave
+  const bool act = ok && (sx - sx == 0.f) && (sy - sy == 0.f) && (sz - sz == 0.f);
+  float best = INFINITY;
+  uint32_t best_group = 0, tie_idx = 0xffffffffu;
+  if (act) {   // the bound: see nn_cull_kernel
+    const uint32_t j = min(idx_warm[i], (uint32_t)(n_tgt - 1));
+    const P3 q = reinterpret_cast<const P3*>(tgt_orig)[j];
+    const float dx = sx - q.x, dy = sy - q.y, dz = sz - q.z;
+    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (d < INFINITY) best = d * 1.000002f + 1.17549435e-38f;
+  }
+  // the wave's source box and its largest bound (+inf as soon as one active lane has none)
+  const float slo[3] = {wave_min(act ? sx : INFINITY), wave_min(act ? sy : INFINITY), wave_min(act ? sz : INFINITY)};
+  const float shi[3] = {wave_max(act ? sx : -INFINITY), wave_max(act ? sy : -INFINITY), wave_max(act ? sz : -INFINITY)};
+  float R = wave_max(act ? best : 0.f);
+  unsigned swept = 0, groups_done = 0;
+  const int64_t n_super = (n_tiles + kSuper - 1) / kSuper;
+  for (int64_t s0 = 0; s0 < n_super; s0 += 64) {
+    // 64 super-boxes at a time, one per lane
+    const int64_t sk = s0 + lane;
+    float sb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (sk < n_super) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sb[a] = super_box[sk * 6 + a];
+    }
+    unsigned long long smask = __ballot(!(box_box_d2(sb, sb + 3, slo, shi) * kShrink > R));
+    while (smask) {
+      const int sl = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      {
+        const float lb = box_point_d2(lane_value(sb[0], sl), lane_value(sb[1], sl), lane_value(sb[2], sl), lane_value(sb[3], sl),
+                                      lane_value(sb[4], sl), lane_value(sb[5], sl), sx, sy, sz) * kShrink;
+        if (!__any(act && !(lb > best))) continue;
+      }
+      // its 16 tiles, one per lane
+      const int64_t tile_l = (s0 + sl) * kSuper + (lane & (kSuper - 1));
+      float tb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (lane < kSuper && tile_l < n_tiles) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) tb[a] = tile_box[tile_l * 6 + a];
+      }
+      unsigned long long tmask = __ballot(lane < kSuper && !(box_box_d2(tb, tb + 3, slo, shi) * kShrink > R));
+      while (tmask) {
+        const int tl = __ffsll((long long)tmask) - 1;
+        tmask &= tmask - 1;
+        {
+          const float lb = box_point_d2(lane_value(tb[0], tl), lane_value(tb[1], tl), lane_value(tb[2], tl), lane_value(tb[3], tl),
+                                        lane_value(tb[4], tl), lane_value(tb[5], tl), sx, sy, sz) * kShrink;
+          if (!__any(act && !(lb > best))) continue;
+        }
+        ++swept;
+        const int64_t tile = (s0 + sl) * kSuper + tl;
+        // its 32 groups, one per lane (the upper half of the wave mirrors the lower: harmless)
+        const int gl = lane & (kTile / kGroup - 1);
+        float gb[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) gb[a] = group_box[(tile * (kTile / kGroup) + gl) * 6 + a];
+        unsigned long long gmask = __ballot(lane < kTile / kGroup && !(box_box_d2(gb, gb + 3, slo, shi) * kShrink > R));
+        while (gmask) {
+          const int g = __ffsll((long long)gmask) - 1;
+          gmask &= gmask - 1;
+          {
+            const float lb = box_point_d2(lane_value(gb[0], g), lane_value(gb[1], g), lane_value(gb[2], g), lane_value(gb[3], g),
+                                          lane_value(gb[4], g), lane_value(gb[5], g), sx, sy, sz) * kShrink;
+            if (!__any(act && !(lb > best))) continue;
+          }
+          ++groups_done;
+          const uint32_t group = (uint32_t)(tile * (kTile / kGroup) + g);
+          const float4 mine = tgt4[(int64_t)group * kGroup + (lane & (kGroup - 1))];   // lane t (and t + 32) holds target t
+          float gmin = INFINITY;
+#pragma unroll
+          for (int t = 0; t < kGroup; ++t) {
+            const float dx = sx - lane_value(mine.x, t), dy = sy - lane_value(mine.y, t), dz = sz - lane_value(mine.z, t);
+            gmin = fminf(gmin, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+          }
+          if (gmin < best) {
+            best = gmin;
+            best_group = group;
+            tie_idx = 0xffffffffu;
+          } else if (gmin == best && best_group != group && gmin < INFINITY) {
+            // the same minimum in another group (rare): original-index order decides -- the lowest original index among this
+            // group's equal targets is noted now (as in nn_cull_kernel)
+            const float4* gp = tgt4 + (int64_t)group * kGroup;
+            for (int k = 0; k < kGroup; ++k) {
+              const float4 p = gp[k];
+              const float dx = sx - p.x, dy = sy - p.y, dz = sz - p.z;
+              if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) == best && __float_as_uint(p.w) < tie_idx) tie_idx = __float_as_uint(p.w);
+            }
+          }
+          R = wave_max(act ? best : 0.f);   // bounds only shrink: the filters above stay valid, the later ones get tighter
+        }
+      }
+    }
+  }
+  // epilogue: exactly nn_cull_kernel's (S = 1, plain xyz sources)
+  double acc[r3d_icp::kSums];
+  if (partials) {
+#pragma unroll
+    for (int k = 0; k < r3d_icp::kSums; ++k) acc[k] = 0.0;
+  }
+  if (ok) {
+    const int64_t g0 = (int64_t)best_group * kGroup;
+    uint32_t found = 0xffffffffu;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    for (int k = 0; k < kGroup; ++k) {
+      const float4 p = tgt4[g0 + k];
+      const float dx = sx - p.x, dy = sy - p.y, dz = sz - p.z;
+      const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      if (d == best && __float_as_uint(p.w) < found) {
+        found = __float_as_uint(p.w);
+        qx = p.x; qy = p.y; qz = p.z;
+      }
+    }
+    if (tie_idx < found) {
+      found = tie_idx;
+      const P3 q = reinterpret_cast<const P3*>(tgt_orig)[found];
+      qx = q.x; qy = q.y; qz = q.z;
+    }
+    if (!(best < INFINITY) || found == 0xffffffffu) {
+      idx_out[i] = 0u;
+      if (d2_out) d2_out[i] = INFINITY;
+    } else {
+      idx_out[i] = found;
+      if (d2_out) d2_out[i] = best;
+      if (partials && !(max_d2 >= 0.f && !(best <= max_d2))) {
+        const double p3[3] = {(double)sx, (double)sy, (double)sz};
+        const double q3[3] = {(double)qx, (double)qy, (double)qz};
+        r3d_icp::pair_accumulate(acc, r3d_icp::pair_weight(best, dead_zone), p3, q3);
+      }
+    }
+  }
+  if (partials) {
+    __shared__ double red[kThreads / 64][r3d_icp::kSums];
+    r3d_icp::block_reduce_store(acc, red, partials + (int64_t)blockIdx.x * r3d_icp::kSums);
+  }
+  if (lane == 0 && stats) {
+    atomicAdd(&stats[0], (unsigned long long)swept);   // tiles opened, per wave here (per workgroup in nn_cull_kernel)
+    atomicAdd(&stats[1], (unsigned long long)groups_done);
+  }
+}
+
 int bits_for(int64_t n) {
   int b = 1;
   while (((int64_t)1 << b) < n) ++b;
@@ -624,7 +816,7 @@ int r3d_nn_index_rebuild(r3d_nn_index* ix, const float* d_tgt, int64_t n_tgt) {
 
 static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
                                int presorted, int64_t* h_tiles_swept, bool want_sums, float max_d2, float dead_zone,
-                               double* d_sums_out, int with_scale = 0, double* d_state = nullptr) {
+                               double* d_sums_out, int with_scale = 0, double* d_state = nullptr, int small_motion = 0) {
   R3D_REQUIRE(ix != nullptr, "nn index is NULL");
   r3d_ctx* ctx = ix->ctx;
   int rc = r3d_ctx_enter(ctx);
@@ -660,6 +852,7 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   const int64_t per_block = (int64_t)kThreads * S;
   const unsigned blocks = (unsigned)((n_src + per_block - 1) / per_block);
   double* partials = nullptr;
+  int n_rows = (int)blocks;
   if (want_sums) {
     void* pv = nullptr;
     if ((rc = r3d_scratch(ctx, 4, (size_t)blocks * r3d_icp::kSums * sizeof(double), &pv))) return rc;
@@ -679,7 +872,22 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
                      (const float*)ix->d_frame, ix->axis_bits, ix->d_tgt4, ix->n, ix->n_tiles, ix->d_tile_box,         \
                      ix->d_sub_box, ix->d_group_box, ix->d_super_box, ix->d_tile_code, (const float*)ix->d_tgt, d_idx_out, d_d2_out,     \
                      h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone, warm)
-  if (presorted) {
+  // Which kernel: the bounds always help nn_cull_kernel (never slower than the cold walk); the wave-local kernel wins big when
+  // the bounds are TIGHT (the sources moved by one ICP step since the matches were made: the loops say so with small_motion)
+  // and loses when they are not (a jump to another start pose: each wave would scan group after group on its own).
+  if (warm && ctx->nn_warm != 2 && (small_motion || ctx->nn_warm == 3)) {
+    // (the partial rows are per 256 sources there as here: S is 1)
+    const unsigned wblocks = (unsigned)((n_src + kThreads - 1) / kThreads);
+    if (want_sums) {
+      void* pv = nullptr;
+      if ((rc = r3d_scratch(ctx, 4, (size_t)wblocks * r3d_icp::kSums * sizeof(double), &pv))) return rc;
+      partials = static_cast<double*>(pv);
+    }
+    hipLaunchKernelGGL(nn_warm_kernel, dim3(wblocks), dim3(kThreads), 0, st, d_src, n_src, ix->d_tgt4, ix->n, ix->n_tiles,
+                       ix->d_tile_box, ix->d_group_box, ix->d_super_box, (const float*)ix->d_tgt, d_idx_out, d_d2_out,
+                       h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone, warm);
+    n_rows = (int)wblocks;
+  } else if (presorted) {
     if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
     else if (S == 2) R3D_LAUNCH_CULL(2, false, d_src);
     else R3D_LAUNCH_CULL(4, false, d_src);
@@ -691,7 +899,7 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
 #undef R3D_LAUNCH_CULL
   R3D_HIP(hipGetLastError());
   if (want_sums &&
-      (rc = r3d_icp_sums_finish(ctx, partials, (int)blocks, d_sums_out, with_scale, d_state)))
+      (rc = r3d_icp_sums_finish(ctx, partials, n_rows, d_sums_out, with_scale, d_state)))
     return rc;
   if (h_tiles_swept) {
     unsigned long long v[2] = {0, 0};
@@ -724,9 +932,15 @@ int r3d_nn_index_target(r3d_nn_index* ix, const float** d_tgt, int64_t* n_tgt, r
 }
 
 int r3d_nn_index_query_solve(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                             float max_d2, double* d_sums_out, int with_scale, double* d_state) {
+                             float max_d2, double* d_sums_out, int with_scale, double* d_state, int small_motion) {
   return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, 1, nullptr, true, max_d2, 0.f, d_sums_out, with_scale,
-                             d_state);
+                             d_state, small_motion);
+}
+
+int r3d_nn_index_query_step(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
+                            int small_motion) {
+  return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, 1, nullptr, false, -1.f, 0.f, nullptr, 0, nullptr,
+                             small_motion);
 }
 
 extern "C" {

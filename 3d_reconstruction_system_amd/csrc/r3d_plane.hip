@@ -619,7 +619,7 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
   R3D_REQUIRE(ictx == ctx, "the index belongs to another context");
   for (int it = 0; it < n_iters; ++it) {
     // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud; rigid moves preserve it)
-    if ((rc = r3d_nn_index_query(index, d_src, n_src, d_idx, d_d2, 1, nullptr))) return rc;
+    if ((rc = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, it > 0))) return rc;
     if ((rc = plane_sums_impl(ctx, d_src, n_src, d_tgt, d_tgt_normals, n_tgt, d_idx, d_d2, max_d2, trim_q, gate_scale, nullptr,
                               d_state)))
       return rc;

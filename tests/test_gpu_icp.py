@@ -106,9 +106,15 @@ def test_index_query_unsorted_sources_and_permutation(icp, ctx):
     perm = d_perm.download(np.uint32, src.shape[0])
     assert sorted(perm.tolist()) == list(range(src.shape[0]))
     np.testing.assert_array_equal(d_src.download(np.float32, src.size).reshape(-1, 3), src[perm])
-    swept = ix.query(d_src.ptr, src.shape[0], d_idx.ptr, d_d2.ptr, want_stats=True, presorted=True)
+    ctx.set_tuning("nn_warm", 1)          # the statistic below is the cold walk's (tiles staged per workgroup)
+    try:
+        swept = ix.query(d_src.ptr, src.shape[0], d_idx.ptr, d_d2.ptr, want_stats=True, presorted=True)
+    finally:
+        ctx.set_tuning("nn_warm", 0)
     np.testing.assert_array_equal(d_idx.download(np.uint32, src.shape[0]), want_i[perm])
     assert swept < 0.6 * (-(-src.shape[0] // 256)) * (-(-tgt.shape[0] // 1024))   # 30 tiles only: culling is modest here
+    ix.query(d_src.ptr, src.shape[0], d_idx.ptr, d_d2.ptr, presorted=True)      # and once more, warm: same answer
+    np.testing.assert_array_equal(d_idx.download(np.uint32, src.shape[0]), want_i[perm])
     ix.close()
     for b in (d_tgt, d_src, d_idx, d_d2, d_perm):
         b.free()
@@ -675,8 +681,10 @@ def _warm_vs_cold(icp, ctx, tgt, src_steps, poison=None):
     d_tgt = ctx.alloc(tgt.nbytes).upload(tgt)
     d_src = ctx.alloc(n * 12)
     out = {}
-    for mode in ("cold", "warm"):
-        ctx.set_tuning("nn_warm", 1 if mode == "cold" else 0)
+    for mode in ("cold", "warm", "warm_wave"):
+        # 0: as the library decides (outside an ICP loop: the bounds in front of the LDS-tile kernel); 3: the wave-local kernel
+        # whenever there are bounds (what the loops use from their second iteration on)
+        ctx.set_tuning("nn_warm", {"cold": 1, "warm": 0, "warm_wave": 3}[mode])
         try:
             ix = icp.NNIndex(ctx, d_tgt.ptr, tgt.shape[0])
             d_idx, d_d2 = ctx.alloc(n * 4), ctx.alloc(n * 4)
@@ -693,27 +701,28 @@ def _warm_vs_cold(icp, ctx, tgt, src_steps, poison=None):
             d_d2.free()
         finally:
             ctx.set_tuning("nn_warm", 0)
-    for (ic, dc, _), (iw, dw, _) in zip(out["cold"], out["warm"]):
-        np.testing.assert_array_equal(iw, ic)
-        np.testing.assert_array_equal(dw.view(np.uint32), dc.view(np.uint32))
+    for form in ("warm", "warm_wave"):
+        for (ic, dc, _), (iw, dw, _) in zip(out["cold"], out[form]):
+            np.testing.assert_array_equal(iw, ic)
+            np.testing.assert_array_equal(dw.view(np.uint32), dc.view(np.uint32))
     d_tgt.free()
     d_src.free()
-    return out["cold"][-1], out["warm"][-1]
+    return out["cold"][-1], out["warm_wave"][-1]
 
 
-def test_warm_started_search_is_bit_identical_and_sweeps_fewer_tiles(icp, ctx):
+def test_warm_started_search_is_bit_identical(icp, ctx):
     """an ICP-like sequence: the sources creep towards the targets; every step's warm result equals the cold one and the
-    oracle's, and the warm search visits fewer tiles"""
+    oracle's (the sweep counters are not comparable: per workgroup in the cold kernel, per wave in the warm one)"""
     rng = np.random.default_rng(77)
-    tgt = (rng.random((200000, 3)) * 20).astype(np.float32)
-    base = tgt[rng.permutation(200000)[:60000]]
+    tgt = (rng.random((80000, 3)) * 20).astype(np.float32)
+    base = tgt[rng.permutation(80000)[:20000]]
     base = base[np.lexsort((base[:, 2] // 2, base[:, 1] // 2, base[:, 0] // 2))]       # spatially coherent order
     steps = [(base * np.float32(1.0 + 0.01 / (k + 1)) + np.float32(0.05 / (k + 1))).astype(np.float32) for k in range(4)]
     (ic, dc, swept_c), (iw, dw, swept_w) = _warm_vs_cold(icp, ctx, tgt, steps)
     oi, od = OI.nearest_neighbours(steps[-1], tgt)
     np.testing.assert_array_equal(iw, oi)
     np.testing.assert_allclose(dw, od, rtol=2e-7)
-    assert swept_w < 0.7 * swept_c, (swept_w, swept_c)
+    assert swept_c > 0 and swept_w > 0
 
 
 def test_warm_start_ignores_what_the_index_buffer_holds(icp, ctx):

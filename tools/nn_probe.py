@@ -17,7 +17,7 @@ ctx = r3d.Context(0)
 
 
 def probe(name, dev, n, m):
-    for mode, knob in (("cold", 1), ("warm", 0)):
+    for mode, knob in (("cold", 1), ("warm bound, LDS kernel", 2), ("warm, wave-local kernel", 3)):
         ctx.set_tuning("nn_warm", knob)
         dev.nn()
         ctx.sync()
@@ -28,7 +28,7 @@ def probe(name, dev, n, m):
             ts.append(ctx.timer_stop())
         swept = dev.index.query(dev.d_src.ptr, dev.n, dev.d_idx.ptr, dev.d_d2.ptr, want_stats=True, presorted=True)
         wgs = -(-n // 256)
-        print("%-28s %s: %.1f us (min %.1f), %.2f tile sweeps per workgroup (%d workgroups, %d tiles)"
+        print("%-28s %-24s: %.1f us (min %.1f), %.2f tiles opened per 256 sources (%d x 256 sources, %d tiles)"
               % (name, mode, sorted(ts)[10] * 1e3, min(ts) * 1e3, swept / wgs, wgs, -(-m // 1024)), flush=True)
     ctx.set_tuning("nn_warm", 0)
 

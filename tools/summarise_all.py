@@ -26,6 +26,7 @@ ALGO = {
     "fuse_rgb_kernel<unsigned char, true>": ("fused + colour, u8 depth + rgb -> f32 xyz + rgba", N_C2 * 20),
     "apply_lane_kernel<float, false>": ("apply-T 4x4, f32 -> f32", N_C2 * 24),
     "nn_cull_kernel<1, false>": ("culled exact NN + fused 18 sums, 500k x 500k (min bytes 12(N+M)+8N)", 500000 * (24 + 8)),
+    "nn_warm_kernel": ("the same search started from the previous matches' distances (wave-local, no LDS), 500k x 500k", 500000 * (24 + 8 + 4)),
     "voxel_insert_kernel<true, false>": ("voxel insert of the C2 cloud (12 B/point read; scattered 8-B atomics)", N_C2 * 12),
     "fuse_voxel_kernel<unsigned char, true, false>": ("cloud + occupied voxels of the C2 frames in one launch (13 B/point; random depth: ~1 voxel per point, "
                                                       "the atomics' worst case)", N_C2 * 13),
