@@ -89,17 +89,15 @@ __global__ __launch_bounds__(kThreads) void nn_kernel(const float* __restrict__ 
         const float4 Z = reinterpret_cast<const float4*>(tz)[g * (kGroup / 4) + q];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          float dx, dy, dz;
-          dx = sx[s] - X.x; dy = sy[s] - Y.x; dz = sz[s] - Z.x;
-          const float d0 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          dx = sx[s] - X.y; dy = sy[s] - Y.y; dz = sz[s] - Z.y;
-          const float d1 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          dx = sx[s] - X.z; dy = sy[s] - Y.z; dz = sz[s] - Z.z;
-          const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          dx = sx[s] - X.w; dy = sy[s] - Y.w; dz = sz[s] - Z.w;
-          const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          gmin[s] = fminf(fminf(gmin[s], d0), d1);  // v_min3_f32
-          gmin[s] = fminf(fminf(gmin[s], d2), d3);
+          // two targets per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32): the same IEEE operations as one at a time
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 px = {sx[s], sx[s]}, py = {sy[s], sy[s]}, pz = {sz[s], sz[s]};
+          const f32x2 ax = px - f32x2{X.x, X.y}, ay = py - f32x2{Y.x, Y.y}, az = pz - f32x2{Z.x, Z.y};
+          const f32x2 bx = px - f32x2{X.z, X.w}, by = py - f32x2{Y.z, Y.w}, bz = pz - f32x2{Z.z, Z.w};
+          const f32x2 da = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+          const f32x2 db = __builtin_elementwise_fma(bz, bz, __builtin_elementwise_fma(by, by, bx * bx));
+          gmin[s] = fminf(fminf(gmin[s], da.x), da.y);  // v_min3_f32
+          gmin[s] = fminf(fminf(gmin[s], db.x), db.y);
         }
       }
 #pragma unroll

@@ -59,6 +59,8 @@ constexpr int kSub = 256;  // targets per sub-tile (wave-level culling inside a 
 constexpr int kSuper = 16;  // tiles per super-box (workgroup-level culling of 16 tiles at once)
 constexpr float kShrink = 1.0f - 16.0f * 5.9604645e-8f;  // (1 - 16u): makes the box bound a strict lower bound
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct __attribute__((packed, aligned(4))) P3 {
   float x, y, z;
 };
@@ -406,17 +408,14 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
           const float4 Z = reinterpret_cast<const float4*>(tz)[g * (kGroup / 4) + q];
 #pragma unroll
           for (int s = 0; s < S; ++s) {
-            float dx, dy, dz;
-            dx = sx[s] - X.x; dy = sy[s] - Y.x; dz = sz[s] - Z.x;
-            const float d0 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            dx = sx[s] - X.y; dy = sy[s] - Y.y; dz = sz[s] - Z.y;
-            const float d1 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            dx = sx[s] - X.z; dy = sy[s] - Y.z; dz = sz[s] - Z.z;
-            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            dx = sx[s] - X.w; dy = sy[s] - Y.w; dz = sz[s] - Z.w;
-            const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            gmin[s] = fminf(fminf(gmin[s], d0), d1);
-            gmin[s] = fminf(fminf(gmin[s], d2), d3);
+            // two targets per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32): the same IEEE operations, the same bits
+            const f32x2 px = {sx[s], sx[s]}, py = {sy[s], sy[s]}, pz = {sz[s], sz[s]};
+            const f32x2 ax = px - f32x2{X.x, X.y}, ay = py - f32x2{Y.x, Y.y}, az = pz - f32x2{Z.x, Z.y};
+            const f32x2 bx = px - f32x2{X.z, X.w}, by = py - f32x2{Y.z, Y.w}, bz = pz - f32x2{Z.z, Z.w};
+            const f32x2 da = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+            const f32x2 db = __builtin_elementwise_fma(bz, bz, __builtin_elementwise_fma(by, by, bx * bx));
+            gmin[s] = fminf(fminf(gmin[s], da.x), da.y);
+            gmin[s] = fminf(fminf(gmin[s], db.x), db.y);
           }
         }
 #pragma unroll
@@ -504,6 +503,10 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(const void* __restric
 // v_readlane, no reload); a group that passes is fetched with ONE coalesced load (lane t holds target t) and its 32 targets
 // are broadcast by v_readlane.  Same candidates-or-better than the cold walk, same `<` / tie rule, same epilogue: the
 // results are the cold search's bit for bit (tests/test_gpu_icp.py::test_warm_*).
+// Measured (tools/nn_probe.py, sources unmoved since the previous query): two 480x640 views 349 us cold, 179 with the bounds in
+// front of nn_cull_kernel, 103 here; C3's 500k x 500k 468 / 432 / 230.  Requesting the surviving groups' targets four at a time
+// and the next tile's group boxes ahead (to shorten a lone wave's chain of memory round trips) made it SLOWER (114 / 243): the
+// kernel is bound by the ~350 vector instructions of a group evaluation, not by those waits.
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
@@ -614,11 +617,17 @@ __global__ __launch_bounds__(kThreads) void nn_warm_kernel(const float* __restri
           ++groups_done;
           const uint32_t group = (uint32_t)(tile * (kTile / kGroup) + g);
           const float4 mine = tgt4[(int64_t)group * kGroup + (lane & (kGroup - 1))];   // lane t (and t + 32) holds target t
+          // two targets per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: the same IEEE operations as the scalar form, so the
+          // distances are the cold kernel's bits)
           float gmin = INFINITY;
+          const f32x2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
 #pragma unroll
-          for (int t = 0; t < kGroup; ++t) {
-            const float dx = sx - lane_value(mine.x, t), dy = sy - lane_value(mine.y, t), dz = sz - lane_value(mine.z, t);
-            gmin = fminf(gmin, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+          for (int t = 0; t < kGroup; t += 2) {
+            const f32x2 X = {lane_value(mine.x, t), lane_value(mine.x, t + 1)}, Y = {lane_value(mine.y, t), lane_value(mine.y, t + 1)},
+                        Z = {lane_value(mine.z, t), lane_value(mine.z, t + 1)};
+            const f32x2 dx = sx2 - X, dy = sy2 - Y, dz = sz2 - Z;
+            const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            gmin = fminf(fminf(gmin, d.x), d.y);
           }
           if (gmin < best) {
             best = gmin;
