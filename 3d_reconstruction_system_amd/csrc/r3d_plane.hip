@@ -7,7 +7,7 @@
 //                          differences of the four raster neighbours, fp64 cross product; raster borders, missing depth
 //                          and depth jumps give the zero vector = "no plane here" (HBM-bound: 12 B read + 12 B written)
 //   plane_residual_kernel  r^2 = (n . (p - q))^2 per matched pair, +inf for pairs that cannot take part
-//   select_*               exact order statistic of an fp32 array by a three-pass 11/11/10-bit radix histogram, all on
+//   select_*               exact order statistic of an fp32 array per class: four passes of 8-bit digits (LDS counts + a pick launch), all on
 //                          the GPU (rank trimming needs the q-quantile of r^2 every iteration; no D2H, no host sort)
 //   plane_accumulate_kernel the 29 fp64 sums of the linearised normal equations over the kept pairs: per-lane
 //                          accumulators -> wave shuffle tree -> LDS across waves -> one row per workgroup
@@ -80,13 +80,16 @@ __global__ __launch_bounds__(kThreads) void normals_kernel(const float* __restri
 // ---- exact order statistics of an fp32 array, per bucket ---------------------------------------------------------
 // Every element belongs to one of n_buckets classes (bucket[i]; NULL = contiguous blocks of per_class elements, or one
 // class).  Per class: the element of rank floor(q (m - 1)) among its m finite values.  Four passes over the keys' 8-bit
-// digits, most significant first, ONE launch per pass: every workgroup counts its elements into an LDS histogram of all
-// classes (32 x 256 counters), adds its non-zero counters to the global one, and the workgroup that finishes LAST (a
-// ticket) picks every class's digit -- a wave per class, four bins per lane, one shuffle scan -- narrows the prefixes and
-// clears the histogram for the next pass.
-// (Round 3 until late: three passes of 11 / 11 / 10 bits, counters straight in HBM -- the residuals of one wall fall into a
-// handful of bins, so every wave of the grid wanted the same few words: 38 us per pass for 300k values even with one atomic
-// per distinct counter per wave -- plus a pick launch per pass: a third of a point-to-plane iteration.)
+// digits, most significant first; per pass a COUNT launch -- every workgroup counts its elements into an LDS histogram of all
+// classes (32 x 256 counters) and adds its non-zero counters to the global one -- and a PICK launch: one workgroup, a wave
+// per class, four bins per lane, one shuffle scan; it narrows the prefixes and clears the histogram for the next pass.
+// Per pass on a 300k-value array of 24 classes (rocprofv3, tools/plane_once.py), in the order they were tried in round 3:
+//   11 / 11 / 10-bit digits, counters straight in HBM (every wave of the grid wants the same few words) + pick   37.8 + 5.2 us  (x 3)
+//   8-bit digits in LDS, the workgroup that finishes LAST (fence + ticket) picks: one launch per pass              21.2 us       (x 4)
+//   all four passes in one launch, the last arriver picks and publishes, the others poll (bounded)                 104 - 127 us in all
+//   8-bit digits in LDS + a pick launch: no fence anywhere                                                         7.4 + 6.4 us  (x 4)  <- this
+// An agent-scope release / acquire pair inside a kernel has to make the eight XCDs' L2 caches agree; a kernel boundary does
+// that anyway.  The "last workgroup done" idiom costs more than the launch it saves on this chip.
 constexpr int kBins = 256;
 constexpr int kSelectPasses = 4;
 constexpr int kMaxBuckets = 32;
@@ -101,25 +104,13 @@ __device__ __forceinline__ unsigned order_key(float f) {
   return (u >> 31) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __restrict__ v, const unsigned char* __restrict__ bucket,
-                                                               int64_t per_class, int64_t n, int n_buckets, int pass, double q,
-                                                               unsigned* hist, unsigned long long* state, unsigned* ticket,
-                                                               SelectOut* __restrict__ out_all) {
-  __shared__ unsigned local[kMaxBuckets * kBins];
-  __shared__ unsigned s_prefix[kMaxBuckets], s_mask[kMaxBuckets];
-  __shared__ int s_last;
-  const int shift = 8 * (kSelectPasses - 1 - pass);
-  const int n_slots = n_buckets * kBins;
-  for (int b = threadIdx.x; b < n_slots; b += kThreads) local[b] = 0;
-  if (threadIdx.x < n_buckets) {
-    s_prefix[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 1];
-    s_mask[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 2];
-  }
-  __syncthreads();
+// counts this workgroup's elements of one pass into the LDS histogram `local` (zeroed, n_buckets x 256)
+__device__ __forceinline__ void select_count(const float* __restrict__ v, const unsigned char* __restrict__ bucket, int64_t per_class,
+                                             int64_t n, int n_buckets, int shift, const unsigned* s_prefix, const unsigned* s_mask,
+                                             unsigned* local) {
   const int lane = threadIdx.x & 63;
   // whole waves stay in the loop together (the aggregation below votes across the wave); four elements per lane are
-  // requested before the first is counted (one memory round trip per four instead of one each: the votes keep the compiler
-  // from overlapping the iterations by itself)
+  // requested before the first is counted
   constexpr int kAhead = 4;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i0 = (int64_t)blockIdx.x * kThreads + (threadIdx.x & ~63); i0 < n; i0 += stride * kAhead) {
@@ -157,29 +148,29 @@ __global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __re
       if (live) atomicAdd(&local[slot], 1u);
     }
   }
-  __syncthreads();
-  for (int b = threadIdx.x; b < n_slots; b += kThreads)
-    if (local[b]) atomicAdd(&hist[b], local[b]);
-  // the last workgroup to get here sees every other one's counters (release by the fence, acquire by the ticket)
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const int wave = threadIdx.x >> 6;
+}
+
+// One workgroup, every class (a wave per class, four bins per lane, one shuffle scan): the digit that holds the wanted rank,
+// the narrowed prefix, after the last pass the value.  Everything it reads was written by OTHER workgroups (this launch or the
+// previous one): agent-scope loads, past this CU's L1.  clear: zero the histogram afterwards (it is reused by the next pass).
+__device__ __forceinline__ void select_pick_all(unsigned* hist, unsigned long long* state, SelectOut* __restrict__ out_all,
+                                                int n_buckets, int pass, double q, bool clear) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int shift = 8 * (kSelectPasses - 1 - pass);
   const int last = pass == kSelectPasses - 1;
   // every class of this wave is requested before the first is scanned (a wave has up to eight classes: eight dependent L2
   // round trips otherwise)
   constexpr int kWaves = kThreads / 64, kPerWave = kMaxBuckets / kWaves;
   unsigned cnt_all[kPerWave][4];
+  unsigned long long st_all[kPerWave][4];
 #pragma unroll
   for (int j = 0; j < kPerWave; ++j) {
     const int c = wave + j * kWaves;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-      cnt_all[j][m] = c < n_buckets ? __hip_atomic_load(&hist[(size_t)c * kBins + lane * 4 + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : 0u;   // (agent scope: past this CU's L1)
+    for (int m = 0; m < 4; ++m) {
+      cnt_all[j][m] = c < n_buckets ? __hip_atomic_load(&hist[(size_t)c * kBins + lane * 4 + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      st_all[j][m] = c < n_buckets ? __hip_atomic_load(&state[(size_t)c * 4 + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
   }
 #pragma unroll
   for (int j = 0; j < kPerWave; ++j) {
@@ -209,9 +200,9 @@ __global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __re
       k = (unsigned long long)r;
       if (total > 0 && k > total - 1) k = total - 1;
     } else {
-      k = st[0];
+      k = st_all[j][0];
     }
-    const unsigned long long old_prefix = st[1], old_mask = st[2], old_count = st[3];
+    const unsigned long long old_prefix = st_all[j][1], old_mask = st_all[j][2], old_count = st_all[j][3];
     if (total > 0) {
       unsigned long long before = inc - mine;
       if (k >= before && k < before + mine) {   // exactly one lane
@@ -244,10 +235,35 @@ __global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __re
         out_all[c].count = 0;
       }
     }
+    if (clear) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) h[lane * 4 + m] = 0;
+      for (int m = 0; m < 4; ++m) h[lane * 4 + m] = 0;
+    }
   }
-  if (threadIdx.x == 0) *ticket = 0;
+}
+
+__global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __restrict__ v, const unsigned char* __restrict__ bucket,
+                                                               int64_t per_class, int64_t n, int n_buckets, int pass,
+                                                               unsigned* hist, const unsigned long long* __restrict__ state) {
+  __shared__ unsigned local[kMaxBuckets * kBins];
+  __shared__ unsigned s_prefix[kMaxBuckets], s_mask[kMaxBuckets];
+  const int n_slots = n_buckets * kBins;
+  for (int b = threadIdx.x; b < n_slots; b += kThreads) local[b] = 0;
+  if (threadIdx.x < n_buckets) {
+    s_prefix[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 1];
+    s_mask[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 2];
+  }
+  __syncthreads();
+  select_count(v, bucket, per_class, n, n_buckets, 8 * (kSelectPasses - 1 - pass), s_prefix, s_mask, local);
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_slots; b += kThreads)
+    if (local[b]) atomicAdd(&hist[b], local[b]);
+}
+
+// one workgroup: every class's digit from the counters the pass kernel left (the kernel boundary publishes them)
+__global__ __launch_bounds__(kThreads) void select_pick_kernel(unsigned* hist, unsigned long long* state, SelectOut* __restrict__ out_all,
+                                                               int n_buckets, int pass, double q) {
+  select_pick_all(hist, state, out_all, n_buckets, pass, q, true);
 }
 
 // ---- point-to-plane pairs ----------------------------------------------------------------------------------
@@ -411,9 +427,11 @@ int select_enqueue(r3d_ctx* ctx, const float* d_values, const unsigned char* d_b
   R3D_HIP(hipMemsetAsync(ws.hist, 0, ws.clear_bytes, st));
   int blocks = (int)std::min<int64_t>((n + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->num_cus);
   if (blocks < 1) blocks = 1;
-  for (int pass = 0; pass < kSelectPasses; ++pass)
-    hipLaunchKernelGGL(select_pass_kernel, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, per_class, n, n_buckets, pass, q,
-                       ws.hist, ws.state, ws.ticket, ws.out);
+  for (int pass = 0; pass < kSelectPasses; ++pass) {
+    hipLaunchKernelGGL(select_pass_kernel, dim3(blocks), dim3(kThreads), 0, st, d_values, d_bucket, per_class, n, n_buckets, pass,
+                       ws.hist, (const unsigned long long*)ws.state);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(kThreads), 0, st, ws.hist, ws.state, ws.out, n_buckets, pass, q);
+  }
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
@@ -453,8 +471,10 @@ __global__ __launch_bounds__(kThreads) void class_sum_below_kernel(const float* 
   }
 }
 
+// one workgroup per CU: every workgroup pays a 29-value fp64 tree reduction and leaves a row for plane_finish_kernel to read
+// (four per CU: accumulate 20 us + finish 19 us per iteration on a 307k-pair cloud, mostly those reductions)
 int accumulate_blocks(r3d_ctx* ctx, int64_t n_src) {
-  int blocks = (int)std::min<int64_t>((n_src + kThreads - 1) / kThreads, (int64_t)ctx->num_cus * 4);
+  int blocks = (int)std::min<int64_t>((n_src + kThreads - 1) / kThreads, (int64_t)ctx->num_cus);
   return blocks < 1 ? 1 : blocks;
 }
 
