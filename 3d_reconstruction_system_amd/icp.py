@@ -723,7 +723,7 @@ def organized_normals(xyz, height, width, max_jump=0.05, viewpoint=None, ctx=Non
 
 def select_quantile(d_values_ptr, n, q, ctx=None):
     """(value, count): the element of rank floor(q (m - 1)) of the m finite values of a DEVICE float32 array, selected on the
-    GPU (three histogram passes; 8 bytes come back)."""
+    GPU (four passes of 8-bit digits; 8 bytes come back)."""
     ctx = ctx or default_context()
     v, m = C.c_float(), C.c_int64()
     L.check(ctx.lib.r3d_select_quantile_f32(ctx.handle, d_values_ptr, int(n), float(q), C.byref(v), C.byref(m)))
