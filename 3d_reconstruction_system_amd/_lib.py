@@ -87,6 +87,8 @@ SIGNATURES = {
     "r3d_remap_u32": (_i, [_vp, _vp, _i64, _vp, _i64]),
     "r3d_nn_index_query": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "r3d_nn_index_sort_cloud": (_i, [_vp, _vp, _i64, _vp]),
+    "r3d_nn_index_sort_cloud_valid": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "r3d_cloud_zero_rows_to_nan": (_i, [_vp, _vp, _i64]),
     "r3d_icp_accumulate": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _vp]),
     "r3d_icp_accumulate_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp]),
     "r3d_nn_index_query_sums": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _f, _f, _vp]),

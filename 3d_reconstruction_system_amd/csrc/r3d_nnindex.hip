@@ -153,6 +153,40 @@ __global__ __launch_bounds__(kThreads) void keys_kernel(const float* __restrict_
   keys[i] = (point_code(p, frame, axis_bits) << idx_bits) | (uint64_t)i;
 }
 
+// the same keys, with every row that has a NaN / inf coordinate given a code ABOVE all codes (one more key bit): the stable sort
+// leaves such rows at the end, in their input order; valid rows are counted (one atomic per workgroup)
+__global__ __launch_bounds__(kThreads) void keys_valid_kernel(const float* __restrict__ xyz, int64_t n, const float* __restrict__ frame,
+                                                              int axis_bits, int idx_bits, uint64_t* __restrict__ keys,
+                                                              unsigned long long* __restrict__ n_valid) {
+  __shared__ unsigned wave_cnt[kThreads / 64];
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  bool valid = false;
+  if (i < n) {
+    const P3 p = reinterpret_cast<const P3*>(xyz)[i];
+    valid = (p.x - p.x == 0.f) && (p.y - p.y == 0.f) && (p.z - p.z == 0.f);
+    const uint64_t code = valid ? point_code(p, frame, axis_bits) : ((uint64_t)1 << (3 * axis_bits));
+    keys[i] = (code << idx_bits) | (uint64_t)i;
+  }
+  const unsigned c = (unsigned)__popcll(__ballot(valid));
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < kThreads / 64; ++w) t += wave_cnt[w];
+    if (t) atomicAdd(n_valid, (unsigned long long)t);
+  }
+}
+
+// rows that are exactly (0, 0, 0) -> (NaN, NaN, NaN): the "no depth" pixels of gentxtcord's clouds (p2c:34-44 emits them like any
+// other point) stop being points BEFORE a pose moves them somewhere plausible
+__global__ __launch_bounds__(kThreads) void zero_rows_to_nan_kernel(float* __restrict__ xyz, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  P3* P = reinterpret_cast<P3*>(xyz);
+  const P3 p = P[i];
+  if (p.x == 0.f && p.y == 0.f && p.z == 0.f) P[i] = P3{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+}
+
 // sorted keys -> float4 (x, y, z, original index); slots past n are padded with x = +inf so they never win
 __global__ __launch_bounds__(kThreads) void gather4_kernel(const float* __restrict__ xyz, const uint64_t* __restrict__ keys,
                                                            int64_t n, int64_t n_padded, int idx_bits, float4* __restrict__ out) {
@@ -965,25 +999,63 @@ __global__ __launch_bounds__(kThreads) void gather3_kernel(const float* __restri
   if (perm) perm[j] = i;
 }
 
-int r3d_nn_index_sort_cloud(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t* d_perm_out) {
+int r3d_cloud_zero_rows_to_nan(r3d_ctx* ctx, float* d_xyz, int64_t n) {
+  int rc = r3d_ctx_enter(ctx);
+  if (rc) return rc;
+  R3D_REQUIRE(n >= 0, "negative cloud size");
+  if (n == 0) return R3D_OK;
+  R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
+  hipLaunchKernelGGL(zero_rows_to_nan_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz, n);
+  R3D_HIP(hipGetLastError());
+  return R3D_OK;
+}
+
+static int sort_cloud_impl(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t* d_perm_out, int64_t* h_n_valid) {
   R3D_REQUIRE(ix != nullptr, "nn index is NULL");
   r3d_ctx* ctx = ix->ctx;
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(n >= 0 && n < ((int64_t)1 << 32), "bad cloud size");
+  if (h_n_valid) *h_n_valid = 0;
   if (n == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
   const int idx_bits = bits_for(n);
-  void *keys = nullptr, *tmp = nullptr, *copy = nullptr;
+  void *keys = nullptr, *tmp = nullptr, *copy = nullptr, *misc = nullptr;
   if ((rc = r3d_scratch(ctx, 0, (size_t)n * 8, &keys))) return rc;
   if ((rc = r3d_scratch(ctx, 2, (size_t)n * 8, &tmp))) return rc;
   if ((rc = r3d_scratch(ctx, 1, (size_t)n * 12, &copy))) return rc;
-  if ((rc = sorted_keys(ctx, d_xyz, n, ix->d_frame, ix->axis_bits, idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) return rc;
+  if (h_n_valid) {
+    if ((rc = r3d_scratch(ctx, 5, 64, &misc))) return rc;
+    R3D_HIP(hipMemsetAsync(misc, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(keys_valid_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                       (const float*)d_xyz, n, (const float*)ix->d_frame, ix->axis_bits, idx_bits, (uint64_t*)keys,
+                       (unsigned long long*)misc);
+    R3D_HIP(hipGetLastError());
+    // one more key bit than sorted_keys(): the "not a point" code
+    if ((rc = r3d_radix_sort_u64(ctx, (uint64_t*)keys, (uint64_t*)tmp, n, 3 * ix->axis_bits + 1 + idx_bits, idx_bits))) return rc;
+  } else if ((rc = sorted_keys(ctx, d_xyz, n, ix->d_frame, ix->axis_bits, idx_bits, (uint64_t*)keys, (uint64_t*)tmp))) {
+    return rc;
+  }
   R3D_HIP(hipMemcpyAsync(copy, d_xyz, (size_t)n * 12, hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(gather3_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
                      (const float*)copy, (const uint64_t*)keys, n, idx_bits, d_xyz, d_perm_out);
   R3D_HIP(hipGetLastError());
+  if (h_n_valid) {
+    unsigned long long v = 0;
+    R3D_HIP(hipMemcpyAsync(&v, misc, 8, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(hipStreamSynchronize(ctx->stream));
+    *h_n_valid = (int64_t)v;
+  }
   return R3D_OK;
+}
+
+int r3d_nn_index_sort_cloud(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t* d_perm_out) {
+  return sort_cloud_impl(ix, d_xyz, n, d_perm_out, nullptr);
+}
+
+int r3d_nn_index_sort_cloud_valid(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t* d_perm_out, int64_t* n_valid_out) {
+  R3D_REQUIRE(n_valid_out != nullptr, "n_valid_out is NULL");
+  return sort_cloud_impl(ix, d_xyz, n, d_perm_out, n_valid_out);
 }
 
 // rows first, first + step, ... of an xyz cloud

@@ -243,6 +243,13 @@ int r3d_nn_index_query(r3d_nn_index* index, const float* d_src, int64_t n_src, u
 /* Permutes an xyz cloud in place into the index's Morton order; d_perm_out (optional, [n] uint32) receives the original
  * position of every row.  Asynchronous on the ctx stream. */
 int r3d_nn_index_sort_cloud(r3d_nn_index* index, float* d_xyz, int64_t n_points, uint32_t* d_perm_out);
+/* The same, for a cloud that still holds rows which are no points: rows with a NaN / inf coordinate end up BEHIND the
+ * valid ones (in their input order), *n_valid_out = the number of valid rows in front (synchronous: it waits for the
+ * count).  With r3d_cloud_zero_rows_to_nan first -- the (0,0,0) rows gentxtcord emits for pixels without depth
+ * (pixel_to_camera.py:34-44) -- this replaces the host-side row filter in front of an ICP (4 ms of NumPy for 307k rows). */
+int r3d_nn_index_sort_cloud_valid(r3d_nn_index* index, float* d_xyz, int64_t n_points, uint32_t* d_perm_out,
+                                  int64_t* n_valid_out);
+int r3d_cloud_zero_rows_to_nan(r3d_ctx* ctx, float* d_xyz, int64_t n_points);
 /* r3d_icp_accumulate: the 18 fp64 sums Umeyama needs over the matched pairs (p=src[k], q=tgt[idx[k]]),
  * pairs with d2 > max_d2 skipped when max_d2 >= 0 (d_d2 may be NULL when max_d2 < 0):
  *   sums[0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p_a*q_b (a major), [16]=sum |p|^2, [17]=sum |q|^2.

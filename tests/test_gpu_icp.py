@@ -3,7 +3,9 @@ HIP NN / covariance sums / full loop against oracle/icp_ref.py and known-answer 
 import numpy as np
 import pytest
 
-from helpers import r3d as _r3d
+import importlib
+
+from helpers import PKG, r3d as _r3d
 from oracle import icp_ref as OI
 
 pytestmark = pytest.mark.gpu
@@ -767,4 +769,45 @@ def test_warm_start_is_dropped_when_the_index_is_rebuilt(icp, ctx):
     np.testing.assert_array_equal(d_idx.download(np.uint32, 8000), OI.nearest_neighbours(src, tgt_b)[0])
     ix.close()
     for b in (d_a, d_b, d_src, d_idx, d_d2):
+        b.free()
+
+
+def test_sort_cloud_valid_puts_non_points_last_and_counts(icp, ctx):
+    """r3d_cloud_zero_rows_to_nan + r3d_nn_index_sort_cloud_valid == the host-side row filter followed by sort_cloud: the same
+    rows in the same order in front, the count, a consistent permutation; rows that are no points behind them"""
+    rng = np.random.default_rng(91)
+    tgt = (rng.random((20000, 3)) * 10).astype(np.float32)
+    src = (rng.random((9001, 3)) * 12 - 1).astype(np.float32)
+    src[::5] = 0.0                                              # pixels without depth
+    src[3::17, 1] = np.nan
+    src[7::29, 2] = np.inf
+    src[11::31, 0] = -np.inf
+    src[13] = (0.0, 0.0, 1e-30)                                 # not a zero row
+    keep = np.isfinite(src).all(axis=1) & (src != 0).any(axis=1)
+    d_tgt = ctx.alloc(tgt.nbytes).upload(tgt)
+    ix = icp.NNIndex(ctx, d_tgt.ptr, tgt.shape[0])
+    # reference: host filter, then the plain sort
+    good = np.ascontiguousarray(src[keep])
+    d_good, d_perm_g = ctx.alloc(good.nbytes).upload(good), ctx.alloc(good.shape[0] * 4)
+    ix.sort_cloud(d_good.ptr, good.shape[0], d_perm_g.ptr)
+    want = d_good.download(np.float32, good.size).reshape(-1, 3)
+    # device: mark, sort with the non-points last, count
+    L_ = importlib.import_module(PKG + "._lib")
+    d_src, d_perm = ctx.alloc(src.nbytes).upload(src), ctx.alloc(src.shape[0] * 4)
+    L_.check(ctx.lib.r3d_cloud_zero_rows_to_nan(ctx.handle, d_src.ptr, src.shape[0]))
+    k = ix.sort_cloud_valid(d_src.ptr, src.shape[0], d_perm.ptr)
+    got = d_src.download(np.float32, src.size).reshape(-1, 3)
+    perm = d_perm.download(np.uint32, src.shape[0])
+    assert k == int(keep.sum()) == good.shape[0]
+    np.testing.assert_array_equal(got[:k].view(np.uint32), want.view(np.uint32))
+    assert sorted(perm.tolist()) == list(range(src.shape[0]))
+    np.testing.assert_array_equal(got[:k], src[perm[:k]])
+    assert not np.isfinite(got[k:]).all(axis=1).any()           # everything behind: no points
+    assert (np.diff(perm[k:].astype(np.int64)) > 0).all()       # ... in their input order
+    # nothing invalid: the count is n and the result is sort_cloud's
+    d_again = ctx.alloc(good.nbytes).upload(good)
+    assert ix.sort_cloud_valid(d_again.ptr, good.shape[0], None) == good.shape[0]
+    np.testing.assert_array_equal(d_again.download(np.float32, good.size).reshape(-1, 3).view(np.uint32), want.view(np.uint32))
+    ix.close()
+    for b in (d_tgt, d_good, d_perm_g, d_src, d_perm, d_again):
         b.free()
