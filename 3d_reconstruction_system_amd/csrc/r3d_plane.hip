@@ -391,32 +391,29 @@ __global__ __launch_bounds__(kThreads) void plane_finish_kernel(const double* __
   }
 }
 
-// workspace in scratch slot 6: [hist n_buckets x 256 u32][state n_buckets x 4 u64][ticket, 64 B][SelectOut x n_buckets][pad],
-// then the partial rows
+// workspace in scratch slot 6: [hist n_buckets x 256 u32][state n_buckets x 4 u64][SelectOut x n_buckets][pad], then the
+// partial rows
 struct Workspace {
   unsigned* hist;
   unsigned long long* state;
-  unsigned* ticket;
   SelectOut* out;
   double* rows;
-  size_t clear_bytes;   // hist + state + ticket
+  size_t clear_bytes;   // hist + state
 };
 
 int workspace(r3d_ctx* ctx, int n_buckets, int n_rows, Workspace* ws) {
   void* p = nullptr;
   const size_t hist_b = (size_t)n_buckets * kBins * sizeof(unsigned), state_b = (size_t)n_buckets * 4 * sizeof(unsigned long long);
-  const size_t ticket_b = 64;
-  const size_t head = hist_b + state_b + ticket_b + (size_t)n_buckets * sizeof(SelectOut) + 64;
+  const size_t head = hist_b + state_b + (size_t)n_buckets * sizeof(SelectOut) + 64;
   const size_t head_al = (head + 255) & ~(size_t)255;
   int rc = r3d_scratch(ctx, 6, head_al + (size_t)(n_rows + 1) * kSums * sizeof(double), &p);
   if (rc) return rc;
   char* c = static_cast<char*>(p);
   ws->hist = reinterpret_cast<unsigned*>(c);
   ws->state = reinterpret_cast<unsigned long long*>(c + hist_b);
-  ws->ticket = reinterpret_cast<unsigned*>(c + hist_b + state_b);
-  ws->out = reinterpret_cast<SelectOut*>(c + hist_b + state_b + ticket_b);
+  ws->out = reinterpret_cast<SelectOut*>(c + hist_b + state_b);
   ws->rows = reinterpret_cast<double*>(c + head_al);
-  ws->clear_bytes = hist_b + state_b + ticket_b;
+  ws->clear_bytes = hist_b + state_b;
   return R3D_OK;
 }
 
