@@ -200,6 +200,7 @@ int r3d_dev_free(r3d_ctx* ctx, void* d_ptr) {
 int r3d_memcpy_h2d(r3d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
+  if (d_dst == ctx->loop_src) ctx->loop_src = nullptr;   // (see r3d_ctx::loop_*)
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_dst && h_src, "NULL pointer with bytes > 0");
   R3D_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -218,6 +219,7 @@ int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
 int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
+  if (d_dst == ctx->loop_src) ctx->loop_src = nullptr;   // (see r3d_ctx::loop_*)
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_dst && d_src, "NULL pointer with bytes > 0");
   R3D_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -227,6 +229,7 @@ int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
 int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
+  if (d_dst == ctx->loop_src) ctx->loop_src = nullptr;   // (see r3d_ctx::loop_*)
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_dst != nullptr, "NULL pointer with bytes > 0");
   R3D_HIP(hipMemsetAsync(d_dst, byte_value, bytes, ctx->stream));

@@ -397,6 +397,7 @@ int r3d_icp_state_reset(r3d_ctx* ctx, double* d_state) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(d_state != nullptr, "d_state is NULL");
+  if (ctx->loop_state == d_state) ctx->loop_state = nullptr;   // a new loop starts here
   hipLaunchKernelGGL(icp_state_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, d_state);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
@@ -422,17 +423,25 @@ int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_s
   void* d_sums_v = nullptr;
   if ((rc = r3d_scratch(ctx, 3, kSums * sizeof(double), &d_sums_v))) return rc;
   double* d_sums = static_cast<double*>(d_sums_v);
+  const bool going_on = index && ctx->loop_state == d_state && ctx->loop_src == d_src && ctx->loop_idx == d_idx && ctx->loop_index == index;
   for (int it = 0; it < n_iters; ++it) {
     if (index) {
       // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud): no sort, sums fused
       // (the last kernel of the sums pass also solves the step and updates d_state)
-      if ((rc = r3d_nn_index_query_solve(index, d_src, n_src, d_idx, d_d2, max_d2, d_sums, with_scale, d_state, it > 0))) return rc;
+      if ((rc = r3d_nn_index_query_solve(index, d_src, n_src, d_idx, d_d2, max_d2, d_sums, with_scale, d_state, it > 0 || going_on)))
+        return rc;
     } else {
       if ((rc = r3d_icp_nn(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2))) return rc;
       if ((rc = accumulate_impl(ctx, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, max_d2, 0.f, d_sums, with_scale, d_state)))
         return rc;
     }
     if ((rc = r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32))) return rc;
+  }
+  if (index && n_iters > 0) {
+    ctx->loop_state = d_state;
+    ctx->loop_src = d_src;
+    ctx->loop_idx = d_idx;
+    ctx->loop_index = index;
   }
   return R3D_OK;
 }

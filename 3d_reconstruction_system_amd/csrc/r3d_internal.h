@@ -28,6 +28,10 @@ struct r3d_ctx {
   // staging a raster that IS cached costs 4 %.  Below ~8 MB the extra launch eats the gain.
   int fuse_stage_auto_mb = 8;
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
+  // the ICP loop that ran last on this ctx (r3d_icp_iterate / _plane): a call with the same state, source, match buffer and
+  // index and no state reset / write to that source through the library in between is the SAME loop going on -- its first
+  // iteration may start from the previous matches like every other one (nn_warm_kernel)
+  const void *loop_state = nullptr, *loop_src = nullptr, *loop_idx = nullptr, *loop_index = nullptr;
   int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances, ICP loops use
                           // nn_warm_kernel from their second iteration on; 1 off; 2 / 3: never / always nn_warm_kernel (A/B)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)

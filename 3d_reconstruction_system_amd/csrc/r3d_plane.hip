@@ -634,9 +634,11 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
   r3d_ctx* ictx = nullptr;
   if ((rc = r3d_nn_index_target(index, &d_tgt, &n_tgt, &ictx))) return rc;
   R3D_REQUIRE(ictx == ctx, "the index belongs to another context");
+  // the same loop going on (r3d_internal.h, r3d_ctx::loop_*): its first iteration starts from the previous matches too
+  const bool going_on = ctx->loop_state == d_state && ctx->loop_src == d_src && ctx->loop_idx == d_idx && ctx->loop_index == index;
   for (int it = 0; it < n_iters; ++it) {
     // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud; rigid moves preserve it)
-    if ((rc = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, it > 0))) return rc;
+    if ((rc = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, it > 0 || going_on))) return rc;
     if ((rc = plane_sums_impl(ctx, d_src, n_src, d_tgt, d_tgt_normals, n_tgt, d_idx, d_d2, max_d2, trim_q, gate_scale, nullptr,
                               d_state)))
       return rc;
@@ -647,6 +649,12 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
     else
       rc = r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32);
     if (rc) return rc;
+  }
+  if (n_iters > 0) {
+    ctx->loop_state = d_state;
+    ctx->loop_src = d_src;
+    ctx->loop_idx = d_idx;
+    ctx->loop_index = index;
   }
   return R3D_OK;
 }

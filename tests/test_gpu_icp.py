@@ -811,3 +811,43 @@ def test_sort_cloud_valid_puts_non_points_last_and_counts(icp, ctx):
     ix.close()
     for b in (d_tgt, d_good, d_perm_g, d_src, d_perm, d_again):
         b.free()
+
+
+def test_a_loop_continued_over_several_enqueues_equals_one_enqueue_bit_for_bit(icp, ctx):
+    """The loops run their later iterations -- and, when the same loop goes on in a further call (same state / source / match
+    buffers, no reset, no write to the source in between), its first -- on the warm-started wave-local search.  Whatever kernel
+    ran, the states must be the same bits: 2 + 2 + 2 iterations == 6; and a source moved between two calls ends the loop (the
+    next call searches from the bounds with the LDS kernel) without changing a bit either."""
+    src, tgt, _, _ = OI.synthetic_pair(n_tgt=60000, n_src=50000, s=1.01, angle_deg=0.5, t_norm=0.02, noise=0.005, seed=5)
+    one = icp.IcpDevice(src, tgt, ctx, True)
+    one.state_reset()
+    one.iterate(6)
+    parts = icp.IcpDevice(src, tgt, ctx, True)
+    parts.state_reset()
+    for _ in range(3):
+        parts.iterate(2)
+    a, b = one.state(), parts.state()
+    assert a["iterations"] == b["iterations"] == 6
+    np.testing.assert_array_equal(a["T_total"].view(np.uint64), b["T_total"].view(np.uint64))
+    np.testing.assert_array_equal(one.source().view(np.uint32), parts.source().view(np.uint32))
+    # cold every time (no bounds at all): still the same bits
+    ctx.set_tuning("nn_warm", 1)
+    try:
+        cold = icp.IcpDevice(src, tgt, ctx, True)
+        cold.state_reset()
+        cold.iterate(6)
+        np.testing.assert_array_equal(cold.state()["T_total"].view(np.uint64), a["T_total"].view(np.uint64))
+        cold.free()
+    finally:
+        ctx.set_tuning("nn_warm", 0)
+    # the source is moved by the caller between two calls: both devices the same way
+    T = np.eye(4)
+    T[:3, 3] = (0.3, -0.2, 0.1)
+    for d in (one, parts):
+        d.move_source(T)
+    one.iterate(4)
+    parts.iterate(1)
+    parts.iterate(3)
+    np.testing.assert_array_equal(one.source().view(np.uint32), parts.source().view(np.uint32))
+    one.free()
+    parts.free()
