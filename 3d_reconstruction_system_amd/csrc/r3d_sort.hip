@@ -1,4 +1,4 @@
-// LSD radix sort of 64-bit keys in HBM for gfx950 (MI355X): 8-bit digits, stable, three kernels per pass.
+// LSD radix sort of 64-bit keys in HBM for gfx950 (MI355X): 8-bit digits, stable, three launches per pass.
 //
 // Used by the voxel path (csrc/r3d_voxel.hip) to put the distinct 48-bit Morton codes in octree order on the
 // GPU instead of on the host.  HBM-bound: per pass 8 B/key read for the histogram, 8 B read + 8 B written by the
@@ -6,7 +6,7 @@
 //
 //   digit_histogram_kernel  tile of 4096 keys per workgroup -> 256-bin LDS histogram -> hist[bin][workgroup]
 //   digit_scan_kernel       one workgroup per bin: exclusive prefix over workgroups (contiguous chunk per thread, wave
-//                           shuffle scan, LDS across waves), bin totals; a final single-wave pass turns totals into bin bases
+//                           shuffle scan, LDS across waves), bin totals (the scatter turns them into bin bases itself)
 //   digit_scatter_kernel    re-reads the tile in 16 rounds of 256 keys; inside a round every lane finds the lanes of
 //                           its wave with the same digit by 8 ballots, the rank among them by popcount, waves are
 //                           ordered through a [4][256] LDS count table; destination = bin base + workgroup prefix +
@@ -69,26 +69,31 @@ __global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restri
   if (threadIdx.x == kThreads - 1) totals[blockIdx.x] = before;   // the last chunk ends at the row's total (empty chunks pass it on)
 }
 
-// one wave: totals[256] -> exclusive bases[256]
-__global__ __launch_bounds__(64) void bin_base_kernel(const uint32_t* __restrict__ totals, uint64_t* __restrict__ bases) {
-  const int lane = threadIdx.x;
-  uint64_t running = 0;
-  for (int b0 = 0; b0 < kBins; b0 += 64) {
-    const uint32_t v = totals[b0 + lane];
-    const uint32_t inc = wave_inclusive_scan(v, lane);
-    bases[b0 + lane] = running + inc - v;
-    running += __shfl(inc, 63, 64);
-  }
-}
-
 __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                                                                  const uint32_t* __restrict__ hist, int n_blocks,
-                                                                 const uint64_t* __restrict__ bases,
+                                                                 const uint32_t* __restrict__ totals,
                                                                  uint64_t* __restrict__ out) {
   __shared__ uint64_t dest[kBins];                // next free output slot of every bin for this workgroup
   __shared__ uint32_t cnt[kThreads / 64][kBins];  // per-wave digit counts of the current round
+  __shared__ uint64_t wave_total[kThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  dest[threadIdx.x] = bases[threadIdx.x] + hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
+  // bin bases = exclusive prefix of the 256 bin totals, computed here by every workgroup (a launch of its own for one wave's
+  // work cost more in launch latency than all workgroups repeating it: sorts of 0.3 - 0.5 M keys are launch-bound)
+  uint64_t bin_base;
+  {
+    const uint64_t mine = totals[threadIdx.x];
+    uint64_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint64_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_total[wave] = inc;
+    __syncthreads();
+    bin_base = inc - mine;
+    for (int w = 0; w < wave; ++w) bin_base += wave_total[w];
+  }
+  dest[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
   const int64_t base = (int64_t)blockIdx.x * kTile;
   for (int r = 0; r < kRounds; ++r) {
 #pragma unroll
@@ -141,20 +146,18 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
   const int n_blocks = (int)n_blocks64;
   void* ws = nullptr;
   const size_t hist_bytes = (size_t)kBins * n_blocks * sizeof(uint32_t);
-  int rc = r3d_scratch(ctx, 3, hist_bytes + kBins * sizeof(uint32_t) + kBins * sizeof(uint64_t) + 64, &ws);
+  int rc = r3d_scratch(ctx, 3, hist_bytes + kBins * sizeof(uint32_t) + 64, &ws);
   if (rc) return rc;
   uint32_t* hist = static_cast<uint32_t*>(ws);
-  uint64_t* bases = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + ((hist_bytes + 15) & ~(size_t)15));
-  uint32_t* totals = reinterpret_cast<uint32_t*>(bases + kBins);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + ((hist_bytes + 15) & ~(size_t)15));
   uint64_t* src = d_keys;
   uint64_t* dst = d_tmp;
   for (int p = 0; p < passes; ++p) {
     const int shift = first_bit + 8 * p;
     hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, totals);
-    hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, ctx->stream, totals, bases);
     hipLaunchKernelGGL(digit_scatter_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks,
-                       bases, dst);
+                       (const uint32_t*)totals, dst);
     uint64_t* t = src;
     src = dst;
     dst = t;

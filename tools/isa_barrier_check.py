@@ -97,9 +97,12 @@ def check_function(lines):
 def main(files):
     bad = 0
     for f in files:
-        with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
-            subprocess.run([HIPCC] + FLAGS + [f, "-o", tmp.name], check=True, stderr=subprocess.DEVNULL)
-            text = open(tmp.name).read()
+        with tempfile.TemporaryDirectory() as tmp_dir:
+            out = os.path.join(tmp_dir, "kernels.s")
+            r = subprocess.run([HIPCC] + FLAGS + [f, "-o", out], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise SystemExit("%s does not compile:\n%s" % (f, r.stderr[-2000:]))
+            text = open(out).read()
         n_barriers = 0
         for name, body in functions(text).items():
             n_barriers += sum(1 for l in body if l.strip() == "s_barrier")
