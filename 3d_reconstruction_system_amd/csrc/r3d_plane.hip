@@ -636,20 +636,23 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
   R3D_REQUIRE(ictx == ctx, "the index belongs to another context");
   // the same loop going on (r3d_internal.h, r3d_ctx::loop_*): its first iteration starts from the previous matches too
   const bool going_on = ctx->loop_state == d_state && ctx->loop_src == d_src && ctx->loop_idx == d_idx && ctx->loop_index == index;
-  for (int it = 0; it < n_iters; ++it) {
+  auto one_iteration = [&](bool warm) -> int {
+    int rc2;
     // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud; rigid moves preserve it)
-    if ((rc = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, it > 0 || going_on))) return rc;
-    if ((rc = plane_sums_impl(ctx, d_src, n_src, d_tgt, d_tgt_normals, n_tgt, d_idx, d_d2, max_d2, trim_q, gate_scale, nullptr,
-                              d_state)))
-      return rc;
+    if ((rc2 = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, warm))) return rc2;
+    if ((rc2 = plane_sums_impl(ctx, d_src, n_src, d_tgt, d_tgt_normals, n_tgt, d_idx, d_d2, max_d2, trim_q, gate_scale, nullptr,
+                               d_state)))
+      return rc2;
     // with the original cloud at hand every iteration moves IT by the accumulated pose: one rounding per point however
     // many steps were taken (moving the moved cloud again and again lets fp32 rounding drift by ~1e-7 per step)
-    if (d_src_orig)
-      rc = r3d_apply_T_dev(ctx, d_src_orig, R3D_F32, n_src, d_state + r3d_icp::kStateTTotal, d_src, R3D_F32);
-    else
-      rc = r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32);
-    if (rc) return rc;
-  }
+    if (d_src_orig) return r3d_apply_T_dev(ctx, d_src_orig, R3D_F32, n_src, d_state + r3d_icp::kStateTTotal, d_src, R3D_F32);
+    return r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32);
+  };
+  // (Replaying one captured iteration as a hipGraph -- 14 launches per iteration, each dependent on the one before -- was
+  // measured in round 3: 190-198 us per iteration against 184-186 us launch by launch, capture and instantiation included.  The
+  // host is ahead of the GPU either way; what separates two dependent kernels is the GPU's own dispatch latency.)
+  for (int it = 0; it < n_iters; ++it)
+    if ((rc = one_iteration(it > 0 || going_on))) return rc;
   if (n_iters > 0) {
     ctx->loop_state = d_state;
     ctx->loop_src = d_src;
