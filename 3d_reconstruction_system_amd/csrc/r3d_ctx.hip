@@ -43,6 +43,7 @@ int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
     }
     R3D_HIP(hipMalloc(&ctx->scratch[slot], bytes));
     ctx->scratch_bytes[slot] = bytes;
+    if (slot == 6) ctx->select_ws = nullptr;   // fresh memory: the selection's histogram is not known to be zero (r3d_plane.hip)
   }
   *p = ctx->scratch[slot];
   return R3D_OK;

@@ -32,6 +32,8 @@ struct r3d_ctx {
   // index and no state reset / write to that source through the library in between is the SAME loop going on -- its first
   // iteration may start from the previous matches like every other one (nn_warm_kernel)
   const void *loop_state = nullptr, *loop_src = nullptr, *loop_idx = nullptr, *loop_index = nullptr;
+  const void* select_ws = nullptr;   // the selection workspace (r3d_plane.hip) whose histogram is known to be all zero ...
+  int select_ws_buckets = 0;         // ... for this many classes
   int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances, ICP loops use
                           // nn_warm_kernel from their second iteration on; 1 off; 2 / 3: never / always nn_warm_kernel (A/B)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
@@ -120,9 +122,11 @@ int r3d_icp_sums_finish(r3d_ctx* ctx, const double* d_partials, int n_rows, doub
 int r3d_nn_index_query_solve(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
                              float max_d2, double* d_sums_out, int with_scale, double* d_state, int small_motion);
 // presorted query of an ICP loop; small_motion: the sources moved by one ICP step since this same query ran last (its matches,
-// still in d_idx_out, bound the new search tightly: wave-local kernel)
+// still in d_idx_out, bound the new search tightly: wave-local kernel).  d_src_orig + d_T_move (device, 12 doubles of a 4x4):
+// when the wave-local kernel runs, it first writes d_src = T . d_src_orig itself (*moved_out = 1) -- the caller then skips
+// its move launch; otherwise d_src is searched as it is (*moved_out = 0).
 int r3d_nn_index_query_step(r3d_nn_index* index, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                            int small_motion);
+                            int small_motion, const float* d_src_orig, const double* d_T_move, int* moved_out);
 
 static inline size_t r3d_depth_size(int dt) { return dt == R3D_DEPTH_U8 ? 1 : dt == R3D_DEPTH_U16 ? 2 : 4; }
 static inline size_t r3d_xyz_size(int dt) { return dt == R3D_F32 ? 4 : 8; }

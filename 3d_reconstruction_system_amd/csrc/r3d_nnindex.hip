@@ -25,6 +25,8 @@
 #include <cmath>
 
 #include "r3d_icp_sums.h"
+#include <cstdlib>
+
 #include "r3d_internal.h"
 
 struct r3d_nn_index {
@@ -574,12 +576,28 @@ __global__ __launch_bounds__(kThreads) void nn_warm_kernel(const float* __restri
                                                            const float* __restrict__ super_box, const float* __restrict__ tgt_orig,
                                                            uint32_t* idx_out, float* __restrict__ d2_out,
                                                            unsigned long long* __restrict__ stats, double* __restrict__ partials,
-                                                           float max_d2, float dead_zone, const uint32_t* idx_warm) {
+                                                           float max_d2, float dead_zone, const uint32_t* idx_warm,
+                                                           const float* __restrict__ src_orig, const double* __restrict__ d_T,
+                                                           float* src_moved) {
   const uint32_t tid = threadIdx.x;
   const int lane = tid & 63;
   const int64_t i = (int64_t)blockIdx.x * kThreads + tid;
   const bool ok = i < n_src;
-  const P3 sp = ok ? reinterpret_cast<const P3*>(src)[i] : P3{0.f, 0.f, 0.f};
+  P3 sp = {0.f, 0.f, 0.f};
+  if (src_orig) {
+    // the move of an ICP iteration folded into its search: this lane's source = T . (its point of the ORIGINAL cloud), in
+    // apply_lane_kernel's arithmetic (fp64 row . [x y z 1], rounded to f32 once), left in src_moved for the kernels that follow
+    if (ok) {
+      const P3 o = reinterpret_cast<const P3*>(src_orig)[i];
+      const double x = o.x, y = o.y, z = o.z;
+      sp.x = (float)(fma(d_T[2], z, fma(d_T[1], y, d_T[0] * x)) + d_T[3]);
+      sp.y = (float)(fma(d_T[6], z, fma(d_T[5], y, d_T[4] * x)) + d_T[7]);
+      sp.z = (float)(fma(d_T[10], z, fma(d_T[9], y, d_T[8] * x)) + d_T[11]);
+      reinterpret_cast<P3*>(src_moved)[i] = sp;
+    }
+  } else if (ok) {
+    sp = reinterpret_cast<const P3*>(src)[i];
+  }
   const float sx = sp.x, sy = sp.y, sz = sp.z;
   // a source with a NaN / inf coordinate has no finite distance to anything (its answer is "index 0, +inf", as in the cold
   // search): it takes no part in the culling votes instead of holding every box open for its wave
@@ -859,7 +877,8 @@ int r3d_nn_index_rebuild(r3d_nn_index* ix, const float* d_tgt, int64_t n_tgt) {
 
 static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
                                int presorted, int64_t* h_tiles_swept, bool want_sums, float max_d2, float dead_zone,
-                               double* d_sums_out, int with_scale = 0, double* d_state = nullptr, int small_motion = 0) {
+                               double* d_sums_out, int with_scale = 0, double* d_state = nullptr, int small_motion = 0,
+                               const float* d_src_orig = nullptr, const double* d_T_move = nullptr, int* moved_out = nullptr) {
   R3D_REQUIRE(ix != nullptr, "nn index is NULL");
   r3d_ctx* ctx = ix->ctx;
   int rc = r3d_ctx_enter(ctx);
@@ -903,8 +922,15 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   }
   // same sources buffer, same count, same output buffer as the last presorted query against this build of the index: the
   // output buffer still holds that query's matches ("nn_warm" = 1 switches the warm start off: A/B, tests)
+  // (test hook: R3D_FORCE_NN_WARM=<0..3> in the environment overrides the knob for every query of the process, so that a whole
+  // test suite can be run through one search form)
+  static const int forced_mode = [] {
+    const char* e = getenv("R3D_FORCE_NN_WARM");
+    return e && *e >= '0' && *e <= '3' && e[1] == 0 ? *e - '0' : -1;
+  }();
+  const int warm_mode = forced_mode >= 0 ? forced_mode : ctx->nn_warm;
   const uint32_t* warm = nullptr;
-  if (presorted && ctx->nn_warm != 1 && ix->warm_src == d_src && ix->warm_idx == d_idx_out && ix->warm_n == n_src) warm = d_idx_out;
+  if (presorted && warm_mode != 1 && ix->warm_src == d_src && ix->warm_idx == d_idx_out && ix->warm_n == n_src) warm = d_idx_out;
   if (presorted) {
     ix->warm_src = d_src;
     ix->warm_idx = d_idx_out;
@@ -918,7 +944,7 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   // Which kernel: the bounds always help nn_cull_kernel (never slower than the cold walk); the wave-local kernel wins big when
   // the bounds are TIGHT (the sources moved by one ICP step since the matches were made: the loops say so with small_motion)
   // and loses when they are not (a jump to another start pose: each wave would scan group after group on its own).
-  if (warm && ctx->nn_warm != 2 && (small_motion || ctx->nn_warm == 3)) {
+  if (warm && warm_mode != 2 && (small_motion || warm_mode == 3)) {
     // (the partial rows are per 256 sources there as here: S is 1)
     const unsigned wblocks = (unsigned)((n_src + kThreads - 1) / kThreads);
     if (want_sums) {
@@ -928,7 +954,9 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
     }
     hipLaunchKernelGGL(nn_warm_kernel, dim3(wblocks), dim3(kThreads), 0, st, d_src, n_src, ix->d_tgt4, ix->n, ix->n_tiles,
                        ix->d_tile_box, ix->d_group_box, ix->d_super_box, (const float*)ix->d_tgt, d_idx_out, d_d2_out,
-                       h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone, warm);
+                       h_tiles_swept ? stats : (unsigned long long*)nullptr, partials, max_d2, dead_zone, warm, d_src_orig, d_T_move,
+                       const_cast<float*>(d_src));
+    if (moved_out) *moved_out = d_src_orig != nullptr;
     n_rows = (int)wblocks;
   } else if (presorted) {
     if (S == 1) R3D_LAUNCH_CULL(1, false, d_src);
@@ -981,9 +1009,10 @@ int r3d_nn_index_query_solve(r3d_nn_index* ix, const float* d_src, int64_t n_src
 }
 
 int r3d_nn_index_query_step(r3d_nn_index* ix, const float* d_src, int64_t n_src, uint32_t* d_idx_out, float* d_d2_out,
-                            int small_motion) {
+                            int small_motion, const float* d_src_orig, const double* d_T_move, int* moved_out) {
+  if (moved_out) *moved_out = 0;
   return nn_index_query_impl(ix, d_src, n_src, d_idx_out, d_d2_out, 1, nullptr, false, -1.f, 0.f, nullptr, 0, nullptr,
-                             small_motion);
+                             small_motion, d_src_orig, d_T_move, moved_out);
 }
 
 extern "C" {

@@ -202,7 +202,7 @@ __device__ __forceinline__ void select_pick_all(unsigned* hist, unsigned long lo
     } else {
       k = st_all[j][0];
     }
-    const unsigned long long old_prefix = st_all[j][1], old_mask = st_all[j][2], old_count = st_all[j][3];
+    const unsigned long long old_prefix = pass ? st_all[j][1] : 0ull, old_mask = pass ? st_all[j][2] : 0ull, old_count = st_all[j][3];
     if (total > 0) {
       unsigned long long before = inc - mine;
       if (k >= before && k < before + mine) {   // exactly one lane
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(kThreads) void select_pass_kernel(const float* __re
   __shared__ unsigned s_prefix[kMaxBuckets], s_mask[kMaxBuckets];
   const int n_slots = n_buckets * kBins;
   for (int b = threadIdx.x; b < n_slots; b += kThreads) local[b] = 0;
-  if (threadIdx.x < n_buckets) {
-    s_prefix[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 1];
-    s_mask[threadIdx.x] = (unsigned)state[threadIdx.x * 4 + 2];
+  if (threadIdx.x < n_buckets) {   // (pass 0 starts from nothing: the state words still hold the previous selection's)
+    s_prefix[threadIdx.x] = pass ? (unsigned)state[threadIdx.x * 4 + 1] : 0u;
+    s_mask[threadIdx.x] = pass ? (unsigned)state[threadIdx.x * 4 + 2] : 0u;
   }
   __syncthreads();
   select_count(v, bucket, per_class, n, n_buckets, 8 * (kSelectPasses - 1 - pass), s_prefix, s_mask, local);
@@ -421,7 +421,13 @@ int workspace(r3d_ctx* ctx, int n_buckets, int n_rows, Workspace* ws) {
 int select_enqueue(r3d_ctx* ctx, const float* d_values, const unsigned char* d_bucket, int n_buckets, int64_t n, double q,
                    const Workspace& ws, int64_t per_class = 0) {
   hipStream_t st = ctx->stream;
-  R3D_HIP(hipMemsetAsync(ws.hist, 0, ws.clear_bytes, st));
+  // The histogram has to be all zero in front of pass 0.  Every pick leaves it so, and pass 0 ignores the state words, so only a
+  // workspace that has not been through a selection of this shape yet is cleared (a 5 us launch per ICP iteration otherwise).
+  if (ctx->select_ws != ws.hist || ctx->select_ws_buckets != n_buckets) {
+    R3D_HIP(hipMemsetAsync(ws.hist, 0, ws.clear_bytes, st));
+    ctx->select_ws = ws.hist;
+    ctx->select_ws_buckets = n_buckets;
+  }
   int blocks = (int)std::min<int64_t>((n + kThreads * 8 - 1) / (kThreads * 8), (int64_t)ctx->num_cus);
   if (blocks < 1) blocks = 1;
   for (int pass = 0; pass < kSelectPasses; ++pass) {
@@ -636,15 +642,34 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
   R3D_REQUIRE(ictx == ctx, "the index belongs to another context");
   // the same loop going on (r3d_internal.h, r3d_ctx::loop_*): its first iteration starts from the previous matches too
   const bool going_on = ctx->loop_state == d_state && ctx->loop_src == d_src && ctx->loop_idx == d_idx && ctx->loop_index == index;
-  auto one_iteration = [&](bool warm) -> int {
-    int rc2;
+  // With the original cloud at hand every iteration moves IT by the accumulated pose: one rounding per point however many
+  // steps were taken (moving the moved cloud again and again lets fp32 rounding drift by ~1e-7 per step).  That move is
+  // idempotent -- d_src = T_total . d_src_orig -- so an iteration that runs the wave-local search lets the search kernel do it
+  // (r3d_nn_index_query_step) and the move launch of the iteration before is left out; only the LAST iteration of a call
+  // moves explicitly, so that the caller finds d_src where the state says it is.
+  bool pending_move = false;   // the state has a pose that d_src does not show yet
+  auto one_iteration = [&](bool warm, bool last) -> int {
+    int rc2, moved = 0;
     // sources are kept in the index's Morton order by the caller (r3d_nn_index_sort_cloud; rigid moves preserve it)
-    if ((rc2 = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, warm))) return rc2;
+    if (pending_move && !(warm && d_src_orig)) {   // (cannot happen: a pending move implies both; kept for safety)
+      if ((rc2 = r3d_apply_T_dev(ctx, d_src_orig, R3D_F32, n_src, d_state + r3d_icp::kStateTTotal, d_src, R3D_F32))) return rc2;
+      pending_move = false;
+    }
+    if ((rc2 = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, warm, pending_move ? d_src_orig : nullptr,
+                                       pending_move ? d_state + r3d_icp::kStateTTotal : nullptr, &moved)))
+      return rc2;
+    if (pending_move && !moved) {   // the query took the other kernel after all: it searched the unmoved cloud -- redo properly
+      if ((rc2 = r3d_apply_T_dev(ctx, d_src_orig, R3D_F32, n_src, d_state + r3d_icp::kStateTTotal, d_src, R3D_F32))) return rc2;
+      if ((rc2 = r3d_nn_index_query_step(index, d_src, n_src, d_idx, d_d2, warm, nullptr, nullptr, nullptr))) return rc2;
+    }
+    pending_move = false;
     if ((rc2 = plane_sums_impl(ctx, d_src, n_src, d_tgt, d_tgt_normals, n_tgt, d_idx, d_d2, max_d2, trim_q, gate_scale, nullptr,
                                d_state)))
       return rc2;
-    // with the original cloud at hand every iteration moves IT by the accumulated pose: one rounding per point however
-    // many steps were taken (moving the moved cloud again and again lets fp32 rounding drift by ~1e-7 per step)
+    if (d_src_orig && !last) {
+      pending_move = true;   // the next iteration's search moves the cloud
+      return R3D_OK;
+    }
     if (d_src_orig) return r3d_apply_T_dev(ctx, d_src_orig, R3D_F32, n_src, d_state + r3d_icp::kStateTTotal, d_src, R3D_F32);
     return r3d_apply_T_dev(ctx, d_src, R3D_F32, n_src, d_state + r3d_icp::kStateTStep, d_src, R3D_F32);
   };
@@ -652,7 +677,7 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
   // measured in round 3: 190-198 us per iteration against 184-186 us launch by launch, capture and instantiation included.  The
   // host is ahead of the GPU either way; what separates two dependent kernels is the GPU's own dispatch latency.)
   for (int it = 0; it < n_iters; ++it)
-    if ((rc = one_iteration(it > 0 || going_on))) return rc;
+    if ((rc = one_iteration(it > 0 || going_on, it == n_iters - 1))) return rc;
   if (n_iters > 0) {
     ctx->loop_state = d_state;
     ctx->loop_src = d_src;

@@ -331,9 +331,12 @@ def secondary(a):
         src = ((tgt0[rng.permutation(m)] - tv) @ np.linalg.inv(1.7 * Rm).T).astype(np.float32)
         tgt = (tgt0 + rng.normal(size=tgt0.shape) * 0.01).astype(np.float32)
         icp.icp_similarity(src[:3000], tgt[:3000], max_iter=2, ctx=ctx)                      # warm-up
-        t0 = time.perf_counter()
-        T, info = icp.icp_similarity(src, tgt, ctx=ctx)
-        wall_ms = (time.perf_counter() - t0) * 1e3
+        walls = []
+        for _ in range(4):   # the first full-size call also grows the library's scratch buffers (hipMalloc): reported apart
+            t0 = time.perf_counter()
+            T, info = icp.icp_similarity(src, tgt, ctx=ctx)
+            walls.append((time.perf_counter() - t0) * 1e3)
+        first_call_ms, wall_ms = walls[0], sorted(walls[1:])[1]
         near = (src.astype(np.float64) @ (T_true[:3, :3] * 1.002).T + T_true[:3, 3]).astype(np.float32)
         dev_b = icp.IcpDevice(near, tgt, ctx, culled=False)
         ms_b = timed(dev_b.nn, 3)
@@ -355,19 +358,23 @@ def secondary(a):
         E[:3, 3] = (0.06, -0.05, 0.06)
         T0 = E @ v2["T_ab"]
         icp.icp_point_to_plane(pb[:60000], pa, tgt_shape=(480, 640), init=T0, max_iter=2, ctx=ctx)      # warm-up
-        t0 = time.perf_counter()
-        Tp, infop = icp.icp_point_to_plane(pb, pa, tgt_shape=(480, 640), init=T0, ctx=ctx)
-        plane_ms = (time.perf_counter() - t0) * 1e3
+        plane_walls = []
+        for _ in range(4):   # (first full-size call apart, as above)
+            t0 = time.perf_counter()
+            Tp, infop = icp.icp_point_to_plane(pb, pa, tgt_shape=(480, 640), init=T0, ctx=ctx)
+            plane_walls.append((time.perf_counter() - t0) * 1e3)
+        plane_ms = sorted(plane_walls[1:])[1]
         devp = icp.PlaneIcpDevice(pb, pa, (480, 640), ctx=ctx)
         devp.move_source(Tp)
         devp.state_reset()
         ms_pit = timed(lambda: devp.iterate(6), 10) / 6
         devp.free()
         plane = {"what": "two 480x640 single views of a room, 15 deg apart, 67 % overlap, depth noise 0.1 %, start 5 deg / 10 cm off",
-                 "wall_ms": round(plane_ms, 2), "iterations": infop["iterations"], "iteration_ms": round(ms_pit, 4),
+                 "wall_ms": round(plane_ms, 2), "first_call_ms": round(plane_walls[0], 2), "iterations": infop["iterations"], "iteration_ms": round(ms_pit, 4),
                  "T_error_max_abs": float(np.abs(Tp - v2["T_ab"]).max()), "pairs": infop["pairs"]}
         line = {"metric": "ICP similarity estimation, two 500k-point clouds (C3: s=1.7, 10 deg, |t|=0.5, no initial guess)",
-                "value": round(wall_ms, 2), "unit": "ms wall (upload, index builds, coarse + fine stages)", "higher_is_better": False,
+                "value": round(wall_ms, 2), "unit": "ms wall (upload, index builds, coarse + fine stages; median of 3 calls after the first)",
+                "first_call_ms": round(first_call_ms, 2), "higher_is_better": False,
                 "T_error_max_abs": float(np.abs(T - T_true).max()), "coarse_iterations": info["coarse_iterations"],
                 "fine_iterations": info["iterations"], "final_rms": info["rms_history"][-1],
                 "fine_iteration_ms": round(ms_it, 4), "culled_nn_ms": round(ms_c, 4), "bruteforce_nn_ms": round(ms_b, 3),
