@@ -88,6 +88,9 @@ __global__ __launch_bounds__(kThreads) void normals_kernel(const float* __restri
 //   8-bit digits in LDS, the workgroup that finishes LAST (fence + ticket) picks: one launch per pass              21.2 us       (x 4)
 //   all four passes in one launch, the last arriver picks and publishes, the others poll (bounded)                 104 - 127 us in all
 //   8-bit digits in LDS + a pick launch: no fence anywhere                                                         7.4 + 6.4 us  (x 4)  <- this
+//   the same, the pick of pass p done by EVERY workgroup at the head of pass p + 1 (a histogram and state per pass)  11.2 us (x 4) + 7.0
+//     (51.8 against 55.2 us per selection: the redundant pick sits on every workgroup's critical path for nearly as long as the
+//      launch it replaces; not worth a histogram per pass -- dropped)
 // An agent-scope release / acquire pair inside a kernel has to make the eight XCDs' L2 caches agree; a kernel boundary does
 // that anyway.  The "last workgroup done" idiom costs more than the launch it saves on this chip.
 constexpr int kBins = 256;
