@@ -73,7 +73,8 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
 /* tuning knobs (integers; 0 = auto everywhere): launch geometry only -- "fuse_blocks", "apply_blocks", "nn_blocks"
  * (workgroup counts), "nn_variant" (sources per lane of the NN sweeps: 1/2/4), "nn_warm" (0 auto: a presorted
  * index query with the same source / output buffers as the previous one starts from that one's matches as bounds, and the ICP
- * loops run their later iterations on the wave-local kernel; 1 off; 2 never the wave-local kernel; 3 always when there are bounds: A/B), "voxel_dedupe" (0 auto, 1 off, 2 on, 3 = the pre-round-3 form with the flush barrier inside its `if`: A/B only),
+ * loops run their later iterations on the wave-local kernel; 1 off; 2 never the wave-local kernel; 3 always when there are bounds: A/B -- the environment variable
+ * R3D_FORCE_NN_WARM=<0..3> overrides it for every query of the process: a test hook), "voxel_dedupe" (0 auto, 1 off, 2 on, 3 = the pre-round-3 form with the flush barrier inside its `if`: A/B only),
  * "fuse_prefetch" (0 auto, 1 off, 2 on: a read-only sweep stages a fused launch's inputs in the 256 MiB Infinity Cache first,
  * chunk by chunk -- "fuse_chunk_mb", 0 = 96 -- so that the kernel's reads do not mix with its write stream at the DRAM; auto:
  * on when one launch reads more than "fuse_stage_auto_mb" (default 8) MB of small-share inputs: frames that a host upload has just
