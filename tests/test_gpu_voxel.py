@@ -445,3 +445,18 @@ def test_fused_cloud_and_voxels_staged_in_chunks(V, ctx):
     finally:
         ctx.set_tuning("fuse_chunk_mb", 0)
     assert st["voxels"] > 1000
+
+
+@pytest.mark.parametrize("blocks", [1, 7, 301, 100000])
+def test_fused_cloud_and_voxels_any_run_length(V, ctx, blocks):
+    """one workgroup walking every tile (a run of 2400: many flushes, the rotating fill counters wrap hundreds of times), uneven
+    runs (a last workgroup with fewer tiles, workgroups with none), one tile per workgroup"""
+    depth, q, t, K = room_views(5, 384, 1280, seed=9)
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, size=depth.shape + (3,), dtype=np.uint8)
+    ctx.set_tuning("fuse_blocks", blocks)
+    try:
+        st = fused_vs_two_calls(V, ctx, depth, q, t, K, rgb, 0.02, 1 << 22, oracle=(blocks == 7))
+    finally:
+        ctx.set_tuning("fuse_blocks", 0)
+    assert st["voxels"] > 50_000 and st["overflow"] == 0
