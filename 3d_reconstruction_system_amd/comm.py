@@ -87,14 +87,28 @@ def exchange_unique_id(rank, world, timeout=120.0):
         try:
             srv.bind(name)              # EADDRINUSE = another job with the same MASTER_PORT / R3D_RENDEZVOUS: fail loudly
             srv.listen(world)
-            served = set()
-            while len(served) < world - 1:
-                srv.settimeout(max(deadline - time.monotonic(), 0.01))
+            handed, confirmed = set(), set()      # got all 128 bytes from us / said so
+            grace_until = None
+            while True:
+                if len(handed) == world - 1:
+                    if confirmed == handed:
+                        break
+                    # Every rank has been handed the id but not every one has confirmed it: a rank whose read failed will
+                    # knock again, so the name stays up for a short grace period (re-serving repeat hellos) instead of
+                    # vanishing under it -- and a confirmation that never comes must not keep rank 0 here for long either.
+                    if grace_until is None:
+                        grace_until = time.monotonic() + 3.0
+                    if time.monotonic() >= grace_until:
+                        break
+                wait_until = deadline if grace_until is None else grace_until
+                srv.settimeout(max(wait_until - time.monotonic(), 0.01))
                 try:
                     conn, _ = srv.accept()
                 except socket.timeout:
+                    if grace_until is not None:
+                        break
                     raise TimeoutError("rendezvous: %d of %d ranks asked for the communicator id within %.0f s"
-                                       % (len(served), world - 1, timeout))
+                                       % (len(handed), world - 1, timeout))
                 with conn:
                     conn.settimeout(10.0)
                     try:
@@ -104,10 +118,13 @@ def exchange_unique_id(rank, world, timeout=120.0):
                         who = int.from_bytes(hello[16:], "little")
                         if not 0 < who < world:
                             continue
-                        conn.sendall(uid)                     # all 128 bytes handed to the kernel = served (a lost
-                        served.add(who)                       # ack must not keep rank 0 here while the others move on)
+                        conn.sendall(uid)
+                        handed.add(who)
+                        conn.settimeout(2.0)                  # the confirmation: one byte, waited for briefly
+                        if _recv_exact(conn, 1) is not None:
+                            confirmed.add(who)
                     except OSError:
-                        pass                 # that rank will retry
+                        pass                 # that rank will retry (or its confirmation was lost: grace period above)
         finally:
             srv.close()
         return uid
@@ -119,6 +136,10 @@ def exchange_unique_id(rank, world, timeout=120.0):
             c.sendall(_nonce() + int(rank).to_bytes(4, "little"))
             uid = _recv_exact(c, ID_BYTES)
             if uid is not None:
+                try:
+                    c.sendall(b"\x01")      # confirmation (best effort: rank 0 does not depend on it)
+                except OSError:
+                    pass
                 return uid
         except OSError:
             pass

@@ -236,7 +236,7 @@ int apply_common(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_poi
   if (n_points == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz_in && d_xyz_out, "NULL device pointer");
   R3D_REQUIRE(d_xyz_in == d_xyz_out ? in_dtype == out_dtype : true, "in-place apply needs equal dtypes");
-  if (d_xyz_out == ctx->loop_src) ctx->loop_src = nullptr;   // the cloud an ICP loop was working on is being moved: that loop is over
+  r3d_wrote(ctx, d_xyz_out, (size_t)n_points * 3 * r3d_xyz_size(out_dtype));   // an ICP loop working on these points is over
   ApplyArgs a;
   a.in = d_xyz_in;
   a.out = d_xyz_out;

@@ -216,6 +216,8 @@ int r3d_comm_allgather(r3d_comm* comm, const void* d_send, const int64_t* h_coun
   R3D_REQUIRE(algo != 1 || equal, "ncclAllGather needs equal shards; use algo 0 or 2");
   char* recv = static_cast<char*>(d_recv);
   hipStream_t st = comm->ctx->stream;
+  // what arrives over the fabric is not in this device's Infinity Cache: a fused launch that reads it stages it first
+  r3d_wrote(comm->ctx, recv, (size_t)off[W]);
   if (algo == 1 || (algo == 0 && equal)) {
     // in place when d_send is already this rank's slot
     R3D_NCCL(api, api->AllGather(d_send, d_recv, (size_t)h_counts[0], ncclUint8, comm->comm, st));

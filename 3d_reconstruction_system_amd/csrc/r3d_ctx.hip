@@ -1,5 +1,6 @@
 // Context, device memory, HIP-event stopwatch and camera tables of libr3d_hip.so.
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "r3d_internal.h"
@@ -30,6 +31,95 @@ int r3d_ctx_enter(r3d_ctx* ctx) {
   return R3D_OK;
 }
 
+// ---- which inputs are presumed cached ---------------------------------------------------------------------------
+// The Infinity Cache belongs to the device, so the record does too (two contexts of one device -- e.g. a compute stream and
+// an exchange stream -- see each other's reads and writes).  A small LRU over byte ranges with a byte clock: a MISS advances
+// the clock by the range's size and stamps the range with it, a HIT only refreshes the stamp; a range is presumed cached
+// while clock - stamp + size <= budget.  Ranges larger than the budget are never presumed cached.
+namespace {
+struct Residency {
+  struct Entry {
+    uintptr_t lo, hi;
+    uint64_t stamp;
+  };
+  static constexpr int kEntries = 32;
+  std::mutex mu;
+  Entry e[kEntries];
+  int n = 0;
+  uint64_t clock = 0;
+  void drop(int k) { e[k] = e[--n]; }
+};
+constexpr int kMaxDevices = 64;
+Residency g_residency[kMaxDevices];
+Residency* residency(r3d_ctx* ctx) { return ctx && ctx->device >= 0 && ctx->device < kMaxDevices ? &g_residency[ctx->device] : nullptr; }
+}  // namespace
+
+bool r3d_inputs_resident(r3d_ctx* ctx, const void* p, size_t bytes, size_t budget) {
+  Residency* r = residency(ctx);
+  if (!r || !bytes) return false;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  std::lock_guard<std::mutex> g(r->mu);
+  for (int k = 0; k < r->n; ++k)
+    if (r->e[k].lo <= lo && hi <= r->e[k].hi) return r->clock - r->e[k].stamp + (r->e[k].hi - r->e[k].lo) <= budget;
+  return false;
+}
+
+void r3d_inputs_read(r3d_ctx* ctx, const void* p, size_t bytes, size_t budget) {
+  Residency* r = residency(ctx);
+  if (!r || !bytes) return;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  std::lock_guard<std::mutex> g(r->mu);
+  for (int k = 0; k < r->n; ++k)
+    if (r->e[k].lo <= lo && hi <= r->e[k].hi && r->clock - r->e[k].stamp + (r->e[k].hi - r->e[k].lo) <= budget) {
+      if (r->e[k].lo == lo && r->e[k].hi == hi) r->e[k].stamp = r->clock;   // hit on the whole range: refreshed
+      return;                                                              // hit on a part: the rest ages as before
+    }
+  r->clock += bytes;
+  for (int k = r->n - 1; k >= 0; --k)
+    if (r->e[k].lo < hi && lo < r->e[k].hi) r->drop(k);   // superseded (a stale or partial record of the same bytes)
+  if (bytes > budget) return;
+  if (r->n == Residency::kEntries) {
+    int oldest = 0;
+    for (int k = 1; k < r->n; ++k)
+      if (r->e[k].stamp < r->e[oldest].stamp) oldest = k;
+    r->drop(oldest);
+  }
+  r->e[r->n++] = {lo, hi, r->clock};
+}
+
+void r3d_inputs_written(r3d_ctx* ctx, const void* p, size_t bytes) {
+  Residency* r = residency(ctx);
+  if (!r || !bytes) return;
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  std::lock_guard<std::mutex> g(r->mu);
+  for (int k = r->n - 1; k >= 0; --k)
+    if (r->e[k].lo < hi && lo < r->e[k].hi) r->drop(k);
+}
+
+void r3d_inputs_forget_all(r3d_ctx* ctx) {
+  Residency* r = residency(ctx);
+  if (!r) return;
+  std::lock_guard<std::mutex> g(r->mu);
+  r->n = 0;
+}
+
+void r3d_wrote(r3d_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx || !bytes) return;
+  r3d_inputs_written(ctx, p, bytes);
+  if (ctx->loop_src) {
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes, slo = (uintptr_t)ctx->loop_src;
+    const uintptr_t shi = slo + (ctx->loop_src_bytes ? ctx->loop_src_bytes : 1);
+    if (lo < shi && slo < hi) ctx->loop_src = nullptr;
+  }
+}
+
+int r3d_inputs_tracked(r3d_ctx* ctx) {
+  Residency* r = residency(ctx);
+  if (!r) return 0;
+  std::lock_guard<std::mutex> g(r->mu);
+  return r->n;
+}
+
 int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
   R3D_REQUIRE(slot >= 0 && slot < r3d_ctx::kScratchSlots, "bad scratch slot");
   if (bytes == 0) bytes = 16;
@@ -37,6 +127,7 @@ int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p) {
     if (ctx->scratch[slot]) {
       R3D_HIP(hipStreamSynchronize(ctx->stream));
       if (ctx->upload_stream) R3D_HIP(hipStreamSynchronize(ctx->upload_stream));
+      r3d_inputs_written(ctx, ctx->scratch[slot], ctx->scratch_bytes[slot]);   // the addresses may come back as anything
       R3D_HIP(hipFree(ctx->scratch[slot]));
       ctx->scratch[slot] = nullptr;
       ctx->scratch_bytes[slot] = 0;
@@ -155,6 +246,9 @@ static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "fuse_prefetch")) return &ctx->fuse_prefetch;
   if (!strcmp(key, "fuse_chunk_mb")) return &ctx->fuse_chunk_mb;
   if (!strcmp(key, "fuse_stage_auto_mb")) return &ctx->fuse_stage_auto_mb;
+  if (!strcmp(key, "fuse_resident_mb")) return &ctx->fuse_resident_mb;
+  if (!strcmp(key, "fuse_inputs_fresh")) return &ctx->fuse_inputs_fresh;
+  if (!strcmp(key, "fuse_sweeps")) return &ctx->fuse_sweeps;
   if (!strcmp(key, "nn_variant")) return &ctx->nn_variant;
   if (!strcmp(key, "nn_warm")) return &ctx->nn_warm;
   if (!strcmp(key, "nn_blocks")) return &ctx->nn_blocks;
@@ -168,6 +262,10 @@ int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value) {
   int* s = tuning_slot(ctx, key);
   R3D_REQUIRE(s != nullptr, "unknown tuning key '%s'", key);
   R3D_REQUIRE(value >= 0, "tuning value must be >= 0");
+  if (s == &ctx->fuse_inputs_fresh) {   // an event, not a state: nothing on this device is presumed cached any more
+    if (value) r3d_inputs_forget_all(ctx);
+    return R3D_OK;
+  }
   *s = value;
   return R3D_OK;
 }
@@ -176,6 +274,10 @@ int r3d_ctx_get_tuning(r3d_ctx* ctx, const char* key, int* value_out) {
   R3D_REQUIRE(ctx && key && value_out, "NULL argument");
   int* s = tuning_slot(ctx, key);
   R3D_REQUIRE(s != nullptr, "unknown tuning key '%s'", key);
+  if (s == &ctx->fuse_inputs_fresh) {   // reads back how many input ranges are on record for this device
+    *value_out = r3d_inputs_tracked(ctx);
+    return R3D_OK;
+  }
   *value_out = *s;
   return R3D_OK;
 }
@@ -194,6 +296,16 @@ int r3d_dev_free(r3d_ctx* ctx, void* d_ptr) {
   if (rc) return rc;
   if (!d_ptr) return R3D_OK;
   R3D_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, d_ptr) == hipSuccess) r3d_wrote(ctx, base, size);
+    else {
+      (void)hipGetLastError();
+      r3d_inputs_forget_all(ctx);
+      ctx->loop_src = nullptr;
+    }
+  }
   R3D_HIP(hipFree(d_ptr));
   return R3D_OK;
 }
@@ -201,9 +313,9 @@ int r3d_dev_free(r3d_ctx* ctx, void* d_ptr) {
 int r3d_memcpy_h2d(r3d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
-  if (d_dst == ctx->loop_src) ctx->loop_src = nullptr;   // (see r3d_ctx::loop_*)
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_dst && h_src, "NULL pointer with bytes > 0");
+  r3d_wrote(ctx, d_dst, bytes);   // DMA lands in HBM, not in the Infinity Cache (measured: bench.py regimes)
   R3D_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return R3D_OK;
 }
@@ -220,9 +332,9 @@ int r3d_memcpy_d2h(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
 int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
-  if (d_dst == ctx->loop_src) ctx->loop_src = nullptr;   // (see r3d_ctx::loop_*)
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_dst && d_src, "NULL pointer with bytes > 0");
+  r3d_wrote(ctx, d_dst, bytes);
   R3D_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return R3D_OK;
 }
@@ -230,9 +342,9 @@ int r3d_memcpy_d2d(r3d_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
 int r3d_memset(r3d_ctx* ctx, void* d_dst, int byte_value, size_t bytes) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
-  if (d_dst == ctx->loop_src) ctx->loop_src = nullptr;   // (see r3d_ctx::loop_*)
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_dst != nullptr, "NULL pointer with bytes > 0");
+  r3d_wrote(ctx, d_dst, bytes);
   R3D_HIP(hipMemsetAsync(d_dst, byte_value, bytes, ctx->stream));
   return R3D_OK;
 }

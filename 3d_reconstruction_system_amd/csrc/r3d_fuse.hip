@@ -623,17 +623,30 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   const bool colour_after = d_rgb && out_dtype == R3D_F64;  // f64 xyz: colour goes through its own pass
   // byte-raster unprojection: dword loads + in-wave redistribution (load_tile_wave); knob 1 = element loads (A/B)
   const bool wave = ctx->fuse_loads != 1 && !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !(d_rgb && !colour_after);
-  // inputs staged through the Infinity Cache chunk by chunk (cache_touch_kernel): auto = when one launch's inputs are more
-  // than a cache that also has the write stream passing through will have kept from an earlier pass anyway
-  const uint64_t in_per_frame = hw * (dsz + ((d_rgb && !colour_after) ? 3 : 0));
+  // Inputs staged through the Infinity Cache chunk by chunk (cache_touch_kernel).  auto = when the inputs are a small share of
+  // the launch's traffic (the sweep is an extra pass over them; measured at 1000 frames, profiles/r02_cold_inputs.log: u8
+  // 4.3 -> 6.4 TB/s, u8 + colour 3.8 -> 5.5, u16 4.8 -> 6.3, f32 depth -> f64 xyz 4.4 -> 5.6, but f32 depth + colour (7 of
+  // 23 B/point are inputs) 5.7 -> 5.0: that one stays as it is), big enough for the extra launch to pay, AND NOT PRESUMED TO BE
+  // IN THE CACHE ALREADY (r3d_inputs_*, r3d_ctx.hip): a raster this device's launches have just read is; one that an H2D copy,
+  // the host pipeline or a collective has just written is not, nor is one the library has never seen, nor any that exceeds
+  // what the cache keeps.  Round 3 staged by size alone and paid a 7.8 us sweep per launch on a raster that was cached.
+  const bool rgb_in_kernel = d_rgb && !colour_after;
+  const uint64_t in_per_frame = hw * (dsz + (rgb_in_kernel ? 3 : 0));
   const uint64_t in_bytes = in_per_frame * (uint64_t)n_frames;
   const uint64_t chunk_bytes = (uint64_t)(ctx->fuse_chunk_mb > 0 ? ctx->fuse_chunk_mb : kStageChunkMB) << 20;
-  // ... AND the inputs are a small share of the traffic: the sweep is an extra pass over them (measured at 1000 frames,
-  // profiles/r02_cold_inputs.log: u8 4.3 -> 6.4 TB/s, u8 + colour 3.8 -> 5.5, u16 4.8 -> 6.3, f32 depth -> f64 xyz 4.4 -> 5.6,
-  // but f32 depth + colour (7 of 23 B/point are inputs) 5.7 -> 5.0: that one stays as it is)
-  const bool small_inputs = dsz <= 2 || (out_dtype == R3D_F64 && !(d_rgb && !colour_after));
-  const bool stage = ctx->fuse_prefetch == 2 ||
-                     (ctx->fuse_prefetch == 0 && small_inputs && in_bytes > ((uint64_t)ctx->fuse_stage_auto_mb << 20));
+  const uint64_t budget = (uint64_t)ctx->fuse_resident_mb << 20;
+  const uint64_t depth_bytes = hw * dsz * (uint64_t)n_frames, rgb_bytes = rgb_in_kernel ? hw * 3 * (uint64_t)n_frames : 0;
+  const bool small_inputs = dsz <= 2 || (out_dtype == R3D_F64 && !rgb_in_kernel);
+  bool stage_depth = ctx->fuse_prefetch == 2, stage_rgb = ctx->fuse_prefetch == 2 && rgb_in_kernel;
+  if (ctx->fuse_prefetch == 0 && small_inputs && in_bytes > ((uint64_t)ctx->fuse_stage_auto_mb << 20)) {
+    stage_depth = !r3d_inputs_resident(ctx, d_depth, depth_bytes, budget);
+    stage_rgb = rgb_in_kernel && !r3d_inputs_resident(ctx, d_rgb, rgb_bytes, budget);
+  }
+  const bool stage = stage_depth || stage_rgb;
+  r3d_wrote(ctx, d_out, hw * osz * (uint64_t)n_frames);
+  // whatever the decision: once this launch has run, it HAS read its inputs
+  r3d_inputs_read(ctx, d_depth, depth_bytes, budget);
+  if (rgb_in_kernel) r3d_inputs_read(ctx, d_rgb, rgb_bytes, budget);
   int frames_per_step = n_frames;
   if (stage) {
     const uint64_t f = chunk_bytes / (in_per_frame ? in_per_frame : 1);
@@ -658,10 +671,9 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
     dm.total_tiles = (uint32_t)total_tiles;
     dm.rgb_vec_ok = rr && ((uintptr_t)rr % 16 == 0) && (hw % 16 == 0);
     dm.depth_vec_ok = ((uintptr_t)dd % 4 == 0) && ((hw * dsz) % 4 == 0);
-    if (stage) {
-      cache_touch(ctx, dd, hw * dsz * (uint64_t)nf);
-      if (p.rgb) cache_touch(ctx, rr, hw * 3 * (uint64_t)nf);
-    }
+    if (stage_depth) cache_touch(ctx, dd, hw * dsz * (uint64_t)nf);
+    if (stage_rgb) cache_touch(ctx, rr, hw * 3 * (uint64_t)nf);
+    ctx->fuse_sweeps += (int)stage_depth + (int)stage_rgb;
     // measured (profiles/r02_c5_probe.log, r02_ab_kernels.log, r02_all_kernels.json): one tile per workgroup for every kernel
     // (the element-load form of the byte-raster unprojection, kept for A/B, likes 8 striding workgroups per CU)
     const bool stride8 = !wave && !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !p.rgb;
@@ -778,6 +790,7 @@ int r3d_cache_prefetch(r3d_ctx* ctx, const void* d_ptr, size_t bytes) {
   if (bytes == 0) return R3D_OK;
   R3D_REQUIRE(d_ptr != nullptr, "NULL device pointer");
   cache_touch(ctx, d_ptr, bytes);
+  r3d_inputs_read(ctx, d_ptr, bytes, (size_t)ctx->fuse_resident_mb << 20);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }

@@ -117,6 +117,7 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
         parallel_memcpy(pin_in[k][b], src, (size_t)n * ib, n_threads);
         src = static_cast<const char*>(pin_in[k][b]);
       }
+      r3d_wrote(ctx, static_cast<char*>(ins[k].d) + (size_t)lo * ib, (size_t)n * ib);   // fresh from the host
       R3D_HIP(hipMemcpyAsync(static_cast<char*>(ins[k].d) + (size_t)lo * ib, src, (size_t)n * ib, hipMemcpyHostToDevice,
                              ctx->upload_stream));
     }

@@ -440,6 +440,7 @@ int r3d_icp_iterate(r3d_ctx* ctx, r3d_nn_index* index, float* d_src, int64_t n_s
   if (index && n_iters > 0) {
     ctx->loop_state = d_state;
     ctx->loop_src = d_src;
+    ctx->loop_src_bytes = (size_t)n_src * 12;
     ctx->loop_idx = d_idx;
     ctx->loop_index = index;
   }

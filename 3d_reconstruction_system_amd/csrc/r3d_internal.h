@@ -27,11 +27,19 @@ struct r3d_ctx {
   // an H2D copy has just written is NOT in the Infinity Cache -- the launch runs at 0.49 of peak plain, 0.82 staged -- while
   // staging a raster that IS cached costs 4 %.  Below ~8 MB the extra launch eats the gain.
   int fuse_stage_auto_mb = 8;
+  // ... and, since round 4, only when those inputs are NOT presumed to sit in the Infinity Cache already: the library keeps a
+  // per-device record of the input ranges its launches have read lately (r3d_inputs_* below) and forgets a range the moment
+  // it writes it from outside the cache (H2D copies, the host pipeline's uploads, collective receives, frees).  This many MB
+  // of inputs are presumed to survive in the 256 MiB cache while a launch's write stream passes through it.
+  int fuse_resident_mb = 128;
+  int fuse_sweeps = 0;        // read-only statistic: staging sweeps the fused launches of this ctx have enqueued so far
+  int fuse_inputs_fresh = 0;  // write-only knob: a foreign producer (torch, another library) has rewritten input buffers
   int nn_variant = 0;     // sources per lane (1, 2, 4; 0 = auto)
   // the ICP loop that ran last on this ctx (r3d_icp_iterate / _plane): a call with the same state, source, match buffer and
   // index and no state reset / write to that source through the library in between is the SAME loop going on -- its first
   // iteration may start from the previous matches like every other one (nn_warm_kernel)
   const void *loop_state = nullptr, *loop_src = nullptr, *loop_idx = nullptr, *loop_index = nullptr;
+  size_t loop_src_bytes = 0;          // ... and the extent of that source cloud: r3d_wrote() ends the loop on ANY overlapping write
   const void* select_ws = nullptr;   // the selection workspace (r3d_plane.hip) whose histogram is known to be all zero ...
   int select_ws_buckets = 0;         // ... for this many classes
   int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances, ICP loops use
@@ -87,6 +95,21 @@ int r3d_ctx_enter(r3d_ctx* ctx);
 // the context a communicator was created on (its collectives run on that context's stream); r3d_comm.hip
 struct r3d_comm;
 r3d_ctx* r3d_comm_context(const r3d_comm* comm);
+
+// Which input ranges are presumed to sit in the device's Infinity Cache (r3d_ctx.hip; one record per device, shared by its
+// contexts).  _resident: [p, p+bytes) was read by a launch of the library and fewer than `budget_bytes` of other inputs have
+// gone through since.  _read: a launch has just been enqueued that reads the range.  _written: the range has been (or is
+// about to be) written from outside the cache, or freed -- forget it.  _forget_all: the hint for foreign producers.
+bool r3d_inputs_resident(r3d_ctx* ctx, const void* p, size_t bytes, size_t budget_bytes);
+void r3d_inputs_read(r3d_ctx* ctx, const void* p, size_t bytes, size_t budget_bytes);
+void r3d_inputs_written(r3d_ctx* ctx, const void* p, size_t bytes);
+void r3d_inputs_forget_all(r3d_ctx* ctx);
+int r3d_inputs_tracked(r3d_ctx* ctx);
+
+// Every entry point that writes a CALLER's device range (or frees one) says so here: the range is no longer presumed cached
+// (r3d_inputs_written) and an ICP loop whose source cloud it overlaps is over (its next call starts cold, not "warm" from
+// matches that describe other points).  Results never depend on either record; speed does.
+void r3d_wrote(r3d_ctx* ctx, const void* p, size_t bytes);
 
 // grow-only scratch slot (device memory); returns device pointer in *p
 int r3d_scratch(r3d_ctx* ctx, int slot, size_t bytes, void** p);

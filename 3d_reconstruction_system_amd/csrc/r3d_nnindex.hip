@@ -922,13 +922,7 @@ static int nn_index_query_impl(r3d_nn_index* ix, const float* d_src, int64_t n_s
   }
   // same sources buffer, same count, same output buffer as the last presorted query against this build of the index: the
   // output buffer still holds that query's matches ("nn_warm" = 1 switches the warm start off: A/B, tests)
-  // (test hook: R3D_FORCE_NN_WARM=<0..3> in the environment overrides the knob for every query of the process, so that a whole
-  // test suite can be run through one search form)
-  static const int forced_mode = [] {
-    const char* e = getenv("R3D_FORCE_NN_WARM");
-    return e && *e >= '0' && *e <= '3' && e[1] == 0 ? *e - '0' : -1;
-  }();
-  const int warm_mode = forced_mode >= 0 ? forced_mode : ctx->nn_warm;
+  const int warm_mode = ctx->nn_warm;
   const uint32_t* warm = nullptr;
   if (presorted && warm_mode != 1 && ix->warm_src == d_src && ix->warm_idx == d_idx_out && ix->warm_n == n_src) warm = d_idx_out;
   if (presorted) {
@@ -1034,6 +1028,7 @@ int r3d_cloud_zero_rows_to_nan(r3d_ctx* ctx, float* d_xyz, int64_t n) {
   R3D_REQUIRE(n >= 0, "negative cloud size");
   if (n == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
+  r3d_wrote(ctx, d_xyz, (size_t)n * 12);
   hipLaunchKernelGGL(zero_rows_to_nan_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz, n);
   R3D_HIP(hipGetLastError());
   return R3D_OK;
@@ -1048,6 +1043,7 @@ static int sort_cloud_impl(r3d_nn_index* ix, float* d_xyz, int64_t n, uint32_t* 
   if (h_n_valid) *h_n_valid = 0;
   if (n == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
+  r3d_wrote(ctx, d_xyz, (size_t)n * 12);   // reordered in place
   const int idx_bits = bits_for(n);
   void *keys = nullptr, *tmp = nullptr, *copy = nullptr, *misc = nullptr;
   if ((rc = r3d_scratch(ctx, 0, (size_t)n * 8, &keys))) return rc;
@@ -1152,6 +1148,7 @@ int r3d_gather_rows(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, const ui
   R3D_REQUIRE(n_points >= 0 && n_out >= 0, "negative size");
   if (n_out == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz && d_rows && d_xyz_out && d_xyz != d_xyz_out, "NULL or aliased device pointer");
+  r3d_wrote(ctx, d_xyz_out, (size_t)n_out * 12);
   hipLaunchKernelGGL(rows_by_index_kernel, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz,
                      n_points, d_rows, n_out, d_xyz_out);
   R3D_HIP(hipGetLastError());
@@ -1166,6 +1163,7 @@ int r3d_gather_rows_strided(r3d_ctx* ctx, const float* d_xyz, int64_t n_points, 
   if (n_out == 0) return R3D_OK;
   R3D_REQUIRE(first + (n_out - 1) * step < n_points, "row selection runs past the cloud (%lld rows)", (long long)n_points);
   R3D_REQUIRE(d_xyz && d_xyz_out && d_xyz != d_xyz_out, "NULL or aliased device pointer");
+  r3d_wrote(ctx, d_xyz_out, (size_t)n_out * 12);
   hipLaunchKernelGGL(rows_strided_kernel, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_xyz,
                      first, step, n_out, d_xyz_out);
   R3D_HIP(hipGetLastError());

@@ -411,6 +411,11 @@ int workspace(r3d_ctx* ctx, int n_buckets, int n_rows, Workspace* ws) {
   const size_t head_al = (head + 255) & ~(size_t)255;
   int rc = r3d_scratch(ctx, 6, head_al + (size_t)(n_rows + 1) * kSums * sizeof(double), &p);
   if (rc) return rc;
+  // The "histogram is known to be zero" record (select_enqueue) describes ONE layout.  A workspace laid out for another class
+  // count puts its state words, picks or partial rows where that layout has its histogram -- e.g. the untrimmed sums pass
+  // (1 class) writes fp64 rows at byte 1280, inside the 24-class histogram -- so the record dies here, whether or not a
+  // selection follows (round-3 advisor finding: trim -> no trim -> trim on one ctx ranked against leftover rows).
+  if (ctx->select_ws_buckets != n_buckets) ctx->select_ws = nullptr;
   char* c = static_cast<char*>(p);
   ws->hist = reinterpret_cast<unsigned*>(c);
   ws->state = reinterpret_cast<unsigned long long*>(c + hist_b);
@@ -684,6 +689,7 @@ int r3d_icp_iterate_plane(r3d_ctx* ctx, r3d_nn_index* index, const float* d_src_
   if (n_iters > 0) {
     ctx->loop_state = d_state;
     ctx->loop_src = d_src;
+    ctx->loop_src_bytes = (size_t)n_src * 12;
     ctx->loop_idx = d_idx;
     ctx->loop_index = index;
   }

@@ -150,6 +150,12 @@ class Context:
         L.check(self.lib.r3d_ctx_get_tuning(self.handle, key.encode(), C.byref(v)))
         return v.value
 
+    def inputs_fresh(self):
+        """Tell the library that a FOREIGN producer (torch, another library) has rewritten input buffers of this device in
+        place: no raster is presumed to sit in the Infinity Cache any more, so the next fused launch stages its inputs again.
+        (Writes that go through the library -- uploads, the host pipeline, r3d_comm receives -- are tracked by themselves.)"""
+        self.set_tuning("fuse_inputs_fresh", 1)
+
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 

@@ -215,6 +215,8 @@ class ShardedFusion:
         launch.  Same bits as fuse_and_gather (same kernel, same per-frame arithmetic), 1/12 of the fabric traffic."""
         torch = self.torch
         depth_all, pose_all = self.gather_inputs(depth, pose, frames_per_rank)
+        if isinstance(self.transport, TorchTransport) and self.fuse_fn == self._hip_fuse and depth.device.type == "cuda":
+            self._ctx_for(depth.device)[0].inputs_fresh()      # torch's collective wrote them: not in the cache, not tracked
         total = sum(frames_per_rank)
         if out is None:
             out = torch.empty((total * self.h * self.w, 3), dtype=self.out_dtype, device=depth.device)

@@ -22,7 +22,10 @@ Extra objects on the JSON line:
                   (roofline.sustained: the same launch over >= 4000 launches before it; roofline.cold_inputs: the same
                   launch on rasters that are NOT in the Infinity Cache, measured in this run by a child process).
   cpu_baseline -- the loop-faithful CPU restatement of the reference path (oracle/, test
-                  infrastructure; rank 0, N=1 only) timed on a bounded sample, 1 core.
+                  infrastructure; rank 0, N=1 only) timed on a bounded sample, 1 core; with and without the PLY writer.
+  end_to_end   -- N=1 only, measured by child processes before this one touches the GPU: (i) pinned host rasters ->
+                  r3d_fuse_frames_host -> pinned host xyz (PCIe both ways: north_star's 2 Gpoints/s floor), (ii) the
+                  camera_to_world.py drop-in on 100 synthetic 1280x384 PNG files -> every file the reference writes.
 """
 import argparse
 import importlib
@@ -59,13 +62,24 @@ def cpu_baseline(sample_frames=1):
         t0 = time.perf_counter()
         O.fuse_frames_loop(depth, q, t, td)
         dt = time.perf_counter() - t0
+        # ... and the reference's last step, the ASCII PLY of the fused cloud (c2w:112-134), on ONE frame's points
+        one = O.fuse_frames(depth[:1], q[:1], t[:1])
+        cols = [one[:, 0].tolist(), one[:, 1].tolist(), one[:, 2].tolist()]
+        t0 = time.perf_counter()
+        O.genply_loop(cols, os.path.join(td, "one.ply"))
+        dt_ply = time.perf_counter() - t0
     t0 = time.perf_counter()
     O.fuse_frames(depth, q, t)
     dt_vec = time.perf_counter() - t0
     pts = sample_frames * H * W
+    per_frame, per_frame_ply = dt / sample_frames, dt / sample_frames + dt_ply
     return {"value": round(pts / dt / 1e6, 5), "unit": "Mpoints/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d frame(s) of 1280x384 u8 (%d points), per-point Python loops + txt round trip as "
                       "camera_to_world.py:67-105, no PLY; %.1f s" % (sample_frames, pts, dt),
+            "files_to_files": {"s_per_frame": round(per_frame_ply, 3), "Mpoints_s": round(H * W / per_frame_ply / 1e6, 5),
+                               "what": "the same loops PLUS the ASCII PLY writer (genply, camera_to_world.py:112-134; %.2f s for "
+                                       "one frame's %d points): the reference's whole per-frame path, files to files"
+                                       % (dt_ply, H * W)},
             "vectorised_numpy_fp64_Mpoints_s": round(pts / dt_vec / 1e6, 3),
             "host_cpus": os.cpu_count()}
 
@@ -90,11 +104,15 @@ def pmc_traffic(frames, out_dtype, depth="u8"):
         with open(p) as f:
             rec = json.load(f)
     except Exception:
-        return None
+        return None, None
     cfg = rec.get("config", {"frames": 100, "out_dtype": "float32", "depth": "u8"})   # r01 file: the C2 default launch
     if (cfg.get("frames"), cfg.get("out_dtype"), cfg.get("depth")) != (frames, out_dtype, depth):
-        return None
-    return rec.get("hbm_bytes_per_launch")
+        return None, None
+    import hashlib
+    with open(p, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:12]
+    return rec.get("hbm_bytes_per_launch"), "recorded: profiles/pmc_fuse_latest.json @%s (%s)" % (sha, rec.get("collected", "rocprofv3 --pmc passes "
+                                                                                                 "over this command"))
 
 
 def kernel_duration_ms(torch, stream, launch, min_launches=1000, min_ms=100.0, warm=50):
@@ -174,17 +192,21 @@ def regimes(a):
         ctx.sync()
     for key, knob in (("plain", 1), ("staged", 2), ("auto", 0)):
         ctx.set_tuning("fuse_prefetch", knob)
+        s0 = ctx.get_tuning("fuse_sweeps")
         ms = median_ms(fuse_rotating)
         out[key + "_ms"], out[key + "_frac"] = round(ms, 5), frac(ms)
+        out[key + "_sweeps_per_launch"] = round((ctx.get_tuning("fuse_sweeps") - s0) / (32 + 8 * 16), 3)
     # for the record, what the library's default costs where it is NOT needed: ONE raster re-read every launch (the parent's
     # bench loop), staging off = the fused kernel alone on cached inputs (rounds 1-2 measured this) / library default
     def fuse_same():
         r3d.fuse_frames_device(ctx, cam, copies[0].ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
     same = {}
-    for key, knob in (("staging_off", 1), ("auto", 0)):
+    for key, knob in (("staging_off", 1), ("auto", 0), ("staging_forced", 2)):
         ctx.set_tuning("fuse_prefetch", knob)
+        s0 = ctx.get_tuning("fuse_sweeps")
         ms = median_ms(fuse_same, groups=8, per=50, warm=100)
         same[key + "_ms"], same[key + "_frac"] = round(ms, 5), frac(ms)
+        same[key + "_sweeps"] = ctx.get_tuning("fuse_sweeps") - s0              # of 500 launches
     out["same_raster_every_launch"] = same
     # (2) fuse right after an H2D upload of fresh frames (pinned host memory -> the same device raster every time)
     host = ctx.pinned_empty((F, H, W), np.uint8)
@@ -199,16 +221,30 @@ def regimes(a):
             for c in copies[1:]:
                 L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, c.ptr, n))
             L.check(ctx.lib.r3d_memcpy_h2d(ctx.handle, copies[0].ptr, host.ctypes.data, n))
+            s0 = ctx.get_tuning("fuse_sweeps")
             ctx.timer_start()
             r3d.fuse_frames_device(ctx, cam, copies[0].ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
             t.append(ctx.timer_stop())
         ms = sorted(t[4:])[10]
         h2d[key + "_ms"], h2d[key + "_frac"] = round(ms, 5), frac(ms)
+        h2d[key + "_sweeps_last_launch"] = ctx.get_tuning("fuse_sweeps") - s0
     h2d["note"] = ("single launches, each right after a 49 MB H2D copy from pinned host memory into the raster it reads (the "
                    "other 15 rasters are swept through the cache before the copy); staging off / on / library default")
     out["after_h2d_upload"] = h2d
     ctx.set_tuning("fuse_prefetch", 0)
-    out["staging_policy"] = "auto stages a launch whose inputs exceed %d MB" % ctx.get_tuning("fuse_stage_auto_mb")
+    out["staging_policy"] = ("by provenance: auto stages a launch whose inputs exceed %d MB unless those bytes are presumed cached "
+                             "(read by a launch on this device, fewer than %d MB of other inputs since, not rewritten through the "
+                             "library); foreign producers say r3d_ctx_set_tuning('fuse_inputs_fresh', 1)"
+                             % (ctx.get_tuning("fuse_stage_auto_mb"), ctx.get_tuning("fuse_resident_mb")))
+    # what one sweep costs when it is needed: the raster alone, cold (the other copies went through the cache in between)
+    ts = []
+    for k in range(12):
+        for c in copies[1:9]:
+            L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, c.ptr, n))
+        ctx.timer_start()
+        L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, copies[0].ptr, n))
+        ts.append(ctx.timer_stop())
+    out["sweep_alone_cold_ms"] = round(sorted(ts[2:])[5], 5)
     out["note"] = ("each launch reads a different copy of the raster (first touch of fresh frames); 'staged' = a read-only sweep "
                    "puts the launch's inputs into the Infinity Cache first; 'auto' = the library's default policy")
     for c in copies[1:]:
@@ -245,6 +281,112 @@ def regimes_in_child():
         return json.loads(lines[-1])
     except Exception as e:  # pragma: no cover
         return {"failed": "%s: %s" % (type(e).__name__, str(e)[:160])}
+
+
+def e2e_host(a):
+    """end_to_end (i), one JSON line: config 2's batch from PINNED HOST memory to PINNED HOST memory through the C ABI's host
+    entry point (r3d_fuse_frames_host: chunks over PCIe both ways at once, kernels in between) -- what a caller that keeps its
+    rasters and wants its cloud in host memory gets, and the figure north_star's ">= 2 Gpoints/s per GPU" floor is about.
+    Pageable NumPy arrays (staged through the library's pinned ring by host threads) beside it."""
+    r3d = importlib.import_module("3d_reconstruction_system_amd")
+    L = importlib.import_module("3d_reconstruction_system_amd._lib")
+    ctx = r3d.Context(0)
+    F = FRAMES_PER_GPU
+    n = F * H * W
+    rng = np.random.default_rng(1234)
+    cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
+    raster = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
+    tab = np.ascontiguousarray(r3d.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10))
+    out = {}
+    for label, alloc in (("pinned", ctx.pinned_empty), ("pageable", lambda shape, dt: np.zeros(shape, dt))):
+        src, dst = alloc((F, H, W), np.uint8), alloc((n, 3), np.float32)
+        src[...] = raster
+        dst[...] = 0                                    # touched: page faults are not PCIe
+        times = []
+        for rep in range(7):
+            t0 = time.perf_counter()
+            L.check(ctx.lib.r3d_fuse_frames_host(ctx.handle, cam.handle, src.ctypes.data, 0, F, 1.0, tab.ctypes.data,
+                                                 dst.ctypes.data, 0))          # returns when the cloud is in `dst`
+            times.append(time.perf_counter() - t0)
+        sec = sorted(times[2:])[2]
+        out[label] = {"ms": round(sec * 1e3, 3), "Gpoints_s": round(n / sec / 1e9, 3),
+                      "pcie_GBps_h2d": round(n / sec / 1e9, 2), "pcie_GBps_d2h": round(n * 12 / sec / 1e9, 2)}
+        if label == "pinned":     # the cloud that came back is the device-resident launch's, bit for bit (sampled rows)
+            d_depth, d_pose, d_xyz = ctx.alloc(n).upload(raster), ctx.alloc(tab.nbytes).upload(tab), ctx.alloc(n * 12)
+            r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
+            want = d_xyz.download(np.float32, n * 3).reshape(-1, 3)
+            out["identical_to_device_resident_launch"] = bool(np.array_equal(want[::257], dst[::257]))
+            for b in (d_depth, d_pose, d_xyz):
+                b.free()
+        del src, dst
+    out["what"] = ("C2's batch (100 x 1280x384 u8, %d points) host memory -> r3d_fuse_frames_host -> f32 xyz in host memory; median "
+                   "of 5 calls after 2; 1 B/point up and 12 B/point down the PCIe link at the same time" % n)
+    out["floor_Gpoints_s"] = 2.0
+    out["meets_floor"] = bool(out["pinned"]["Gpoints_s"] >= 2.0)
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def e2e_dropin(frames=100):
+    """end_to_end (ii): `python camera_to_world.py` -- the drop-in with the reference's name and defaults -- run from a
+    directory with `frames` synthetic 1280x384 depth PNGs and a pose file, writing EVERY file the reference writes (one
+    camera txt per frame, the world txt, the fused ASCII PLY).  Wall seconds of the child process, interpreter start included.
+    CPU-only here: the scene is made before anything touches the GPU, the script is its own process."""
+    import shutil
+    import subprocess
+    from PIL import Image
+    td = tempfile.mkdtemp(prefix="r3d_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for d in ("depth", "camera_pose", "point", "point_world", "ply"):
+            os.makedirs(os.path.join(td, d))
+        rng = np.random.default_rng(1234)
+        base = 40 + 30 * np.sin(np.add.outer(np.arange(H), np.arange(W + 7 * frames)) / 37.0)
+        lines = ["id,tx,ty,tz,qx,qy,qz,qw,name,tail\n"]
+        t0 = time.perf_counter()
+        for k in range(frames):
+            depth = np.clip(base[:, 7 * k:7 * k + W] + rng.integers(0, 6, (H, W)), 1, 255).astype(np.uint8)
+            Image.fromarray(depth, "L").save(os.path.join(td, "depth", "%04d.png" % k), compress_level=1)
+            q, t = rng.normal(size=4), rng.normal(size=3) * 10
+            lines.append("%d,%r,%r,%r,%r,%r,%r,%r,%04d.png,x\n" % ((k,) + tuple(map(float, t)) + tuple(map(float, q)) + (k,)))
+        with open(os.path.join(td, "camera_pose", "image_colmap_simi_2.txt"), "w") as f:
+            f.writelines(lines)
+        prep = time.perf_counter() - t0
+        script = os.path.join(ROOT, "3d_reconstruction_system_amd", "transfer", "camera_to_world.py")
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, script], cwd=td, capture_output=True, text=True, timeout=300)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"failed": "camera_to_world.py exited with %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        written = 0
+        for d in ("point", "point_world", "ply"):
+            for name in os.listdir(os.path.join(td, d)):
+                written += os.path.getsize(os.path.join(td, d, name))
+        pts = frames * H * W
+        return {"frames": frames, "points": pts, "wall_s": round(wall, 3), "Mpoints_s": round(pts / wall / 1e6, 1),
+                "s_per_frame": round(wall / frames, 5), "bytes_written": written, "scene_prep_s_not_counted": round(prep, 2),
+                "what": "python camera_to_world.py (drop-in, reference defaults) on %d synthetic 1280x384 PNGs in %s: PNG decode, "
+                        "one fused launch, %d camera txt files + world txt + fused ASCII PLY; wall clock of the child process"
+                        % (frames, "/dev/shm" if td.startswith("/dev/shm") else "a temp dir", frames)}
+    except Exception as e:  # pragma: no cover
+        return {"failed": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def end_to_end_children():
+    """Both end_to_end legs, run BEFORE the parent touches the GPU (same rule as the regimes child)."""
+    import subprocess
+    out = {}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "e2e"], capture_output=True, text=True,
+                           timeout=300, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out["host_buffers"] = json.loads(lines[-1]) if r.returncode == 0 and lines else \
+            {"failed": "child exited with %d: %s" % (r.returncode, (r.stderr or r.stdout)[-200:])}
+    except Exception as e:  # pragma: no cover
+        out["host_buffers"] = {"failed": "%s: %s" % (type(e).__name__, str(e)[:160])}
+    out["dropin_camera_to_world"] = e2e_dropin()
+    return out
 
 
 def apply_cpu_baseline(sample_points=200000):
@@ -561,8 +703,11 @@ def main():
                          "rasters = inputs not in the Infinity Cache, plain / staged; right after an H2D upload; config 4's 1000 "
                          "frames as one launch).  It runs by default and lands in roofline.cold_inputs; rocprofv3 --pmc passes use "
                          "this flag (a profiled process must not start another program)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="N=1: skip the end_to_end object (two more child processes: host buffers over PCIe through "
+                         "r3d_fuse_frames_host, and the camera_to_world.py drop-in on 100 PNG files)")
     ap.add_argument("--out-dtype", default="float32", choices=["float32", "float64"])
-    ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel", "c5", "regimes"],
+    ap.add_argument("--workload", default="fuse", choices=["fuse", "apply", "icp", "voxel", "c5", "regimes", "e2e"],
                     help="fuse (default, the headline C2 line); the others print one JSON line for a secondary kernel on "
                          "one GPU: apply = 4x4 apply on the C2 cloud, icp = C3 (two 500k clouds, SURVEY recipe), voxel = occupancy insert, "
                          "c5 = config 5 geometry (1080p f32 RGBD, colour carried, + voxel insert)")
@@ -571,6 +716,8 @@ def main():
         return c5_sharded(a)
     if a.workload == "regimes":
         return regimes(a)
+    if a.workload == "e2e":
+        return e2e_host(a)
     if a.workload != "fuse":
         return secondary(a)
 
@@ -579,6 +726,10 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1 and not a.no_regimes and a.out_dtype == "float32" \
             and a.frames == FRAMES_PER_GPU:
         cold = regimes_in_child()
+    e2e = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1 and not a.no_end_to_end and a.out_dtype == "float32" \
+            and a.frames == FRAMES_PER_GPU:
+        e2e = end_to_end_children()
 
     import torch
     import torch.distributed as dist
@@ -685,6 +836,8 @@ def main():
                         events[c].record(side)
                 for c in range(C_):
                     stream.wait_event(events[c])
+                    if not isinstance(side_transport, D.R3dTransport):
+                        ctx.inputs_fresh()
                     for r in range(world):
                         r3d.fuse_frames_device(ctx, cam, d_chunks[c][r * fc:].data_ptr(), np.uint8, fc,
                                                p_chunks[c][r * fc:].data_ptr(),
@@ -695,6 +848,8 @@ def main():
             with_algo(algo)
             transport.allgather_rows(depth, frames_pr, out=depth_all)
             transport.allgather_rows(table, frames_pr, out=pose_all)
+            if not isinstance(transport, D.R3dTransport):
+                ctx.inputs_fresh()        # torch's collective wrote the rasters: a foreign producer (r3d_comm tracks its own)
             fuse_all()
         return step_inputs
 
@@ -729,6 +884,13 @@ def main():
         total_pts = world * n_local * a.steps
         k_ms = kernel_region_ms if kernel_region_ms else kernel_ms
         ach = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(F, a.out_dtype)
+        sweeps = region.get("sweeps")            # staging sweeps the library enqueued inside the timed region (counted, not guessed)
+        fused_only_ms = k_ms if not sweeps else kernel_ms
+        kernels = [{"name": kernel_label, "ms": round(fused_only_ms, 5), "launches_per_step": 1}]
+        if sweeps:
+            kernels.insert(0, {"name": "cache_touch_kernel", "ms": round(max(k_ms - fused_only_ms, 0.0), 5),
+                               "launches_per_step": round(sweeps / max(a.steps, 1), 3)})
         line = {
             "metric": "Mpoints/s fused (1280x384 depth, N frames)",
             "value": round(total_pts / elapsed / 1e6, 2),
@@ -759,10 +921,16 @@ def main():
                        "assemble_choice": a.assemble,
                        "parallelism": "frames sharded, %d rank(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(F, a.out_dtype),
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_measured_copy": round(ach / HBM_COPY_GBS, 4),
                          "kernel": kernel_label,
                          "kernel_ms": round(k_ms, 5),
+                         # every kernel the library launched per step of the timed region, each with its own duration (they
+                         # sum to kernel_ms): since round 4 a raster the previous launch has just read is not staged again, so
+                         # the steady-state step is the fused kernel alone (round 3: + a 7.8 us sweep on every launch)
+                         "kernels": kernels,
+                         "staging_sweeps_in_timed_region": sweeps,
+                         "frac_kernel_only": round(bytes_per_launch / (fused_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "timing": ("HIP events on the launch stream around the %d launches of the timed region / %d "
                                     "(same region as ms_per_step, which is the wall clock between the two fences)"
@@ -798,6 +966,7 @@ def main():
             step()
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0 = ctx.get_tuning("fuse_sweeps")
         t0 = time.perf_counter()
         ev0.record(stream)
         for _ in range(a.steps):
@@ -805,6 +974,7 @@ def main():
         ev1.record(stream)
         fence()
         sec = time.perf_counter() - t0
+        region["sweeps"] = ctx.get_tuning("fuse_sweeps") - s0
         return max_over_ranks(sec), ev0.elapsed_time(ev1) / max(a.steps, 1)   # this rank's stream: first start to last end
 
     # N > 1: every assembly strategy, timed briefly BEFORE the headline region (all of them go on the line); the
@@ -815,6 +985,7 @@ def main():
     assemble = {}
     mode = "none"
     fallback = {}
+    region = {}
     beat = {"t": time.monotonic(), "what": "start", "armed": False}
 
     def watchdog():
@@ -918,6 +1089,13 @@ def main():
         line = make_line(mode, elapsed, gpu_ms_per_step, gpu_ms_per_step if mode == "none" else None)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
+        if e2e is not None:
+            line["end_to_end"] = e2e
+            ref = line.get("cpu_baseline", {}).get("files_to_files")
+            drop = e2e.get("dropin_camera_to_world", {})
+            if ref and "s_per_frame" in drop:      # the reference's per-frame path (1 core, loops + PLY) beside the drop-in's
+                drop["cpu_reference_s_per_frame"] = ref["s_per_frame"]
+                drop["cpu_reference_kind"] = "port: oracle/fusion_ref.py loops incl. genply, 1 core, extrapolated per frame"
         print(json.dumps(line), flush=True)
     if use_dist:
         fence()

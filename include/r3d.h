@@ -73,12 +73,17 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
 /* tuning knobs (integers; 0 = auto everywhere): launch geometry only -- "fuse_blocks", "apply_blocks", "nn_blocks"
  * (workgroup counts), "nn_variant" (sources per lane of the NN sweeps: 1/2/4), "nn_warm" (0 auto: a presorted
  * index query with the same source / output buffers as the previous one starts from that one's matches as bounds, and the ICP
- * loops run their later iterations on the wave-local kernel; 1 off; 2 never the wave-local kernel; 3 always when there are bounds: A/B -- the environment variable
- * R3D_FORCE_NN_WARM=<0..3> overrides it for every query of the process: a test hook), "voxel_dedupe" (0 auto, 1 off, 2 on, 3 = the pre-round-3 form with the flush barrier inside its `if`: A/B only),
+ * loops run their later iterations on the wave-local kernel; 1 off; 2 never the wave-local kernel; 3 always when there are bounds: A/B), "voxel_dedupe" (0 auto, 1 off, 2 on, 3 = the pre-round-3 form with the flush barrier inside its `if`: A/B only),
  * "fuse_prefetch" (0 auto, 1 off, 2 on: a read-only sweep stages a fused launch's inputs in the 256 MiB Infinity Cache first,
- * chunk by chunk -- "fuse_chunk_mb", 0 = 96 -- so that the kernel's reads do not mix with its write stream at the DRAM; auto:
- * on when one launch reads more than "fuse_stage_auto_mb" (default 8) MB of small-share inputs: frames that a host upload has just
- * written are not in that cache -- measured: 0.49 of the HBM peak plain, 0.82 staged; staging cached inputs costs 4 %), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
+ * chunk by chunk -- "fuse_chunk_mb", 0 = 96 -- so that the kernel's reads do not mix with its write stream at the DRAM.  auto
+ * stages BY PROVENANCE: a launch whose small-share inputs exceed "fuse_stage_auto_mb" (default 8) MB is staged unless those very
+ * bytes are presumed to be in the cache already -- i.e. a launch of this library on this device read them and fewer than
+ * "fuse_resident_mb" (default 128) MB of other inputs went through since.  r3d_memcpy_h2d / _d2d / r3d_memset, the *_host
+ * pipeline's uploads, r3d_comm_allgather's receives and r3d_dev_free make the library forget the ranges they touch (measured:
+ * a raster an H2D copy has just written runs at 0.49 of the HBM peak plain, 0.82 staged; staging a cached one costs 8 %).
+ * A FOREIGN producer (torch, another library) that rewrites an input buffer in place says so with
+ * r3d_ctx_set_tuning(ctx, "fuse_inputs_fresh", 1): an event, not a state -- nothing on the device is presumed cached any more;
+ * reading the key back gives the number of ranges on record; "fuse_sweeps" counts the staging sweeps enqueued so far), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
  * No knob changes any result bit.  Unknown key -> R3D_ERR_INVALID.  (Kernel A/B variants live in tools/ab_kernels.hip,
  * not in the library.) */
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);
@@ -86,7 +91,7 @@ int r3d_ctx_get_tuning(r3d_ctx* ctx, const char* key, int* value_out);
 
 /* Read-only sweep of a device buffer on the ctx stream: leaves (up to ~100 MB of) it in the 256 MiB Infinity Cache, so that a
  * write-heavy kernel enqueued next reads it from there instead of mixing reads into its HBM write stream (the fused kernels do
- * this themselves for big batches, see "fuse_prefetch").  Asynchronous; changes nothing. */
+ * this themselves where it pays, see "fuse_prefetch" -- and they take a range swept here as cached).  Asynchronous; changes nothing. */
 int r3d_cache_prefetch(r3d_ctx* ctx, const void* d_ptr, size_t bytes);
 
 /* ---- device memory + timing helpers (so a ctypes host needs nothing but this library) */

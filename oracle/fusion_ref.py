@@ -223,6 +223,22 @@ def fuse_frames_loop(depths, quats_xyzw, ts, workdir):
     return np.stack([np.array(xs), np.array(ys), np.array(zs)], axis=1)
 
 
+def genply_loop(coords, pc_file):
+    """c2w:112-134 with its loop structure: the three coordinate lists go into a (3, N) float64 array, every column is
+    formatted with three "%.4f" calls and one str.format into a list of rows, and the file is ONE write of the header
+    template with the joined rows inside.  Same bytes as format_ply (tests/test_oracle_golden.py); here for its cost."""
+    n = len(coords[0])
+    table = np.zeros((3, n))
+    for axis in range(3):
+        table[axis] = coords[axis]
+    fmt4 = lambda value: "%.4f" % value
+    rows = []
+    for col in table.T:
+        rows.append("{} {} {} \n".format(fmt4(col[0]), fmt4(col[1]), fmt4(col[2])))
+    with open(pc_file, "w") as f:
+        f.write(PLY_HEAD % len(rows) + "".join(rows) + PLY_TAIL)
+
+
 # --------------------------------------------------------------------------- tolerance
 def parity_errors(got, ref):
     """SURVEY 8(d) tolerance metrics: (max point-wise ||d||/max(||ref||,1e-6),

@@ -45,3 +45,32 @@ def test_env_rank_world_and_timeout(monkeypatch):
     monkeypatch.setenv("R3D_RENDEZVOUS", "nobody_%d" % os.getpid())
     with pytest.raises(TimeoutError):
         CM.exchange_unique_id(1, 2, timeout=0.3)                    # no rank 0 anywhere
+
+
+def test_a_rank_whose_first_read_failed_is_served_again(monkeypatch):
+    """Rank 0 hands the id to a connection that dies before reading it (no confirmation).  The name must stay up for the
+    rank's second attempt instead of vanishing once 'everyone was served' (round-3 advisor finding)."""
+    import socket
+    import threading
+    import time
+    CM = importlib.import_module(PKG + ".comm")
+    monkeypatch.setenv("R3D_RENDEZVOUS", "retry_%d" % os.getpid())
+    monkeypatch.setattr(CM.Comm, "unique_id", staticmethod(lambda: bytes(range(128))))
+    out = {}
+    t0 = threading.Thread(target=lambda: out.setdefault("r0", CM.exchange_unique_id(0, 2, timeout=20.0)))
+    t0.start()
+    name = CM._rendezvous_name()
+    for _ in range(200):                                   # the failing first attempt of rank 1
+        c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            c.connect(name)
+            c.sendall(CM._nonce() + (1).to_bytes(4, "little"))
+            c.close()                                      # ... gone before a single byte of the id was read
+            break
+        except OSError:
+            c.close()
+            time.sleep(0.02)
+    time.sleep(0.3)
+    assert CM.exchange_unique_id(1, 2, timeout=10.0) == bytes(range(128))      # the retry finds the name still there
+    t0.join(timeout=15)
+    assert not t0.is_alive() and out["r0"] == bytes(range(128))

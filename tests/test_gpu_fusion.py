@@ -581,3 +581,86 @@ def test_auto_staging_above_64_mb_of_inputs_is_bit_identical(R, ctx):
         ctx.set_tuning("fuse_prefetch", 0)
         for buf in (d_depth, d_pose, d_rgb, d_a, d_b, d_ca, d_cb):
             buf.free()
+
+
+def test_staging_follows_provenance_not_size(R, ctx):
+    """`fuse_prefetch` auto since round 4: a launch's inputs are swept into the Infinity Cache first UNLESS the library has
+    reason to presume they are there -- a launch on this device read those very bytes and little else since.  The library's
+    own counter ("fuse_sweeps") says which launches were staged; every cloud is the same bit for bit."""
+    L = importlib.import_module(R.__name__ + "._lib")
+    rng = np.random.default_rng(12)
+    F, H, W = 24, 384, 1280                                      # 11.8 MB of raster: above the 8 MB floor of the policy
+    n = F * H * W
+    d = rng.integers(0, 256, size=(F, H, W), dtype=np.uint8)
+    tab = R.pose_table(rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10)
+    cam = ctx.camera(H, W, *R.REF_INTRINSICS)
+    d_depth, d_pose, d_out = ctx.alloc(n).upload(d), ctx.alloc(tab.nbytes).upload(tab), ctx.alloc(n * 12)
+    d_other = ctx.alloc(n).upload(d)
+    ctx.set_tuning("fuse_prefetch", 1)
+    R.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+    want = d_out.download(np.uint32, n * 3)
+    ctx.set_tuning("fuse_prefetch", 0)
+    ctx.inputs_fresh()
+
+    def launch(src=d_depth):
+        s0 = ctx.get_tuning("fuse_sweeps")
+        L.check(ctx.lib.r3d_memset(ctx.handle, d_out.ptr, 0, n * 12))
+        R.fuse_frames_device(ctx, cam, src.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+        assert np.array_equal(d_out.download(np.uint32, n * 3), want)
+        return ctx.get_tuning("fuse_sweeps") - s0
+
+    try:
+        assert launch() == 1                                     # never seen: staged
+        assert launch() == 0 and launch() == 0                   # the previous launch has just read it: not again
+        d_depth.upload(d)
+        assert launch() == 1 and launch() == 0                   # an H2D copy rewrote it: DMA does not land in the cache
+        L.check(ctx.lib.r3d_memcpy_d2d(ctx.handle, d_depth.ptr + 4096, d_other.ptr + 4096, 1 << 20))
+        assert launch() == 1 and launch() == 0                   # any write through the library that overlaps the range
+        ctx.inputs_fresh()
+        assert launch() == 1 and launch() == 0                   # a foreign producer said so
+        assert launch(d_other) == 1 and launch() == 0 and launch(d_other) == 0    # two rasters fit the budget side by side
+        L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, d_depth.ptr, n))
+        ctx.inputs_fresh()
+        L.check(ctx.lib.r3d_cache_prefetch(ctx.handle, d_depth.ptr, n))
+        assert launch() == 0                                     # the caller swept it himself
+        ctx.set_tuning("fuse_resident_mb", 16)                   # a cache that keeps 16 MB: the two rasters evict each other
+        assert launch(d_other) == 1 and launch() == 1 and launch(d_other) == 1 and launch(d_other) == 0
+        ctx.set_tuning("fuse_resident_mb", 8)                    # ... and one that cannot keep even one of them
+        assert launch() == 1 and launch() == 1
+        ctx.set_tuning("fuse_resident_mb", 128)
+        # the record belongs to the DEVICE: a second context on it sees the first one's reads and writes
+        other = R.Context(0)
+        cam2 = other.camera(H, W, *R.REF_INTRINSICS)
+        assert launch() == 1 and launch() == 0
+        s0 = other.get_tuning("fuse_sweeps")
+        R.fuse_frames_device(other, cam2, d_depth.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
+        other.sync()
+        assert other.get_tuning("fuse_sweeps") - s0 == 0
+        L.check(other.lib.r3d_memcpy_h2d(other.handle, d_depth.ptr, d.ctypes.data, n))
+        other.sync()
+        assert launch() == 1
+        other.close()
+        # forced on / off ignore the record
+        ctx.set_tuning("fuse_prefetch", 2)
+        assert launch() == 1 and launch() == 1
+        ctx.set_tuning("fuse_prefetch", 1)
+        ctx.inputs_fresh()
+        assert launch() == 0
+        # a freed range is forgotten: the next allocation may get the same addresses
+        ctx.set_tuning("fuse_prefetch", 0)
+        assert launch() in (0, 1) and launch() == 0
+        assert ctx.get_tuning("fuse_inputs_fresh") >= 1          # ranges on record
+        d_depth.free()
+        d_depth = ctx.alloc(n).upload(d)
+        assert launch() == 1
+        # below the policy's floor nothing is staged
+        small = 12
+        s0 = ctx.get_tuning("fuse_sweeps")
+        ctx.inputs_fresh()
+        R.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, small, d_pose.ptr, d_out.ptr, np.float32)
+        assert ctx.get_tuning("fuse_sweeps") == s0
+    finally:
+        ctx.set_tuning("fuse_prefetch", 0)
+        ctx.set_tuning("fuse_resident_mb", 128)
+        for b in (d_depth, d_pose, d_out, d_other):
+            b.free()

@@ -162,6 +162,30 @@ def test_29_sums_match_oracle_and_are_repeatable(icp, S, ctx, trim_q, gate_scale
     dev.free()
 
 
+def test_trimmed_untrimmed_trimmed_on_one_ctx(icp, S, ctx):
+    """The selection's 'histogram is known to be zero' record must not outlive a workspace of another layout: the untrimmed
+    pass writes its fp64 partial rows where the 24-class layout keeps its histogram.  trim -> no trim -> trim (twice round,
+    then the plain quantile's 1-class layout in between as well), every result against the oracle and bitwise equal to the
+    first of its kind."""
+    v, pa, dev, cur, idx, d2 = matched_state(icp, S, ctx)
+    nrm = dev.normals()
+    want = {q: PR.plane_sums(cur, pa, nrm, idx, d2, -1.0, q, 20.0) for q in (0.5, 0.0, 0.8)}
+    first = {}
+    d_vals = ctx.alloc(4000 * 4).upload(np.random.default_rng(2).random(4000, dtype=np.float32))
+    for k, q in enumerate((0.5, 0.0, 0.5, 0.0, 0.8, 0.0, 0.5, "quantile", 0.5, 0.8)):
+        if q == "quantile":
+            icp.select_quantile(d_vals.ptr, 4000, 0.3, ctx)
+            continue
+        got = dev.sums(q, 20.0, -1.0)
+        assert got[0] == want[q][0], (k, q)
+        np.testing.assert_allclose(got, want[q], rtol=1e-11, atol=1e-11 * np.abs(want[q]).max(), err_msg="call %d (trim %s)" % (k, q))
+        if q in first:
+            np.testing.assert_array_equal(got.view(np.uint64), first[q].view(np.uint64))
+        first.setdefault(q, got)
+    d_vals.free()
+    dev.free()
+
+
 def test_device_loop_follows_the_oracle_loop_step_for_step(icp, S, ctx):
     """r3d_icp_iterate_plane (culled exact NN, per-class selection, device solve, no host in the loop) against the oracle's
     loop with the brute-force fp32 neighbour definition: same pairs, same steps."""

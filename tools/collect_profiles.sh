@@ -8,11 +8,15 @@ OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
-# the PMC passes must not start another program from a profiled process (the regimes child): --no-regimes
-BENCH_PMC="$BENCH --no-regimes"
-echo "== kernel trace of: $BENCH   (the regimes child process is traced into its own <pid>_ files)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || echo "trace rc=$?"
+# a profiled process must not start another program (the profiler's preload has initialised the GPU): every pass runs the
+# bench with --no-regimes / --no-end-to-end, and the other regimes of the launch are profiled as their own direct command
+BENCH_PMC="$BENCH --no-regimes --no-end-to-end"
+echo "== kernel trace of: $BENCH_PMC"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH_PMC > $OUT/trace.log 2>&1 || echo "trace rc=$?"
 tail -c 600 $OUT/trace.log
+echo "== kernel trace of the regimes (rotating rasters, after H2D, config 4 as one launch), own process"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_regimes -- python3 bench.py --workload regimes > $OUT/trace_regimes.log 2>&1 || echo "regimes trace rc=$?"
+tail -c 300 $OUT/trace_regimes.log
 echo "== PMC FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH_PMC > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch rc=$?"
 echo "== PMC WRITE_SIZE"
