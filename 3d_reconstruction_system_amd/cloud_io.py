@@ -17,65 +17,120 @@ from . import _lib as L
 from .device import xyz_code
 
 
-def read_depth_gray(path):
-    """8-bit grey raster with OpenCV's IMREAD_GRAYSCALE meaning (c2w:160): OpenCV itself if importable.  Without it:
-    8-bit single-channel PNGs (the reference's input) are what they are; a 16-bit grey PNG keeps its HIGH byte -- OpenCV
-    reads those through libpng's png_set_strip_16, i.e. v >> 8, where PIL's 'L' conversion would clip at 255; colour files
-    take PIL's 'L' (ITU-R 601 weights like OpenCV's; equal for the R=G=B files depth maps are saved as)."""
+GRAY_RULES = {"opencv_png": 0, "cvtcolor": 1}
+
+
+class UnsupportedDepthFormat(L.R3DError):
+    """A depth file this build cannot turn into OpenCV's IMREAD_GRAYSCALE raster bit for bit (R3D_ERR_UNSUPPORTED)."""
+
+    def __init__(self, message):
+        L.R3DError.__init__(self, L.ERR_UNSUPPORTED, message)
+
+
+def _is_png(path):
     try:
-        import cv2
-        img = cv2.imread(path, cv2.IMREAD_GRAYSCALE)
-    except ImportError:
-        img = None
-        lib = L.load()
-        h, w, bits = C.c_int(), C.c_int(), C.c_int()
-        if lib.r3d_png_gray_info(os.fsencode(path), C.byref(h), C.byref(w), C.byref(bits)) == L.OK and bits.value == 16:
-            raw = np.empty((h.value, w.value), np.uint16)
-            arr = (C.c_char_p * 1)(os.fsencode(path))
-            if lib.r3d_png_gray_decode_batch(arr, 1, raw.ctypes.data, h.value, w.value, 16) == L.OK:
-                img = (raw >> 8).astype(np.uint8)
-        if img is None:
-            try:
-                from PIL import Image
-                pil = Image.open(path)
-                if pil.mode.startswith("I;16") or pil.mode == "I":
-                    img = (np.array(pil).astype(np.uint32) >> 8).clip(0, 255).astype(np.uint8)
-                else:
-                    img = np.array(pil.convert("L"))
-            except FileNotFoundError:
-                img = None
-    if img is None:
+        with open(path, "rb") as f:
+            return f.read(8) == b"\x89PNG\r\n\x1a\n"
+    except FileNotFoundError:
         raise FileNotFoundError("cannot read depth image %r" % path)
-    return np.ascontiguousarray(img)
 
 
-def read_depth_batch(paths, out=None):
-    """[F,H,W] raster batch for a list of depth PNGs with IMREAD_GRAYSCALE meaning (c2w:160).  8-bit greyscale PNGs --
-    the reference's input -- are inflated and unfiltered by the library's host threads straight into one contiguous
-    (optionally pinned) buffer; any other flavour goes through cv2/PIL file by file."""
+def rgb_to_gray(rgb, rule="cvtcolor"):
+    """[...,3|4] uint8 R,G,B(,A) -> [...] uint8 grey by one of OpenCV's two integer rules (include/r3d.h, R3D_GRAY_*):
+    "opencv_png" = what cv.imread(<png>, IMREAD_GRAYSCALE) does (libpng's rgb_to_gray), "cvtcolor" = cv.cvtColor(BGR2GRAY)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    out = np.empty(rgb.shape[:-1], np.uint8)
+    L.check(L.load().r3d_rgb_to_gray_u8(rgb.ctypes.data, out.size, rgb.shape[-1], GRAY_RULES[rule], out.ctypes.data))
+    return out
+
+
+def _default_rule():
+    return os.environ.get("R3D_GRAY_RULE", "opencv_png")
+
+
+def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
+    """uint8 raster with the meaning of `cv.imread(path, cv.IMREAD_GRAYSCALE)` (c2w:160), without OpenCV.
+      * PNG (the reference's input): decoded natively -- 8-bit grey as stored, 16-bit -> high byte, alpha dropped, colour
+        converted by `rule` ("opencv_png", the default: libpng's rgb_to_gray as OpenCV's PNG reader requests it; or
+        "cvtcolor"; env R3D_GRAY_RULE).  PIL's 'L' weights are neither and are not used.
+      * JPEG (AirSim stores depth as 3-channel JPG): OpenCV asks libjpeg itself for grey output.  PIL can make the same
+        request (draft mode 'L'), but whether the two libjpeg builds agree to the bit cannot be checked here, so it is
+        refused unless allow_pil_jpeg=True / R3D_ALLOW_PIL_JPEG=1 says the caller accepts that.
+      * other formats PIL reads (BMP, TIFF, ...): decoded to RGB by PIL (lossless formats: the same samples), converted by
+        the cvtColor rule, which is what imread does for them."""
+    path = os.fspath(path)
+    try:
+        import cv2                                   # the real thing, where it exists
+        img = cv2.imread(path, cv2.IMREAD_GRAYSCALE)
+        if img is None:
+            raise FileNotFoundError("cannot read depth image %r" % path)
+        return np.ascontiguousarray(img)
+    except ImportError:
+        pass
+    rule = rule or _default_rule()
+    if _is_png(path):
+        lib = L.load()
+        h, w = C.c_int(), C.c_int()
+        rc = lib.r3d_png_gray8_info(os.fsencode(path), C.byref(h), C.byref(w))
+        if rc == L.OK:
+            img = np.empty((h.value, w.value), np.uint8)
+            arr = (C.c_char_p * 1)(os.fsencode(path))
+            L.check(lib.r3d_png_gray8_decode_batch(arr, 1, img.ctypes.data, h.value, w.value, GRAY_RULES[rule]))
+            return img
+        if rc != L.ERR_UNSUPPORTED:
+            L.check(rc)
+        raise UnsupportedDepthFormat("%r: %s.  Palette / interlaced / sub-byte PNGs are not decoded natively and PIL's grey "
+                                     "conversion is not OpenCV's; re-save the file as a plain 8/16-bit PNG" % (path, L.last_error()))
+    from PIL import Image
+    pil = Image.open(path)
+    if pil.format in ("JPEG", "MPO"):
+        if allow_pil_jpeg is None:
+            allow_pil_jpeg = os.environ.get("R3D_ALLOW_PIL_JPEG", "0") not in ("", "0")
+        if not allow_pil_jpeg:
+            raise UnsupportedDepthFormat(
+                "%r is a JPEG: this build has no JPEG decoder of its own and cannot promise OpenCV's IMREAD_GRAYSCALE bytes for it.  "
+                "Fallback: read_depth_gray(path, allow_pil_jpeg=True) or R3D_ALLOW_PIL_JPEG=1 decodes it through PIL asking libjpeg "
+                "for greyscale output (the request OpenCV makes); or convert the depth maps to PNG" % path)
+        pil.draft("L", pil.size)
+        return np.ascontiguousarray(np.array(pil.convert("L") if pil.mode != "L" else pil))
+    if pil.mode == "L":
+        return np.ascontiguousarray(np.array(pil))
+    if pil.mode.startswith("I;16") or pil.mode == "I":
+        return np.ascontiguousarray((np.array(pil).astype(np.uint32) >> 8).clip(0, 255).astype(np.uint8))
+    return rgb_to_gray(np.array(pil.convert("RGB")), "cvtcolor")
+
+
+def read_depth_batch(paths, out=None, rule=None):
+    """[F,H,W] raster batch for a list of depth files with IMREAD_GRAYSCALE meaning (c2w:160).  PNGs of any supported
+    flavour -- 8/16-bit, grey or colour (read_depth_gray has the rules) -- are inflated, unfiltered and converted by the
+    library's host threads straight into one contiguous (optionally pinned) buffer; other formats go file by file."""
     paths = [os.fspath(p) for p in paths]
     if not paths:
         return np.empty((0, 0, 0), np.uint8)
+    rule = rule or _default_rule()
     lib = L.load()
-    h, w, bits = C.c_int(), C.c_int(), C.c_int()
-    rc = lib.r3d_png_gray_info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(bits))
-    if rc == L.OK and bits.value == 8:
+    h, w = C.c_int(), C.c_int()
+    if not os.path.exists(paths[0]):
+        raise FileNotFoundError("cannot read depth image %r" % paths[0])
+    rc = lib.r3d_png_gray8_info(os.fsencode(paths[0]), C.byref(h), C.byref(w)) if _is_png(paths[0]) else L.ERR_UNSUPPORTED
+    if rc == L.OK:
         shape = (len(paths), h.value, w.value)
         if out is None:
             out = np.empty(shape, np.uint8)
         elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        rc = lib.r3d_png_gray_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value, 8)
+        rc = lib.r3d_png_gray8_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value, GRAY_RULES[rule])
         if rc == L.OK:
             return out
         if rc != L.ERR_UNSUPPORTED:
+            for p in paths:
+                if not os.path.exists(p):
+                    raise FileNotFoundError("cannot read depth image %r" % p)
             L.check(rc)
-    elif rc not in (L.OK, L.ERR_UNSUPPORTED):
-        if not os.path.exists(paths[0]):
-            raise FileNotFoundError("cannot read depth image %r" % paths[0])
+    elif rc != L.ERR_UNSUPPORTED:
         L.check(rc)
-    rasters = [read_depth_gray(p) for p in paths]          # colour / 16-bit / palette / interlaced files
+    rasters = [read_depth_gray(p, rule) for p in paths]          # a flavour the batch decoder does not take: file by file
     for p, r in zip(paths, rasters):
         if r.shape != rasters[0].shape:
             raise ValueError("depth %s is %s, expected %s: all frames of one pose file share a camera"

@@ -254,6 +254,8 @@ static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "nn_blocks")) return &ctx->nn_blocks;
   if (!strcmp(key, "apply_blocks")) return &ctx->apply_blocks;
   if (!strcmp(key, "voxel_dedupe")) return &ctx->voxel_dedupe;
+  if (!strcmp(key, "voxel_path")) return &ctx->voxel_path;
+  if (!strcmp(key, "voxel_last_path")) return &ctx->voxel_last_path;
   return nullptr;
 }
 

@@ -830,8 +830,41 @@ int r3d_fuse_frames_voxel(r3d_ctx* ctx, const r3d_camera* cam, const void* d_dep
                           uint32_t* d_rgba_out, r3d_voxelset* vs) {
   R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
   R3D_REQUIRE((d_rgb == nullptr) == (d_rgba_out == nullptr), "colour needs both the rgb plane and the rgba output");
-  return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, d_pose, d_pose != nullptr, d_xyz_out, R3D_F32,
-                     d_rgb, d_rgba_out, vs);
+  R3D_REQUIRE(ctx != nullptr && cam != nullptr, "NULL argument");
+  const bool with_pose = d_pose != nullptr;
+  // Which form is faster depends on the CLOUD: where neighbouring pixels share voxels (scans) the one-launch kernel saves
+  // reading the cloud back; where nearly every point has a voxel of its own, its per-point CAS into the table is the whole cost
+  // and plain fuse + the sort-merge insert wins 2-3x (r3d_voxel.hip).  So a big batch is probed: the first frames are fused by
+  // the plain kernel, a sample of THEIR cloud decides for the rest ("voxel_path" 1 / 2 force a form).  Same cloud, same set.
+  const int64_t hw = (int64_t)cam->height * cam->width, total = hw * (int64_t)n_frames;
+  const int path = ctx->voxel_path;
+  if (path == 1 || n_frames <= 0 || !r3d_voxelset_sort_feasible(vs, total, path == 2)) {
+    if (n_frames > 0) ctx->voxel_last_path = 1;
+    return fuse_common(ctx, cam, d_depth, depth_dtype, n_frames, depth_scale, d_pose, with_pose, d_xyz_out, R3D_F32, d_rgb,
+                       d_rgba_out, vs);
+  }
+  const int64_t want = (int64_t)1 << 18;
+  const int f0 = path == 2 ? n_frames : (int)std::min<int64_t>(n_frames, std::max<int64_t>(1, (want + hw - 1) / hw));
+  int rc = fuse_common(ctx, cam, d_depth, depth_dtype, f0, depth_scale, d_pose, with_pose, d_xyz_out, R3D_F32, d_rgb, d_rgba_out);
+  if (rc) return rc;
+  bool sort = path == 2;
+  if (!sort && (rc = r3d_voxelset_sample(vs, d_xyz_out, hw * f0, &sort))) return rc;
+  const size_t dsz = r3d_depth_size(depth_dtype);
+  const char* depth_rest = static_cast<const char*>(d_depth) + (size_t)hw * f0 * dsz;
+  const double* pose_rest = with_pose ? d_pose + (size_t)f0 * 12 : nullptr;
+  const unsigned char* rgb_rest = d_rgb ? d_rgb + (size_t)hw * f0 * 3 : nullptr;
+  uint32_t* rgba_rest = d_rgba_out ? d_rgba_out + (size_t)hw * f0 : nullptr;
+  float* xyz_rest = d_xyz_out + (size_t)hw * f0 * 3;
+  if (sort) {
+    if (f0 < n_frames && (rc = fuse_common(ctx, cam, depth_rest, depth_dtype, n_frames - f0, depth_scale, pose_rest, with_pose, xyz_rest,
+                                           R3D_F32, rgb_rest, rgba_rest)))
+      return rc;
+    return r3d_voxelset_insert_path(vs, d_xyz_out, total, 2);
+  }
+  if ((rc = r3d_voxelset_insert_path(vs, d_xyz_out, hw * f0, 1))) return rc;
+  if (f0 == n_frames) return R3D_OK;
+  return fuse_common(ctx, cam, depth_rest, depth_dtype, n_frames - f0, depth_scale, pose_rest, with_pose, xyz_rest, R3D_F32, rgb_rest,
+                     rgba_rest, vs);
 }
 
 int r3d_fuse_frames_rgb_host(r3d_ctx* ctx, const r3d_camera* cam, const void* h_depth, int depth_dtype, int n_frames,

@@ -46,6 +46,8 @@ struct r3d_ctx {
                           // nn_warm_kernel from their second iteration on; 1 off; 2 / 3: never / always nn_warm_kernel (A/B)
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
+  int voxel_path = 0;     // big inserts: 0 auto (a sample of the cloud decides), 1 LDS-set + CAS kernel, 2 sort-merge (r3d_voxel.hip)
+  int voxel_last_path = 0; // read-only: the path the last r3d_voxelset_insert took (1 / 2)
   int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set; 3: on, with the
                           // flush barrier inside its `if` (A/B against DESIGN 4.5b's finding only)
   // HIP-event stopwatch
@@ -131,11 +133,17 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
 int r3d_voxelset_device_view(r3d_voxelset* vs, r3d_ctx** ctx, double* factor, uint64_t** d_table, int* log2cap,
                              unsigned long long** d_counters);
 
+// the two insert paths of a voxel set, and how a big insert chooses between them (r3d_voxel.hip)
+bool r3d_voxelset_sort_feasible(const r3d_voxelset* vs, int64_t n_points, bool forced);
+int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, bool* sort_out);
+int r3d_voxelset_insert_path(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int path);
+
 // Device -> pageable host memory through pinned staging chunks (r3d_hostpipe.hip); synchronous.
 int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
 // Stable LSD radix sort of 64-bit keys by their bits [first_bit, bits) (r3d_sort.hip); d_tmp holds n keys.
-int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit = 0);
+int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit = 0,
+                       uint64_t** d_result = nullptr);
 
 // r3d_nnindex.hip: the index's own copy of the target cloud (original order), its size and its context
 int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx);

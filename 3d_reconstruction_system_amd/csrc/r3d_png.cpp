@@ -203,6 +203,75 @@ int decode_gray(const char* path, void* out, size_t cap_bytes, int* h_out, int* 
   }
 }
 
+// ---- colour -> grey, the two integer rules OpenCV has ---------------------------------------------------------------
+// R3D_GRAY_OPENCV_PNG: what cv.imread(<png>, IMREAD_GRAYSCALE) executes (camera_to_world.py:160).  OpenCV's PNG reader
+//   (modules/imgcodecs/src/grfmt_png.cpp, the pinned 4.2.0 included) does not call cvtColor: it asks libpng for grey,
+//   png_set_rgb_to_gray(png_ptr, 1, 0.299, 0.587).  libpng turns the weights into 15-bit integers WITHOUT rounding
+//   (29900 * 32768 / 100000 = 9797, 58700 * 32768 / 100000 = 19234, blue = 32768 - 9797 - 19234 = 3737) and, for 8-bit
+//   samples of a file without gamma information, truncates: (9797 R + 19234 G + 3737 B) >> 15; a pixel whose channels
+//   agree keeps its value; 16-bit samples get (... + 16384) >> 15 and are then reduced to their high byte (strip_16 runs
+//   after rgb_to_gray in libpng's transformation order).
+// R3D_GRAY_CVTCOLOR: cv.cvtColor(..., COLOR_BGR2GRAY) on 8-bit data, which imread applies to the decoders that deliver
+//   colour (BMP, TIFF, WebP ...): (4899 R + 9617 G + 1868 B + 8192) >> 14.
+// Neither equals PIL's 'L' ((19595 R + 38470 G + 7471 B + 32768) >> 16).  cv2 is not in this image, so the rules are
+// restated from the two libraries' sources and pinned by known-answer vectors worked out by hand (tests/test_host_logic.py).
+inline unsigned gray8(unsigned r, unsigned g, unsigned b, int rule) {
+  if (rule == R3D_GRAY_CVTCOLOR) return (4899u * r + 9617u * g + 1868u * b + 8192u) >> 14;
+  return (r == g && r == b) ? r : (9797u * r + 19234u * g + 3737u * b) >> 15;
+}
+inline unsigned gray16(unsigned r, unsigned g, unsigned b) {   // libpng, 16-bit samples
+  return (r == g && r == b) ? r : (9797u * r + 19234u * g + 3737u * b + 16384u) >> 15;
+}
+
+// one PNG as the uint8 raster cv.imread(path, IMREAD_GRAYSCALE) returns; out == NULL: header query
+int decode_gray8_impl(const char* path, unsigned char* out, size_t cap_bytes, int rule, int* h_out, int* w_out, std::string* msg) {
+  PngInfo info;
+  int channels = 0;
+  std::vector<unsigned char> px;
+  int rc = decode_png(path, out == nullptr, &info, &channels, &px, msg);
+  if (h_out) *h_out = (int)info.height;
+  if (w_out) *w_out = (int)info.width;
+  if (rc || !out) return rc;
+  const size_t n = (size_t)info.width * info.height;
+  if (cap_bytes < n) {
+    *msg = std::string("'") + path + "': output buffer too small";
+    return R3D_ERR_NOMEM;
+  }
+  const unsigned char* s = px.data();
+  if (info.bit_depth == 8) {
+    if (channels == 1) {
+      memcpy(out, s, n);
+    } else if (channels == 2) {
+      for (size_t k = 0; k < n; ++k) out[k] = s[2 * k];                       // alpha is stripped
+    } else {
+      for (size_t k = 0; k < n; ++k, s += channels) out[k] = (unsigned char)gray8(s[0], s[1], s[2], rule);
+    }
+  } else {  // 16-bit big-endian samples
+    const size_t px_bytes = (size_t)channels * 2;
+    if (channels <= 2) {
+      for (size_t k = 0; k < n; ++k) out[k] = s[px_bytes * k];                 // the high byte (png_set_strip_16)
+    } else {
+      for (size_t k = 0; k < n; ++k, s += px_bytes) {
+        const unsigned r = (s[0] << 8) | s[1], g = (s[2] << 8) | s[3], b = (s[4] << 8) | s[5];
+        out[k] = rule == R3D_GRAY_CVTCOLOR ? (unsigned char)gray8(r >> 8, g >> 8, b >> 8, rule) : (unsigned char)(gray16(r, g, b) >> 8);
+      }
+    }
+  }
+  return R3D_OK;
+}
+
+int decode_gray8(const char* path, unsigned char* out, size_t cap_bytes, int rule, int* h_out, int* w_out, std::string* msg) {
+  try {
+    return decode_gray8_impl(path, out, cap_bytes, rule, h_out, w_out, msg);
+  } catch (const std::exception& e) {
+    try {
+      *msg = std::string("'") + path + "': " + e.what();
+    } catch (...) {
+    }
+    return R3D_ERR_NOMEM;
+  }
+}
+
 // one 8-bit PNG as R,G,B bytes ([H][W][3]); grey is replicated, alpha is dropped; out == NULL: header query
 int decode_rgb(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, int* channels_out, std::string* msg) {
   try {
@@ -310,6 +379,46 @@ int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out
       rc = R3D_ERR_INVALID;
       *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + "x" + std::to_string(bits) +
              " bits, the batch expects " + std::to_string(width) + "x" + std::to_string(height) + "x" + std::to_string(bit_depth);
+    }
+    return rc;
+  });
+}
+
+int r3d_rgb_to_gray_u8(const unsigned char* pixels, int64_t n_pixels, int channels, int rule, unsigned char* gray_out) {
+  if (n_pixels < 0 || (channels != 3 && channels != 4) || (rule != R3D_GRAY_OPENCV_PNG && rule != R3D_GRAY_CVTCOLOR) ||
+      (n_pixels > 0 && (!pixels || !gray_out))) {
+    r3d_set_error("r3d_rgb_to_gray_u8: bad argument (3 or 4 channels, rule R3D_GRAY_OPENCV_PNG or R3D_GRAY_CVTCOLOR)");
+    return R3D_ERR_INVALID;
+  }
+  for (int64_t k = 0; k < n_pixels; ++k, pixels += channels) gray_out[k] = (unsigned char)gray8(pixels[0], pixels[1], pixels[2], rule);
+  return R3D_OK;
+}
+
+int r3d_png_gray8_info(const char* path, int* height, int* width) {
+  if (!path) {
+    r3d_set_error("r3d_png_gray8_info: path is NULL");
+    return R3D_ERR_INVALID;
+  }
+  std::string msg;
+  const int rc = decode_gray8(path, nullptr, 0, R3D_GRAY_OPENCV_PNG, height, width, &msg);
+  if (rc) r3d_set_error("%s", msg.c_str());
+  return rc;
+}
+
+int r3d_png_gray8_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width, int rule) {
+  if (n_files < 0 || (n_files > 0 && (!paths || !h_out)) || height <= 0 || width <= 0 ||
+      (rule != R3D_GRAY_OPENCV_PNG && rule != R3D_GRAY_CVTCOLOR)) {
+    r3d_set_error("r3d_png_gray8_decode_batch: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  const size_t frame_bytes = (size_t)height * width;
+  return run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
+    int h = 0, w = 0;
+    int rc = paths[k] ? decode_gray8(paths[k], h_out + frame_bytes * k, frame_bytes, rule, &h, &w, msg) : R3D_ERR_INVALID;
+    if (rc == R3D_OK && (h != height || w != width)) {
+      rc = R3D_ERR_INVALID;
+      *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + ", the batch expects " +
+             std::to_string(width) + "x" + std::to_string(height);
     }
     return rc;
   });

@@ -136,8 +136,10 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
 // Sorts d_keys[0..n) ascending by their bits [first_bit, bits) (the span rounded up to whole 8-bit digits, <= 64), STABLY:
 // keys that agree on those bits keep their input order -- so a caller whose low bits already ascend (an index packed under
 // a Morton code) skips the passes over them.
-// d_tmp: scratch of n keys.  The result is in d_keys when the number of passes is even, else it is copied back.
-int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit) {
+// d_tmp: scratch of n keys.  The result is in d_keys when the number of passes is even, else it is copied back -- unless the
+// caller asks where it ended up (d_result != NULL: *d_result = d_keys or d_tmp, no copy).
+int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit, uint64_t** d_result) {
+  if (d_result) *d_result = d_keys;
   if (n <= 1) return R3D_OK;
   if (first_bit < 0 || first_bit >= bits) first_bit = 0;
   const int passes = (bits - first_bit + 7) / 8;
@@ -163,7 +165,10 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
     dst = t;
   }
   R3D_HIP(hipGetLastError());
-  if (src != d_keys) R3D_HIP(hipMemcpyAsync(d_keys, src, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  if (d_result)
+    *d_result = src;
+  else if (src != d_keys)
+    R3D_HIP(hipMemcpyAsync(d_keys, src, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
   return R3D_OK;
 }
 

@@ -187,6 +187,213 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
   }
 }
 
+
+// ---- sort-merge insert: the path for clouds whose points mostly fall into DIFFERENT voxels -----------------------------------
+// The LDS-set kernel above wins when neighbouring pixels share voxels (scans: tens of points per voxel).  On a cloud without
+// surfaces (BASELINE C2's random depth: 49.2 M points -> 48.4 M voxels) nothing dedupes and every point ends as a 64-bit CAS
+// at a random place of a 1 GB table: 3.3 ms, ~80 B written per 8-byte key (profiles/r03_all_kernels.json) -- every CAS drags
+// a whole line through HBM and back.  Random access is the cost, so this path has none:
+//   voxel_keys_kernel     12 B/point in, 8 B out: word = REGION << 48 | packed key, where REGION = the top bits of the key's
+//                         home slot in the table (the packed key has 48 bits: the region rides in the 16 above them);
+//   r3d_radix_sort_u64    on the region bits only (two 8-bit passes for a 65536-region table): the words of one region
+//                         become one contiguous run;
+//   voxel_bounds_kernel   where each region's run starts;
+//   voxel_merge_kernel    one workgroup per region that received keys: the region's 2048..8192 table slots come into LDS with
+//                         16-byte loads, the run's keys are inserted THERE (LDS compare-and-swap, linear probing from the home
+//                         slot -- the same placement rule as table_insert, so later lookups and CAS inserts see a table they
+//                         understand), the region goes back with 16-byte stores.  A probe that runs off the region's end is
+//                         deferred to a spill list, inserted by voxel_spill_kernel with the ordinary CAS afterwards (~0.1 % of
+//                         the keys at load 0.4).
+// HBM sees streams only.  Per point: 20 B (keys) + 48 B (two sort passes) + 8 B (bounds) + 8 B + 16 B x capacity / n (merge).
+constexpr int kRegionMinLog2 = 11;   // slots per region: 2048 (16 KB of LDS) ... 8192 (64 KB)
+constexpr int kRegionMaxLog2 = 13;
+constexpr int kMaxRegionBits = 16;   // what fits above a 48-bit key
+constexpr uint64_t kKeyMask48 = ((uint64_t)1 << 48) - 1;
+constexpr uint64_t kSkip = ~0ull;    // a word that carries no key (ignored point, duplicate of the previous lane)
+
+__device__ __forceinline__ uint64_t home_slot(uint64_t key, int log2cap) { return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap); }
+
+__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor, int log2cap,
+                                                              int region_log2, uint64_t* __restrict__ words,
+                                                              uint64_t* __restrict__ table, unsigned long long* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
+  unsigned n_new = 0, n_ignored = 0, n_over = 0;
+  const int64_t n_tiles = (n + kThreads * 4 - 1) / (kThreads * 4);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t base = tile * (kThreads * 4) + threadIdx.x;
+    P3 p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + (int64_t)r * kThreads;
+      p[r] = reinterpret_cast<const P3*>(xyz)[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + (int64_t)r * kThreads;
+      uint64_t key = kEmpty;
+      bool live = i < n;
+      if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
+        ++n_ignored;
+        live = false;
+        key = kEmpty;
+      }
+      const uint64_t prev = prev_lane_u64(key);
+      if (live && lane > 0 && prev == key) live = false;
+      uint64_t word = kSkip;
+      if (live) {
+        word = ((home_slot(key, log2cap) >> region_log2) << 48) | key;
+        if (word == kSkip) {   // voxel (65535, 65535, 65535) in region 65535 would read as "no key": it goes in by itself
+          const int r2 = table_insert(table, mask, log2cap, key);
+          n_new += r2 > 0 ? 1u : 0u;
+          n_over += r2 < 0 ? 1u : 0u;
+        }
+      }
+      if (i < n) words[i] = word;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_ignored += __shfl_down(n_ignored, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  if (lane == 0) {
+    if (n_new) atomicAdd(&counters[0], (unsigned long long)n_new);
+    if (n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);
+    if (n_over) atomicAdd(&counters[2], (unsigned long long)n_over);
+  }
+}
+
+// starts[b] = index of the first word whose region is >= b, for b in [0, n_regions + 1]; words that carry no key sort behind
+// every region when there are fewer than 65536 of them (pseudo-region n_regions) and are skipped by value in any case
+__global__ __launch_bounds__(kThreads) void voxel_bounds_kernel(const uint64_t* __restrict__ words, int64_t n, uint32_t n_regions,
+                                                                uint32_t* __restrict__ starts) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t cur = i < n ? (int64_t)min((uint32_t)(words[i] >> 48), n_regions) : (int64_t)n_regions + 1;
+    const int64_t prev = i > 0 ? (int64_t)min((uint32_t)(words[i - 1] >> 48), n_regions) : -1;
+    for (int64_t b = prev + 1; b <= cur; ++b) starts[b] = (uint32_t)i;
+  }
+}
+
+template <int REGION_LOG2>
+__global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* __restrict__ words, const uint32_t* __restrict__ starts,
+                                                               uint32_t n_regions, uint64_t* __restrict__ table, int log2cap,
+                                                               unsigned long long* __restrict__ counters,
+                                                               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                               unsigned long long spill_cap) {
+  constexpr int kSlots = 1 << REGION_LOG2;
+  __shared__ __attribute__((aligned(16))) unsigned long long region[kSlots];
+  __shared__ unsigned changed;
+  const int lane = threadIdx.x & 63;
+  unsigned n_new = 0, n_over = 0;
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {   // workgroup-uniform trip count
+    const uint32_t lo = starts[r], hi = starts[r + 1];
+    if (lo == hi) continue;                                          // nothing for this region: its slots are not even read
+    ulonglong2* g = reinterpret_cast<ulonglong2*>(table + ((uint64_t)r << REGION_LOG2));
+    r3d_vox::lds_settle();
+    __syncthreads();   // the previous region's write-back has read the LDS copy
+    if (threadIdx.x == 0) changed = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots / 2 / kThreads; ++k) reinterpret_cast<ulonglong2*>(region)[k * kThreads + threadIdx.x] = g[k * kThreads + threadIdx.x];
+    r3d_vox::lds_settle();
+    __syncthreads();
+    bool mine_changed = false;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+      const uint64_t word = words[i];
+      if (word == kSkip) continue;
+      const uint64_t key = word & kKeyMask48;
+      bool done = false;
+      for (uint32_t s = (uint32_t)home_slot(key, log2cap) & (kSlots - 1); s < (uint32_t)kSlots && !done; ++s) {
+        const unsigned long long old = atomicCAS(&region[s], (unsigned long long)kEmpty, (unsigned long long)key);
+        if (old == kEmpty) {
+          ++n_new;
+          mine_changed = true;
+          done = true;
+        } else if (old == key) {
+          done = true;
+        }
+      }
+      if (!done) {   // every slot from home to the region's end is taken by others: the probe goes on in the next region -- later
+        const unsigned long long at = atomicAdd(spill_count, 1ull);
+        if (at < spill_cap) spill[at] = key; else ++n_over;
+      }
+    }
+    if (mine_changed) changed = 1;   // (benign race: everybody writes the same value)
+    r3d_vox::lds_settle();
+    __syncthreads();
+    if (changed) {
+#pragma unroll
+      for (int k = 0; k < kSlots / 2 / kThreads; ++k) g[k * kThreads + threadIdx.x] = reinterpret_cast<const ulonglong2*>(region)[k * kThreads + threadIdx.x];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  if (lane == 0) {
+    if (n_new) atomicAdd(&counters[0], (unsigned long long)n_new);
+    if (n_over) atomicAdd(&counters[2], (unsigned long long)n_over);
+  }
+}
+
+// the deferred keys, by the ordinary CAS (their count is known on the device only: fixed grid, device-side bound)
+__global__ __launch_bounds__(kThreads) void voxel_spill_kernel(const uint64_t* __restrict__ spill, const unsigned long long* __restrict__ spill_count,
+                                                               unsigned long long spill_cap, uint64_t* __restrict__ table, int log2cap,
+                                                               unsigned long long* __restrict__ counters) {
+  const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
+  unsigned long long n = *spill_count;
+  if (n > spill_cap) n = spill_cap;
+  unsigned n_new = 0, n_over = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kThreads) {
+    const int r = table_insert(table, mask, log2cap, spill[i]);
+    n_new += r > 0 ? 1u : 0u;
+    n_over += r < 0 ? 1u : 0u;
+  }
+  if (n_new) atomicAdd(&counters[0], (unsigned long long)n_new);
+  if (n_over) atomicAdd(&counters[2], (unsigned long long)n_over);
+}
+
+// How alike are neighbouring points?  Each sampling workgroup takes 4 consecutive tiles (4096 points: a few image rows) and
+// counts the distinct voxels among them in an LDS set; sums[0] += points that have a key, sums[1] += distinct keys.
+constexpr int kSampleSlots = 8192;
+__global__ __launch_bounds__(kThreads) void voxel_sample_kernel(const float* __restrict__ xyz, int64_t n, double factor, int64_t stride_tiles,
+                                                                unsigned long long* __restrict__ sums) {
+  __shared__ unsigned long long set[kSampleSlots];
+  for (int k = threadIdx.x; k < kSampleSlots; k += kThreads) set[k] = kEmpty;
+  __syncthreads();
+  const int64_t first = (int64_t)blockIdx.x * stride_tiles * (kThreads * 4);
+  unsigned valid = 0, distinct = 0;
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = first + (int64_t)r * kThreads + threadIdx.x;
+    if (i >= n) break;
+    const P3 p = reinterpret_cast<const P3*>(xyz)[i];
+    uint64_t key;
+    if (!r3d_vox::voxel_key(p.x, p.y, p.z, factor, &key)) continue;
+    ++valid;
+    uint32_t s = (((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u)) >> 19;   // 13 bits
+    for (int probe = 0; probe < kSampleSlots; ++probe) {   // <= 4096 keys in 8192 slots: always ends
+      const unsigned long long old = atomicCAS(&set[s], (unsigned long long)kEmpty, (unsigned long long)key);
+      if (old == kEmpty) {
+        ++distinct;
+        break;
+      }
+      if (old == key) break;
+      s = (s + 1) & (kSampleSlots - 1);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    valid += __shfl_down(valid, off, 64);
+    distinct += __shfl_down(distinct, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (valid) atomicAdd(&sums[0], (unsigned long long)valid);
+    if (distinct) atomicAdd(&sums[1], (unsigned long long)distinct);
+  }
+}
+
 // Insert ready-made 48-bit Morton codes (another rank's occupied voxels: the union step of a sharded map).
 __global__ __launch_bounds__(kThreads) void voxel_insert_codes_kernel(const uint64_t* __restrict__ codes, int64_t n,
                                                                       uint64_t* __restrict__ table, int log2cap,
@@ -522,6 +729,103 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
   R3D_REQUIRE(n_points >= 0, "n_points must be >= 0");
   if (n_points == 0) return R3D_OK;
   R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
+  // big inserts: a sample of the cloud decides between the two paths ("voxel_path": 1 / 2 force one)
+  int path = 1;
+  if (vs->ctx->voxel_path == 2 && r3d_voxelset_sort_feasible(vs, n_points, true)) {
+    path = 2;
+  } else if (vs->ctx->voxel_path == 0 && r3d_voxelset_sort_feasible(vs, n_points, false)) {
+    bool sort = false;
+    if ((rc = r3d_voxelset_sample(vs, d_xyz, n_points, &sort))) return rc;
+    path = sort ? 2 : 1;
+  }
+  return r3d_voxelset_insert_path(vs, d_xyz, n_points, path);
+}
+
+}  // extern "C"
+
+// Is the sort-merge path possible for this set (region sizes that fit LDS, region ids that fit above the key) and, unless
+// `forced`, worth considering for this many points (its fixed costs -- a dozen launches, the table streamed once -- want a
+// big insert and a table that is not vastly larger than it)?
+bool r3d_voxelset_sort_feasible(const r3d_voxelset* vs, int64_t n_points, bool forced) {
+  if (vs->log2cap < 16 || vs->log2cap > kMaxRegionBits + kRegionMaxLog2) return false;
+  if (forced) return n_points >= 1;
+  return n_points >= ((int64_t)1 << 22) && vs->capacity <= (uint64_t)n_points * 16;
+}
+
+// *sort_out = the sample says most points have a voxel of their own (>= 1 distinct voxel per 2 points among neighbours):
+// the CAS path would pay a random HBM access for nearly every point.  Synchronises the stream (16 bytes come back).
+int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, bool* sort_out) {
+  *sort_out = false;
+  r3d_ctx* ctx = vs->ctx;
+  const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
+  const int64_t samples = std::max<int64_t>(1, std::min<int64_t>(256, n_tiles / 4));
+  void* ws = nullptr;
+  int rc = r3d_scratch(ctx, 5, 64, &ws);
+  if (rc) return rc;
+  unsigned long long* d_sums = static_cast<unsigned long long*>(ws);
+  R3D_HIP(hipMemsetAsync(d_sums, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(voxel_sample_kernel, dim3((unsigned)samples), dim3(kThreads), 0, ctx->stream, d_xyz, n_points, vs->factor,
+                     n_tiles / samples, d_sums);
+  R3D_HIP(hipGetLastError());
+  unsigned long long h[2] = {0, 0};
+  R3D_HIP(hipMemcpyAsync(h, d_sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  R3D_HIP(hipStreamSynchronize(ctx->stream));
+  *sort_out = h[0] > 0 && 2 * h[1] >= h[0];
+  return R3D_OK;
+}
+
+static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) {
+  r3d_ctx* ctx = vs->ctx;
+  const int region_bits = std::min(kMaxRegionBits, vs->log2cap - kRegionMinLog2);
+  const int region_log2 = vs->log2cap - region_bits;
+  const uint32_t n_regions = (uint32_t)1 << region_bits;
+  const int64_t chunk = (int64_t)1 << 27;   // points per round: 1 GB of words + 1 GB of sort scratch
+  int rc;
+  for (int64_t off = 0; off < n_points; off += chunk) {
+    const int64_t m = std::min(chunk, n_points - off);
+    const float* src = d_xyz + off * 3;
+    const uint64_t spill_cap = (uint64_t)m;   // every key may be deferred (a nearly full table): the list can take them all
+    void *words_v = nullptr, *tmp_v = nullptr, *ws = nullptr;
+    if ((rc = r3d_scratch(ctx, 1, (size_t)m * 8, &words_v))) return rc;
+    if ((rc = r3d_scratch(ctx, 2, (size_t)m * 8, &tmp_v))) return rc;
+    const size_t starts_bytes = (((size_t)n_regions + 2) * sizeof(uint32_t) + 63) & ~(size_t)63;
+    if ((rc = r3d_scratch(ctx, 5, 64 + starts_bytes + spill_cap * 8, &ws))) return rc;
+    unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 32);
+    uint32_t* d_starts = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + 64);
+    uint64_t* d_spill = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + 64 + starts_bytes);
+    uint64_t* words = static_cast<uint64_t*>(words_v);
+    R3D_HIP(hipMemsetAsync(d_spill_count, 0, 8, ctx->stream));
+    const int64_t n_tiles = (m + kThreads * 4 - 1) / (kThreads * 4);
+    const unsigned key_blocks = (unsigned)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(key_blocks), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, vs->log2cap, region_log2,
+                       words, vs->d_table, vs->d_counters);
+    R3D_HIP(hipGetLastError());
+    uint64_t* sorted = nullptr;
+    // both region digits, always: the words that carry no key (all ones) must end up behind every region
+    if ((rc = r3d_radix_sort_u64(ctx, words, static_cast<uint64_t*>(tmp_v), m, 64, 48, &sorted))) return rc;
+    const unsigned bound_blocks = (unsigned)std::min<int64_t>((m + kThreads) / kThreads, (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL(voxel_bounds_kernel, dim3(bound_blocks), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted, m, n_regions, d_starts);
+    const unsigned merge_blocks = std::min<uint32_t>(n_regions, (uint32_t)ctx->num_cus * 32);
+#define R3D_LAUNCH_MERGE(L2)                                                                                                      \
+  hipLaunchKernelGGL(voxel_merge_kernel<L2>, dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted,         \
+                     (const uint32_t*)d_starts, n_regions, vs->d_table, vs->log2cap, vs->d_counters, d_spill, d_spill_count,     \
+                     (unsigned long long)spill_cap)
+    if (region_log2 == 11) R3D_LAUNCH_MERGE(11);
+    else if (region_log2 == 12) R3D_LAUNCH_MERGE(12);
+    else R3D_LAUNCH_MERGE(13);
+#undef R3D_LAUNCH_MERGE
+    hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
+                       (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters);
+    R3D_HIP(hipGetLastError());
+  }
+  return R3D_OK;
+}
+
+// path 1: the LDS-set + CAS kernel; path 2: sort-merge (the caller has checked r3d_voxelset_sort_feasible)
+int r3d_voxelset_insert_path(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int path) {
+  if (n_points <= 0) return R3D_OK;
+  vs->ctx->voxel_last_path = path;
+  if (path == 2) return insert_sorted(vs, d_xyz, n_points);
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
   int blocks = vs->ctx->num_cus * 8;
   if ((int64_t)blocks > n_tiles) blocks = (int)n_tiles;
@@ -537,6 +841,8 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
   R3D_HIP(hipGetLastError());
   return R3D_OK;
 }
+
+extern "C" {
 
 int r3d_voxelset_insert_host(r3d_voxelset* vs, const float* h_xyz, int64_t n_points) {
   R3D_REQUIRE(vs != nullptr, "voxel set is NULL");

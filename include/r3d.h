@@ -428,6 +428,22 @@ int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double
  * contiguous [n][height][width] buffer (pageable or pinned). */
 int r3d_png_gray_info(const char* path, int* height, int* width, int* bit_depth);
 int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out, int height, int width, int bit_depth);
+/* The SAME raster cv.imread(path, IMREAD_GRAYSCALE) returns, for every non-interlaced 8/16-bit PNG: uint8 [n][height][width].
+ * 8-bit grey: as stored; 16-bit: the high byte (libpng's strip_16, OpenCV's choice); alpha: dropped; RGB(A): converted by
+ * `rule` --
+ *   R3D_GRAY_OPENCV_PNG  (9797 R + 19234 G + 3737 B) >> 15, a pixel with R = G = B keeps its value: libpng's
+ *                        png_set_rgb_to_gray(1, 0.299, 0.587), which is what OpenCV's PNG reader (4.2.0, the reference's pin,
+ *                        and later) calls instead of cvtColor; the reference's camera_to_world.py:160 on a PNG file;
+ *   R3D_GRAY_CVTCOLOR    (4899 R + 9617 G + 1868 B + 8192) >> 14: cv.cvtColor(BGR2GRAY), imread's rule for the formats whose
+ *                        decoders deliver colour (BMP, TIFF, WebP).
+ * (Files carrying gamma information -- gAMA / sRGB / iCCP chunks -- make libpng convert in linear light: not restated here;
+ * palette, interlaced and sub-byte PNGs: R3D_ERR_UNSUPPORTED.)  r3d_rgb_to_gray_u8: the rule alone, on [n][channels] 8-bit
+ * R,G,B(,A) pixels already in memory. */
+#define R3D_GRAY_OPENCV_PNG 0
+#define R3D_GRAY_CVTCOLOR 1
+int r3d_png_gray8_info(const char* path, int* height, int* width);
+int r3d_png_gray8_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width, int rule);
+int r3d_rgb_to_gray_u8(const unsigned char* pixels, int64_t n_pixels, int channels, int rule, unsigned char* gray_out);
 /* The colour images of the RGBD path (the `Image.open(imgpath)` of genply_noRGB, pixel_to_camera.py:58-60): non-interlaced
  * 8-bit PNGs -- RGB, RGBA (alpha dropped) or grey (replicated) -- as R,G,B bytes, n files into one [n][height][width][3]
  * buffer, which is what r3d_fuse_frames_rgb takes.  *channels = samples per pixel in the file. */
@@ -445,12 +461,23 @@ struct r3d_comm; /* multi-GPU communicator, declared below */
 int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_voxelset** vs_out);
 int r3d_voxelset_destroy(r3d_voxelset* vs);
 int r3d_voxelset_clear(r3d_voxelset* vs);
-/* insert float32 xyz points (asynchronous on the ctx stream; may be called once per frame batch) */
+/* Insert float32 xyz points (on the ctx stream; may be called once per frame batch).  Two paths with the same result:
+ *   1  per-workgroup LDS set in front of 64-bit CAS into the table: for clouds whose neighbouring points share voxels (scans);
+ *   2  sort-merge: region-tagged keys, two radix passes, every table region updated in LDS and streamed back -- no random
+ *      access to HBM: for clouds where nearly every point has a voxel of its own (2-3x faster there; needs a table of
+ *      2^16..2^29 slots).
+ * Tuning key "voxel_path": 0 (default) = inserts of >= 2^22 points into a table of <= 16 slots per point are SAMPLED first
+ * (256 groups of 4096 neighbouring points; path 2 when they show >= 1 distinct voxel per 2 points) -- that sample
+ * synchronises the stream once (16 bytes come back); smaller inserts take path 1 without asking.  1 / 2 force a path
+ * (asynchronous).  "voxel_last_path" reads back which one the last insert took. */
 int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points);
 /* The cloud AND the map in one launch: r3d_fuse_frames_rgb (f32 xyz; d_pose NULL = camera frame; d_rgb and d_rgba_out both
  * NULL = no colour) followed by r3d_voxelset_insert of the points it wrote, without reading them back: the keys are taken
  * from the very floats the store writes.  Same cloud bytes, same set, same counters as the two calls.  (camera_to_world.py
- * :77-86 feeding txt_transfer_octomap.py:16-26 in the reference.) */
+ * :77-86 feeding txt_transfer_octomap.py:16-26 in the reference.)  The call picks the faster FORM itself ("voxel_path" 0): a
+ * big batch is probed -- its first ~2^18 points are fused by the plain kernel and sampled as above -- and the rest goes
+ * either through the one-launch kernel (scans) or through plain fuse + sort-merge insert of the whole cloud (no surfaces);
+ * "voxel_path" 1 = always the one-launch kernel, 2 = always fuse + sort-merge. */
 int r3d_fuse_frames_voxel(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int depth_dtype, int n_frames,
                           double depth_scale, const double* d_pose, const unsigned char* d_rgb, float* d_xyz_out,
                           uint32_t* d_rgba_out, r3d_voxelset* vs);

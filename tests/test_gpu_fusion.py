@@ -602,7 +602,8 @@ def test_staging_follows_provenance_not_size(R, ctx):
     ctx.set_tuning("fuse_prefetch", 0)
     ctx.inputs_fresh()
 
-    def launch(src=d_depth):
+    def launch(src=None):
+        src = src or d_depth
         s0 = ctx.get_tuning("fuse_sweeps")
         L.check(ctx.lib.r3d_memset(ctx.handle, d_out.ptr, 0, n * 12))
         R.fuse_frames_device(ctx, cam, src.ptr, np.uint8, F, d_pose.ptr, d_out.ptr, np.float32)
@@ -652,12 +653,13 @@ def test_staging_follows_provenance_not_size(R, ctx):
         assert ctx.get_tuning("fuse_inputs_fresh") >= 1          # ranges on record
         d_depth.free()
         d_depth = ctx.alloc(n).upload(d)
-        assert launch() == 1
+        assert launch(d_depth) == 1
         # below the policy's floor nothing is staged
         small = 12
         s0 = ctx.get_tuning("fuse_sweeps")
         ctx.inputs_fresh()
         R.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, small, d_pose.ptr, d_out.ptr, np.float32)
+        ctx.sync()
         assert ctx.get_tuning("fuse_sweeps") == s0
     finally:
         ctx.set_tuning("fuse_prefetch", 0)

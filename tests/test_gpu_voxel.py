@@ -238,24 +238,29 @@ def fuse_on_device(ctx, depth, q, t, K, rgb=None):
 
 
 def check_device_cloud_against_oracle(V, ctx, d_xyz, n, res, capacity):
-    """insert with the LDS set, and without it: both must equal the oracle's set of the very same f32 cloud."""
+    """Every way in: the CAS path with the LDS set and without it, the sort-merge path, and the library's own choice between
+    them -- all must equal the oracle's set of the very same f32 cloud."""
     cloud = d_xyz.download(np.float32, n * 3).reshape(-1, 3)
     want, dropped = OM.occupied_set(cloud, res)
     got = {}
-    for knob in (0, 1):
-        ctx.set_tuning("voxel_dedupe", knob)
+    for path, dedupe in ((1, 0), (1, 1), (2, 0), (0, 0)):
+        ctx.set_tuning("voxel_path", path)
+        ctx.set_tuning("voxel_dedupe", dedupe)
         try:
             vs = V.VoxelSet(res, capacity, ctx)
             vs.insert_device(d_xyz.ptr, n)
-            assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}, (knob, vs.stats(), len(want))
-            got[knob] = vs.codes()
+            assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}, (path, dedupe, vs.stats(), len(want))
+            if path:
+                assert ctx.get_tuning("voxel_last_path") == path
+            got[path, dedupe] = vs.codes()
             vs.insert_device(d_xyz.ptr, n)                        # idempotent at size
             assert vs.stats()["voxels"] == len(want)
             vs.close()
         finally:
             ctx.set_tuning("voxel_dedupe", 0)
-    np.testing.assert_array_equal(got[0], want)
-    np.testing.assert_array_equal(got[1], got[0])
+            ctx.set_tuning("voxel_path", 0)
+    for k in got:
+        np.testing.assert_array_equal(got[k], want, err_msg=str(k))
     return want
 
 
@@ -460,3 +465,133 @@ def test_fused_cloud_and_voxels_any_run_length(V, ctx, blocks):
     finally:
         ctx.set_tuning("fuse_blocks", 0)
     assert st["voxels"] > 50_000 and st["overflow"] == 0
+
+
+# ---- the sort-merge insert (path 2): region-tagged keys, two radix passes, table regions updated in LDS ---------------------
+
+@pytest.mark.parametrize("n,log2cap,spread", [(1, 16, 1.0), (1000, 16, 3.0), (4097, 17, 8.0), (300_000, 20, 40.0), (300_000, 19, 40.0),
+                                               (1_000_000, 21, 60.0), (2_000_003, 22, 25.0), (3_000_000, 29, 80.0)])
+def test_sort_merge_insert_matches_oracle_and_the_cas_path(V, ctx, n, log2cap, spread):
+    """forced at every size: one region's worth of keys up to millions, tables of 2^16 .. 2^29 slots (regions of 2048, 4096 and
+    8192 slots), load factors up to ~0.55; non-finite / out-of-range points and repeats among them; then the SAME table through
+    the CAS path (what one path placed the other must find) and back"""
+    rng = np.random.default_rng(n + log2cap)
+    pts = (rng.normal(size=(n, 3)) * spread).astype(np.float32)
+    if n >= 1000:
+        pts[::97] = pts[5]                                  # repeats far apart
+        pts[3:200:7] = pts[2:199:7]                         # ... and in neighbouring lanes
+        pts[11] = (np.nan, 0, 0)
+        pts[12] = (0, np.inf, 0)
+        pts[13] = (5000.0, 0, 0)
+        pts[14] = (3276.75, 3276.75, 3276.75)               # key 65535 on every axis: the all-ones packed key
+    want, dropped = OM.occupied_set(pts)
+    d_xyz = ctx.alloc(n * 12).upload(pts)
+    vs = V.VoxelSet(0.1, 1 << log2cap, ctx)
+    try:
+        ctx.set_tuning("voxel_path", 2)
+        vs.insert_device(d_xyz.ptr, n)
+        assert ctx.get_tuning("voxel_last_path") == 2
+        assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}, (vs.stats(), len(want), dropped)
+        np.testing.assert_array_equal(vs.codes(), want)
+        ctx.set_tuning("voxel_path", 1)
+        vs.insert_device(d_xyz.ptr, n)                      # the CAS path finds every key the merge placed
+        assert vs.stats()["voxels"] == len(want)
+        ctx.set_tuning("voxel_path", 2)
+        vs.insert_device(d_xyz.ptr, n)                      # ... and the merge finds its own
+        assert vs.stats()["voxels"] == len(want) and vs.stats()["overflow"] == 0
+        # a set that already holds half of the voxels (CAS-placed), then everything through the merge
+        vs.clear()
+        ctx.set_tuning("voxel_path", 1)
+        vs.insert_device(d_xyz.ptr, n // 2)
+        ctx.set_tuning("voxel_path", 2)
+        vs.insert_device(d_xyz.ptr, n)
+        assert vs.stats()["voxels"] == len(want)
+        np.testing.assert_array_equal(vs.codes(), want)
+    finally:
+        ctx.set_tuning("voxel_path", 0)
+        vs.close()
+        d_xyz.free()
+
+
+def test_sort_merge_insert_on_a_nearly_full_table_spills_and_still_agrees(V, ctx):
+    """load factor 0.93: long probe runs cross region boundaries all the time (thousands of deferred keys), some keys were
+    CAS-placed in the NEXT region before -- and the set is still the oracle's; a table that is too small reports overflow"""
+    rng = np.random.default_rng(44)
+    n = 62_500
+    pts = (rng.random((n, 3)) * 12).astype(np.float32)
+    want, dropped = OM.occupied_set(pts)
+    assert 0.85 < len(want) / 65536 < 0.99
+    d_xyz = ctx.alloc(n * 12).upload(pts)
+    try:
+        for first in (0, n // 3):
+            vs = V.VoxelSet(0.1, 1 << 16, ctx)
+            ctx.set_tuning("voxel_path", 1)
+            vs.insert_device(d_xyz.ptr, first)
+            ctx.set_tuning("voxel_path", 2)
+            vs.insert_device(d_xyz.ptr, n)
+            assert vs.stats() == {"voxels": len(want), "ignored_points": dropped + OM.occupied_set(pts[:first])[1], "overflow": 0}
+            np.testing.assert_array_equal(vs.codes(), want)
+            vs.close()
+        big = (rng.random((200_000, 3)) * 30).astype(np.float32)
+        d_big = ctx.alloc(big.nbytes).upload(big)
+        vs = V.VoxelSet(0.1, 1 << 16, ctx)
+        vs.insert_device(d_big.ptr, big.shape[0])
+        st = vs.stats()
+        assert st["voxels"] == 1 << 16 and st["overflow"] > 0
+        vs.close()
+        d_big.free()
+    finally:
+        ctx.set_tuning("voxel_path", 0)
+        d_xyz.free()
+
+
+def test_small_tables_and_small_inserts_take_the_cas_path(V, ctx):
+    rng = np.random.default_rng(3)
+    pts = (rng.normal(size=(50_000, 3)) * 5).astype(np.float32)
+    d_xyz = ctx.alloc(pts.nbytes).upload(pts)
+    want = OM.occupied_set(pts)[0]
+    try:
+        for cap, path, expect in ((1 << 15, 2, 1), (1 << 17, 0, 1), (1 << 17, 2, 2), (1 << 17, 1, 1)):
+            ctx.set_tuning("voxel_path", path)
+            vs = V.VoxelSet(0.1, cap, ctx)
+            vs.insert_device(d_xyz.ptr, pts.shape[0])
+            assert ctx.get_tuning("voxel_last_path") == expect, (cap, path)
+            if cap > 1 << 15:
+                np.testing.assert_array_equal(vs.codes(), want)
+            vs.close()
+    finally:
+        ctx.set_tuning("voxel_path", 0)
+        d_xyz.free()
+
+
+@pytest.mark.parametrize("kind", ["random", "room"])
+def test_the_library_picks_the_path_by_sampling_the_cloud(V, ctx, kind):
+    """config 2's worst case (random depth: a voxel per point) goes through the sort-merge path, a room scan (tens of points per
+    voxel) through the LDS-set kernel -- for r3d_voxelset_insert and for r3d_fuse_frames_voxel, which also chooses between its
+    one-launch kernel and plain fuse + insert; clouds, colour words, sets and counters equal either way."""
+    F, H, W = 12, 384, 1280                                    # 5.9 M points: above the 2^22 floor of the sampling
+    rng = np.random.default_rng(17)
+    if kind == "room":
+        depth, q, t, K = room_views(F, H, W, seed=17)
+    else:
+        depth = rng.integers(1, 256, size=(F, H, W), dtype=np.uint8)
+        q, t, K = rng.normal(size=(F, 4)), rng.normal(size=(F, 3)) * 10, _r3d().REF_INTRINSICS
+    rgb = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    expect = 2 if kind == "random" else 1
+    d_xyz = fuse_on_device(ctx, depth, q, t, K)
+    vs = V.VoxelSet(0.1, 1 << 24, ctx)
+    vs.insert_device(d_xyz.ptr, F * H * W)
+    assert ctx.get_tuning("voxel_last_path") == expect
+    want, dropped = OM.occupied_set(d_xyz.download(np.float32, F * H * W * 3).reshape(-1, 3))
+    assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}
+    np.testing.assert_array_equal(vs.codes(), want)
+    vs.close()
+    d_xyz.free()
+    for path in (0, 1, 2):
+        ctx.set_tuning("voxel_path", path)
+        try:
+            st = fused_vs_two_calls(V, ctx, depth, q, t, K, rgb, 0.1, 1 << 24)
+            assert ctx.get_tuning("voxel_last_path") == (path or expect)
+        finally:
+            ctx.set_tuning("voxel_path", 0)
+        assert st["voxels"] == len(want)

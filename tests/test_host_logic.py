@@ -398,3 +398,114 @@ def test_depth_maps_saved_in_colour_decode_natively_when_their_channels_agree(R,
     got = R.cloud_io.read_depth_batch([paths[0], str(tmp_path / "c.png")])                  # falls back per file, still works
     np.testing.assert_array_equal(got[0], greys[0])
     assert got.shape == (2, H, W)
+
+
+def _gray_opencv_png(r, g, b):
+    """libpng's 8-bit rgb_to_gray as OpenCV's PNG reader requests it (weights 0.299, 0.587 -> 15-bit integers, truncated twice)."""
+    rc, gc = 29900 * 32768 // 100000, 58700 * 32768 // 100000
+    r, g, b = (np.asarray(c).astype(np.int64) for c in (r, g, b))
+    v = (rc * r + gc * g + (32768 - rc - gc) * b) >> 15
+    return np.where((r == g) & (g == b), r, v).astype(np.uint8)
+
+
+def _gray_cvtcolor(r, g, b):
+    r, g, b = (np.asarray(c).astype(np.int64) for c in (r, g, b))
+    return ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
+
+
+def test_colour_to_grey_rules_known_answers_and_sweep(R):
+    """f3: the two integer colour -> grey rules OpenCV has (include/r3d.h R3D_GRAY_*), cv2 being absent: known answers worked
+    out by hand from the two libraries' formulas, the rounding edges, and 200k random triples against an independent NumPy
+    restatement.  The three candidates (libpng-as-OpenCV-calls-it, cvtColor, PIL 'L') really are three different maps."""
+    kat = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [1, 1, 1], [254, 255, 255], [12, 200, 77],
+                    [0, 1, 0], [3, 0, 0], [0, 0, 9], [128, 127, 128]], np.uint8)
+    # (9797 R + 19234 G + 3737 B) >> 15, equal channels kept           (4899 R + 9617 G + 1868 B + 8192) >> 14
+    want_png = [76, 149, 29, 255, 0, 1, 254, 129, 0, 0, 1, 127]       # 2498235>>15, 4904670>>15, 952935>>15, ...
+    want_cvt = [76, 150, 29, 255, 0, 1, 255, 130, 1, 1, 1, 127]       # 1257437>>14, 2460527>>14, 484532>>14, ...
+    np.testing.assert_array_equal(R.cloud_io.rgb_to_gray(kat, "opencv_png"), want_png)
+    np.testing.assert_array_equal(R.cloud_io.rgb_to_gray(kat, "cvtcolor"), want_cvt)
+    rng = np.random.default_rng(77)
+    px = rng.integers(0, 256, (200000, 3), dtype=np.uint8)
+    px[:5000, 1] = px[:5000, 0]                                        # many near-grey pixels: the equal-channel branch and its edge
+    px[:2500, 2] = px[:2500, 0]
+    r, g, b = px[:, 0], px[:, 1], px[:, 2]
+    got_png, got_cvt = R.cloud_io.rgb_to_gray(px, "opencv_png"), R.cloud_io.rgb_to_gray(px, "cvtcolor")
+    np.testing.assert_array_equal(got_png, _gray_opencv_png(r, g, b))
+    np.testing.assert_array_equal(got_cvt, _gray_cvtcolor(r, g, b))
+    r, g, b = (c.astype(np.int64) for c in (r, g, b))
+    pil_l = ((19595 * r + 38470 * g + 7471 * b + 32768) >> 16).astype(np.uint8)
+    assert (got_png != got_cvt).mean() > 0.3 and (got_png != pil_l).mean() > 0.3 and (got_cvt != pil_l).mean() > 0.001
+    assert np.abs(got_png.astype(int) - got_cvt).max() == 1
+    # every exact tie of the cvtColor rounding: (4899 R + 9617 G + 1868 B) mod 16384 == 8192 rounds UP
+    rr, gg, bb = np.meshgrid(np.arange(256), np.arange(256), np.arange(0, 256, 5), indexing="ij")
+    s = 4899 * rr + 9617 * gg + 1868 * bb
+    tie = (s % 16384) == 8192
+    if tie.any():
+        t = np.stack([rr[tie], gg[tie], bb[tie]], 1).astype(np.uint8)
+        np.testing.assert_array_equal(R.cloud_io.rgb_to_gray(t, "cvtcolor"), (s[tie] // 16384 + 1).astype(np.uint8))
+    rgba = np.concatenate([px[:1000], rng.integers(0, 256, (1000, 1), dtype=np.uint8)], 1)      # alpha is ignored
+    np.testing.assert_array_equal(R.cloud_io.rgb_to_gray(rgba, "cvtcolor"), got_cvt[:1000])
+    L = importlib.import_module(R.__name__ + "._lib")
+    with pytest.raises(R.R3DError):
+        L.check(R.load_library().r3d_rgb_to_gray_u8(px.ctypes.data, 10, 3, 7, px.ctypes.data))
+
+
+def test_colour_depth_files_take_the_opencv_rules_not_pils(R, tmp_path, monkeypatch):
+    """cv.imread(path, IMREAD_GRAYSCALE) (c2w:160) on files that really are colour: PNG -> libpng's rule, natively, in the
+    batch decoder too (8- and 16-bit, with and without alpha); BMP -> the cvtColor rule; JPEG -> refused with the fallback
+    named, accepted on request."""
+    from PIL import Image
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV present: its own decode is used")
+    except ImportError:
+        pass
+    L = importlib.import_module(R.__name__ + "._lib")
+    rng = np.random.default_rng(5)
+    H, W = 33, 47
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    Image.fromarray(np.dstack([rgb, rng.integers(0, 256, (H, W), dtype=np.uint8)]), "RGBA").save(tmp_path / "ca.png")
+    want = _gray_opencv_png(r, g, b)
+    for name in ("c.png", "ca.png"):
+        np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / name)), want)
+        np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / name), rule="cvtcolor"), _gray_cvtcolor(r, g, b))
+    got = R.cloud_io.read_depth_batch([str(tmp_path / "c.png"), str(tmp_path / "ca.png")])
+    np.testing.assert_array_equal(got, np.stack([want, want]))
+    monkeypatch.setenv("R3D_GRAY_RULE", "cvtcolor")
+    np.testing.assert_array_equal(R.cloud_io.read_depth_batch([str(tmp_path / "c.png")])[0], _gray_cvtcolor(r, g, b))
+    monkeypatch.delenv("R3D_GRAY_RULE")
+    assert (want != np.array(Image.open(tmp_path / "c.png").convert("L"))).mean() > 0.3       # PIL's 'L' is another map
+    # 16-bit RGB PNG (hand-made: PIL does not write them): libpng converts at 16 bits, rounds, THEN keeps the high byte
+    import struct
+    import zlib
+    v16 = rng.integers(0, 65536, (H, W, 3), dtype=np.uint16)
+    v16[:4] = v16[:4, :, :1]                                                                   # some equal-channel rows
+    raw = b"".join(b"\x00" + v16[y].astype(">u2").tobytes() for y in range(H))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    (tmp_path / "c16.png").write_bytes(png)
+    r6, g6, b6 = (v16[..., k].astype(np.int64) for k in range(3))
+    w16 = np.where((r6 == g6) & (g6 == b6), r6, (9797 * r6 + 19234 * g6 + 3737 * b6 + 16384) >> 15)
+    np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "c16.png")), (w16 >> 8).astype(np.uint8))
+    # BMP: decoded in colour, converted by cvtColor's rule
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.bmp")
+    np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "c.bmp")), _gray_cvtcolor(r, g, b))
+    # JPEG: refused by default, with the way out in the message
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.jpg", quality=95)
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat) as e:
+        R.cloud_io.read_depth_gray(str(tmp_path / "c.jpg"))
+    assert e.value.code == L.ERR_UNSUPPORTED and "allow_pil_jpeg" in str(e.value) and "R3D_ALLOW_PIL_JPEG" in str(e.value)
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
+        R.cloud_io.read_depth_batch([str(tmp_path / "c.jpg")])
+    j = R.cloud_io.read_depth_gray(str(tmp_path / "c.jpg"), allow_pil_jpeg=True)
+    assert j.shape == (H, W) and j.dtype == np.uint8 and np.abs(j.astype(int) - _gray_cvtcolor(r, g, b)).mean() < 12
+    monkeypatch.setenv("R3D_ALLOW_PIL_JPEG", "1")
+    np.testing.assert_array_equal(R.cloud_io.read_depth_batch([str(tmp_path / "c.jpg")])[0], j)
+    # a palette PNG is not guessed at either
+    Image.fromarray(rgb, "RGB").quantize(16).save(tmp_path / "p.png")
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
+        R.cloud_io.read_depth_gray(str(tmp_path / "p.png"))
