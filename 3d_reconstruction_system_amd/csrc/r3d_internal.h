@@ -143,7 +143,9 @@ int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t b
 
 // Stable LSD radix sort of 64-bit keys by their bits [first_bit, bits) (r3d_sort.hip); d_tmp holds n keys.
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit = 0,
-                       uint64_t** d_result = nullptr);
+                       uint64_t** d_result = nullptr, bool first_hist_done = false);
+constexpr int kSortTile = 4096;   // keys per workgroup of every sort kernel
+int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* n_blocks_out);
 
 // r3d_nnindex.hip: the index's own copy of the target cloud (original order), its size and its context
 int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx);

@@ -7,10 +7,10 @@
 //   digit_histogram_kernel  tile of 4096 keys per workgroup -> 256-bin LDS histogram -> hist[bin][workgroup]
 //   digit_scan_kernel       one workgroup per bin: exclusive prefix over workgroups (contiguous chunk per thread, wave
 //                           shuffle scan, LDS across waves), bin totals (the scatter turns them into bin bases itself)
-//   digit_scatter_kernel    re-reads the tile in 16 rounds of 256 keys; inside a round every lane finds the lanes of
-//                           its wave with the same digit by 8 ballots, the rank among them by popcount, waves are
-//                           ordered through a [4][256] LDS count table; destination = bin base + workgroup prefix +
-//                           running count of earlier rounds + rank.  Order of equal digits is preserved (stable).
+//   digit_scatter_kernel    re-reads the tile; every wave ranks its quarter on its own (8 ballots per round find the lanes
+//                           with the same digit, a per-wave LDS counter carries the earlier rounds), the tile is put into
+//                           bin order in LDS and written out by consecutive lanes; destination = bin base + workgroup
+//                           prefix + place inside the tile's bin.  Order of equal digits is preserved (stable).
 #include "r3d_internal.h"
 
 namespace {
@@ -69,13 +69,28 @@ __global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restri
   if (threadIdx.x == kThreads - 1) totals[blockIdx.x] = before;   // the last chunk ends at the row's total (empty chunks pass it on)
 }
 
+// The tile's 4096 keys leave in BIN ORDER: ranked without a workgroup barrier per round, staged in LDS, written out by
+// consecutive lanes.  (Until round 4 every round of 256 keys took four barriers and every lane stored its key where its
+// rank said -- a wave instruction of 64 eight-byte stores to ~56 different places: 490 us per pass on 49 M keys = 1.6 TB/s.)
+//   * wave w owns keys [1024 w, 1024 (w + 1)) of the tile, 16 rounds of 64: inside a round the lanes with the same digit find
+//     each other by 8 ballots, the lowest of them bumps the wave's OWN digit counter in LDS (returning add: the wave's earlier
+//     rounds are in it) and hands the old value to its peers -- rank within the wave's quarter, no other wave involved;
+//   * one barrier; thread b turns bin b's four wave counts into the bin's place in the tile (exclusive scan over the bins),
+//     the waves' offsets inside the bin, and the bin's global position for this tile (scan kernel's prefix + bin base);
+//   * every key goes to sorted[bin start + waves before + rank] in LDS (input order inside a bin: the sort stays stable);
+//   * the tile is written out front to back: lanes that follow each other write addresses that follow each other as long
+//     as the bin does not change -- runs of ~16 keys = 128 B on uniform digits, the whole tile in one piece on sorted input.
 __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                                                                  const uint32_t* __restrict__ hist, int n_blocks,
                                                                  const uint32_t* __restrict__ totals,
                                                                  uint64_t* __restrict__ out) {
-  __shared__ uint64_t dest[kBins];                // next free output slot of every bin for this workgroup
-  __shared__ uint32_t cnt[kThreads / 64][kBins];  // per-wave digit counts of the current round
-  __shared__ uint64_t wave_total[kThreads / 64];
+  constexpr int kWaves = kThreads / 64, kPerWave = kTile / kWaves;
+  __shared__ uint64_t sorted[kTile];
+  __shared__ uint32_t wave_cnt[kWaves][kBins];   // running counts while ranking, then the waves' offsets inside each bin
+  __shared__ uint32_t bin_start[kBins];
+  __shared__ uint64_t g_base[kBins];
+  __shared__ uint64_t wave_total[kWaves];
+  __shared__ uint32_t wave_sum[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // bin bases = exclusive prefix of the 256 bin totals, computed here by every workgroup (a launch of its own for one wave's
   // work cost more in launch latency than all workgroups repeating it: sorts of 0.3 - 0.5 M keys are launch-bound)
@@ -89,21 +104,25 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
       if (lane >= off) inc += t;
     }
     if (lane == 63) wave_total[wave] = inc;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) wave_cnt[w][threadIdx.x] = 0;
     __syncthreads();
     bin_base = inc - mine;
     for (int w = 0; w < wave; ++w) bin_base += wave_total[w];
   }
-  dest[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
   const int64_t base = (int64_t)blockIdx.x * kTile;
-  for (int r = 0; r < kRounds; ++r) {
+  const int64_t first = base + (int64_t)wave * kPerWave + lane;
+  uint64_t key[kRounds];
+  uint32_t place[kRounds];   // rank inside the wave's quarter among the keys of the same digit
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) cnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t i = base + r * kThreads + threadIdx.x;
-    const bool live = i < n;
-    const uint64_t key = live ? keys[i] : 0;
-    const uint32_t digit = (uint32_t)(key >> shift) & 0xff;
-    // lanes of this wave that hold the same digit (dead lanes match nobody)
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = first + r * 64;
+    key[r] = i < n ? keys[i] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const bool live = first + r * 64 < n;
+    const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xff;
     unsigned long long peers = __ballot(live);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -111,23 +130,51 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
       peers &= ((digit >> b) & 1) ? m : ~m;
     }
     const uint32_t rank = __popcll(peers & ((1ull << lane) - 1));
-    if (live && rank == 0) cnt[wave][digit] = __popcll(peers);  // the lowest peer lane publishes the wave's count
-    __syncthreads();
-    if (live) {
-      uint32_t before = 0;
+    uint32_t before = 0;
+    if (live && rank == 0) before = atomicAdd(&wave_cnt[wave][digit], (uint32_t)__popcll(peers));
+    // (dead lanes have peers == 0 only when no lane is live with digit 0 ... they read lane 0, and never use the value)
+    before = __shfl(before, peers ? __ffsll((long long)peers) - 1 : 0, 64);
+    place[r] = before + rank;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    // thread b: bin b over the four waves
+    uint32_t c[kWaves], tot = 0;
 #pragma unroll
-      for (int w = 0; w < kThreads / 64; ++w) before += (w < wave) ? cnt[w][digit] : 0;
-      out[dest[digit] + before + rank] = key;
+    for (int w = 0; w < kWaves; ++w) {
+      c[w] = wave_cnt[w][threadIdx.x];
+      tot += c[w];
     }
-    __syncthreads();
-    {
-      uint32_t total = 0;
+    const uint32_t inc = wave_inclusive_scan(tot, lane);
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();   // everybody has read the running counts; the wave sums are there
+    uint32_t start = inc - tot;
+    for (int w = 0; w < wave; ++w) start += wave_sum[w];
+    bin_start[threadIdx.x] = start;
+    uint32_t off = 0;
 #pragma unroll
-      for (int w = 0; w < kThreads / 64; ++w) total += cnt[w][threadIdx.x];
-      dest[threadIdx.x] += total;
+    for (int w = 0; w < kWaves; ++w) {
+      wave_cnt[w][threadIdx.x] = off;
+      off += c[w];
     }
-    // the next round's zeroing of cnt is ordered behind this update by the barrier at its top
-    __syncthreads();
+    g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    if (first + r * 64 < n) {
+      const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xff;
+      sorted[bin_start[digit] + wave_cnt[wave][digit] + place[r]] = key[r];
+    }
+  }
+  __syncthreads();
+  const int n_tile = (int)(n - base < (int64_t)kTile ? n - base : (int64_t)kTile);
+#pragma unroll 4
+  for (int j = threadIdx.x; j < n_tile; j += kThreads) {
+    const uint64_t k = sorted[j];
+    const uint32_t digit = (uint32_t)(k >> shift) & 0xff;
+    out[g_base[digit] + (uint32_t)(j - (int)bin_start[digit])] = k;
   }
 }
 
@@ -138,25 +185,40 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
 // a Morton code) skips the passes over them.
 // d_tmp: scratch of n keys.  The result is in d_keys when the number of passes is even, else it is copied back -- unless the
 // caller asks where it ended up (d_result != NULL: *d_result = d_keys or d_tmp, no copy).
-int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit, uint64_t** d_result) {
+// The workspace of a sort of n keys (scratch slot 3): hist[bin][workgroup] + the 256 bin totals.  A producer that writes the
+// keys tile by tile (kSortTile keys per workgroup, same tiling as the sort) can fill `hist` for the FIRST digit itself and
+// save the sort its first histogram pass (r3d_voxel.hip's key kernel does).
+int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* n_blocks_out) {
+  const int64_t n_blocks64 = (n + kTile - 1) / kTile;
+  R3D_REQUIRE(n_blocks64 < ((int64_t)1 << 31), "too many keys for one sort");
+  void* ws = nullptr;
+  const size_t hist_bytes = (size_t)kBins * n_blocks64 * sizeof(uint32_t);
+  int rc = r3d_scratch(ctx, 3, hist_bytes + kBins * sizeof(uint32_t) + 64, &ws);
+  if (rc) return rc;
+  *hist_out = static_cast<uint32_t*>(ws);
+  *n_blocks_out = (int)n_blocks64;
+  return R3D_OK;
+}
+
+int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit, uint64_t** d_result,
+                       bool first_hist_done) {
+  static_assert(kTile == kSortTile, "r3d_internal.h announces the sort's tile size");
   if (d_result) *d_result = d_keys;
   if (n <= 1) return R3D_OK;
   if (first_bit < 0 || first_bit >= bits) first_bit = 0;
   const int passes = (bits - first_bit + 7) / 8;
-  const int64_t n_blocks64 = (n + kTile - 1) / kTile;
-  R3D_REQUIRE(n_blocks64 < ((int64_t)1 << 31), "too many keys for one sort");
-  const int n_blocks = (int)n_blocks64;
-  void* ws = nullptr;
-  const size_t hist_bytes = (size_t)kBins * n_blocks * sizeof(uint32_t);
-  int rc = r3d_scratch(ctx, 3, hist_bytes + kBins * sizeof(uint32_t) + 64, &ws);
+  uint32_t* hist = nullptr;
+  int n_blocks = 0;
+  int rc = r3d_radix_sort_workspace(ctx, n, &hist, &n_blocks);
   if (rc) return rc;
-  uint32_t* hist = static_cast<uint32_t*>(ws);
-  uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + ((hist_bytes + 15) & ~(size_t)15));
+  const size_t hist_bytes = (size_t)kBins * n_blocks * sizeof(uint32_t);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + ((hist_bytes + 15) & ~(size_t)15));
   uint64_t* src = d_keys;
   uint64_t* dst = d_tmp;
   for (int p = 0; p < passes; ++p) {
     const int shift = first_bit + 8 * p;
-    hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
+    if (p > 0 || !first_hist_done)
+      hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, totals);
     hipLaunchKernelGGL(digit_scatter_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks,
                        (const uint32_t*)totals, dst);

@@ -34,6 +34,7 @@ struct r3d_voxelset {
   uint64_t capacity = 0;  // power of two
   int log2cap = 0;
   unsigned long long* d_counters = nullptr;  // [0] voxels, [1] ignored points, [2] overflow, [3] compaction cursor
+  bool pristine = true;   // nothing has gone into the table since it was created / cleared (the merge then need not read it)
 };
 
 namespace {
@@ -213,24 +214,30 @@ constexpr uint64_t kSkip = ~0ull;    // a word that carries no key (ignored poin
 
 __device__ __forceinline__ uint64_t home_slot(uint64_t key, int log2cap) { return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap); }
 
+// One workgroup per SORT TILE (4096 points -> 4096 words): besides the words it leaves the tile's histogram of the first sort
+// digit (bits 48..55) where the sort's first pass would have had to compute it from the words again (hist[bin][tile]).
 __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor, int log2cap,
                                                               int region_log2, uint64_t* __restrict__ words,
-                                                              uint64_t* __restrict__ table, unsigned long long* __restrict__ counters) {
+                                                              uint32_t* __restrict__ hist, int n_tiles,
+                                                              uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                              unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t bins[256];
   const int lane = threadIdx.x & 63;
-  const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
-  unsigned n_new = 0, n_ignored = 0, n_over = 0;
-  const int64_t n_tiles = (n + kThreads * 4 - 1) / (kThreads * 4);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t base = tile * (kThreads * 4) + threadIdx.x;
+  unsigned n_ignored = 0;
+  bins[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < kSortTile / (kThreads * 4); ++q) {
     P3 p[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + (int64_t)r * kThreads;
+      const int64_t i = base + (int64_t)(q * 4 + r) * kThreads;
       p[r] = reinterpret_cast<const P3*>(xyz)[i < n ? i : n - 1];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + (int64_t)r * kThreads;
+      const int64_t i = base + (int64_t)(q * 4 + r) * kThreads;
       uint64_t key = kEmpty;
       bool live = i < n;
       if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
@@ -243,36 +250,54 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
       uint64_t word = kSkip;
       if (live) {
         word = ((home_slot(key, log2cap) >> region_log2) << 48) | key;
-        if (word == kSkip) {   // voxel (65535, 65535, 65535) in region 65535 would read as "no key": it goes in by itself
-          const int r2 = table_insert(table, mask, log2cap, key);
-          n_new += r2 > 0 ? 1u : 0u;
-          n_over += r2 < 0 ? 1u : 0u;
+        if (word == kSkip) {   // voxel (65535, 65535, 65535) in region 65535 would read as "no key": it takes the deferred way in
+          spill[atomicAdd(spill_count, 1ull)] = key;   // (the list holds one entry per point: always room)
         }
       }
-      if (i < n) words[i] = word;
+      if (i < n) {
+        words[i] = word;
+        atomicAdd(&bins[(uint32_t)(word >> 48) & 0xff], 1u);
+      }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    n_new += __shfl_down(n_new, off, 64);
-    n_ignored += __shfl_down(n_ignored, off, 64);
-    n_over += __shfl_down(n_over, off, 64);
-  }
-  if (lane == 0) {
-    if (n_new) atomicAdd(&counters[0], (unsigned long long)n_new);
-    if (n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);
-    if (n_over) atomicAdd(&counters[2], (unsigned long long)n_over);
-  }
+  for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
+  if (lane == 0 && n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);
+  r3d_vox::lds_settle();
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = bins[threadIdx.x];
 }
 
 // starts[b] = index of the first word whose region is >= b, for b in [0, n_regions + 1]; words that carry no key sort behind
-// every region when there are fewer than 65536 of them (pseudo-region n_regions) and are skipped by value in any case
+// every region when there are fewer than 65536 of them (pseudo-region n_regions) and are skipped by value in any case.
+// Eight words per thread (four 16-byte loads in flight) + the one in front of them.
 __global__ __launch_bounds__(kThreads) void voxel_bounds_kernel(const uint64_t* __restrict__ words, int64_t n, uint32_t n_regions,
                                                                 uint32_t* __restrict__ starts) {
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kThreads) {
-    const int64_t cur = i < n ? (int64_t)min((uint32_t)(words[i] >> 48), n_regions) : (int64_t)n_regions + 1;
-    const int64_t prev = i > 0 ? (int64_t)min((uint32_t)(words[i - 1] >> 48), n_regions) : -1;
-    for (int64_t b = prev + 1; b <= cur; ++b) starts[b] = (uint32_t)i;
+  const int64_t groups = (n + 8) / 8 + 1;   // covers index n (the end marker) too
+  for (int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kThreads) {
+    const int64_t i0 = g * 8;
+    if (i0 > n) break;
+    uint64_t w[8];
+    if (i0 + 8 <= n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2*>(words + i0)[k];
+        w[2 * k] = v.x;
+        w[2 * k + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = i0 + k < n ? words[i0 + k] : 0;
+    }
+    int64_t prev = i0 > 0 ? (int64_t)min((uint32_t)(words[i0 - 1] >> 48), n_regions) : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = i0 + k;
+      if (i > n) break;
+      const int64_t cur = i < n ? (int64_t)min((uint32_t)(w[k] >> 48), n_regions) : (int64_t)n_regions + 1;
+      for (int64_t b = prev + 1; b <= cur; ++b) starts[b] = (uint32_t)i;
+      prev = cur;
+    }
   }
 }
 
@@ -281,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
                                                                uint32_t n_regions, uint64_t* __restrict__ table, int log2cap,
                                                                unsigned long long* __restrict__ counters,
                                                                uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                               unsigned long long spill_cap) {
+                                                               unsigned long long spill_cap, int pristine) {
   constexpr int kSlots = 1 << REGION_LOG2;
   __shared__ __attribute__((aligned(16))) unsigned long long region[kSlots];
   __shared__ unsigned changed;
@@ -294,8 +319,13 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
     r3d_vox::lds_settle();
     __syncthreads();   // the previous region's write-back has read the LDS copy
     if (threadIdx.x == 0) changed = 0;
+    if (pristine) {   // nothing has been inserted since the set was cleared: the region is known to be empty, half the stream saved
 #pragma unroll
-    for (int k = 0; k < kSlots / 2 / kThreads; ++k) reinterpret_cast<ulonglong2*>(region)[k * kThreads + threadIdx.x] = g[k * kThreads + threadIdx.x];
+      for (int k = 0; k < kSlots / 2 / kThreads; ++k) reinterpret_cast<ulonglong2*>(region)[k * kThreads + threadIdx.x] = ulonglong2{kEmpty, kEmpty};
+    } else {
+#pragma unroll
+      for (int k = 0; k < kSlots / 2 / kThreads; ++k) reinterpret_cast<ulonglong2*>(region)[k * kThreads + threadIdx.x] = g[k * kThreads + threadIdx.x];
+    }
     r3d_vox::lds_settle();
     __syncthreads();
     bool mine_changed = false;
@@ -666,6 +696,7 @@ int r3d_voxelset_device_view(r3d_voxelset* vs, r3d_ctx** ctx, double* factor, ui
   *d_table = vs->d_table;
   *log2cap = vs->log2cap;
   *d_counters = vs->d_counters;
+  vs->pristine = false;   // whoever asks for the table is about to write it
   return R3D_OK;
 }
 
@@ -719,6 +750,7 @@ int r3d_voxelset_clear(r3d_voxelset* vs) {
   if (rc) return rc;
   R3D_HIP(hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), vs->ctx->stream));
   R3D_HIP(hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), vs->ctx->stream));
+  vs->pristine = true;
   return R3D_OK;
 }
 
@@ -795,21 +827,25 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     uint64_t* d_spill = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + 64 + starts_bytes);
     uint64_t* words = static_cast<uint64_t*>(words_v);
     R3D_HIP(hipMemsetAsync(d_spill_count, 0, 8, ctx->stream));
-    const int64_t n_tiles = (m + kThreads * 4 - 1) / (kThreads * 4);
-    const unsigned key_blocks = (unsigned)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * 32);
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(key_blocks), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, vs->log2cap, region_log2,
-                       words, vs->d_table, vs->d_counters);
+    uint32_t* hist = nullptr;
+    int n_tiles = 0;
+    if ((rc = r3d_radix_sort_workspace(ctx, m, &hist, &n_tiles))) return rc;
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, vs->log2cap, region_log2,
+                       words, hist, n_tiles, d_spill, d_spill_count, vs->d_counters);
     R3D_HIP(hipGetLastError());
     uint64_t* sorted = nullptr;
-    // both region digits, always: the words that carry no key (all ones) must end up behind every region
-    if ((rc = r3d_radix_sort_u64(ctx, words, static_cast<uint64_t*>(tmp_v), m, 64, 48, &sorted))) return rc;
-    const unsigned bound_blocks = (unsigned)std::min<int64_t>((m + kThreads) / kThreads, (int64_t)ctx->num_cus * 32);
+    // both region digits, always: the words that carry no key (all ones) must end up behind every region.  The first
+    // digit's histogram is the key kernel's.
+    if ((rc = r3d_radix_sort_u64(ctx, words, static_cast<uint64_t*>(tmp_v), m, 64, 48, &sorted, true))) return rc;
+    const unsigned bound_blocks = (unsigned)std::min<int64_t>((m / 8 + 2 + kThreads) / kThreads, (int64_t)ctx->num_cus * 32);
     hipLaunchKernelGGL(voxel_bounds_kernel, dim3(bound_blocks), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted, m, n_regions, d_starts);
     const unsigned merge_blocks = std::min<uint32_t>(n_regions, (uint32_t)ctx->num_cus * 32);
+    const int pristine = vs->pristine ? 1 : 0;
+    vs->pristine = false;
 #define R3D_LAUNCH_MERGE(L2)                                                                                                      \
   hipLaunchKernelGGL(voxel_merge_kernel<L2>, dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted,         \
                      (const uint32_t*)d_starts, n_regions, vs->d_table, vs->log2cap, vs->d_counters, d_spill, d_spill_count,     \
-                     (unsigned long long)spill_cap)
+                     (unsigned long long)spill_cap, pristine)
     if (region_log2 == 11) R3D_LAUNCH_MERGE(11);
     else if (region_log2 == 12) R3D_LAUNCH_MERGE(12);
     else R3D_LAUNCH_MERGE(13);
@@ -826,6 +862,7 @@ int r3d_voxelset_insert_path(r3d_voxelset* vs, const float* d_xyz, int64_t n_poi
   if (n_points <= 0) return R3D_OK;
   vs->ctx->voxel_last_path = path;
   if (path == 2) return insert_sorted(vs, d_xyz, n_points);
+  vs->pristine = false;
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
   int blocks = vs->ctx->num_cus * 8;
   if ((int64_t)blocks > n_tiles) blocks = (int)n_tiles;
@@ -879,6 +916,7 @@ int r3d_voxelset_insert_codes(r3d_voxelset* vs, const uint64_t* d_codes, int64_t
   R3D_REQUIRE(n_codes >= 0, "n_codes must be >= 0");
   if (n_codes == 0) return R3D_OK;
   R3D_REQUIRE(d_codes != nullptr, "NULL device pointer");
+  vs->pristine = false;
   int64_t blocks = (n_codes + kThreads - 1) / kThreads;
   if (blocks > (int64_t)vs->ctx->num_cus * 16) blocks = (int64_t)vs->ctx->num_cus * 16;
   hipLaunchKernelGGL(voxel_insert_codes_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, vs->ctx->stream, d_codes, n_codes,

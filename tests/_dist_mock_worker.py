@@ -54,11 +54,12 @@ def main():
     V = importlib.import_module("3d_reconstruction_system_amd.voxelmap")
     per = H * W
     mine = want[lo * per:hi * per]
-    vs = V.VoxelSet(0.5, 1 << 18, ctx)
+    cap = 1 << max(18, int(np.ceil(np.log2(2.5 * max(n_frames * per, 1)))))      # random depth: nearly a voxel per point
+    vs = V.VoxelSet(0.5, cap, ctx)
     if hi > lo:
         vs.insert(mine)
     vs.union_across(comm)
-    whole = V.VoxelSet(0.5, 1 << 18, ctx)
+    whole = V.VoxelSet(0.5, cap, ctx)
     whole.insert(want)
     ok = ok and np.array_equal(vs.codes(), whole.codes()) and vs.stats()["overflow"] == 0
     vs.close()

@@ -186,6 +186,8 @@ def test_watchdog_prints_the_pre_measured_line_when_an_exchange_wedges(mock_rccl
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.returncode != 0                                  # a wedged exchange is a FAILED multi-GPU run, line or no line
+    import re
+    assert re.search(r"exitcode\s*:\s*4\b", r.stderr), r.stderr[-1500:]   # ... and the ranks said so with the watchdog's own code
     d = json.loads(lines[0])
     for k in REQUIRED:
         assert k in d, k
