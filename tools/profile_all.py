@@ -106,7 +106,14 @@ def main():
     def ins():
         vs.clear()
         vs.insert_device(d_xyz.ptr, n)
+    ms_clear0 = timed(ctx, vs.clear, 10)
+    per_path = {}
+    for label, path in (("cas_lds_set", 1), ("sort_merge", 2)):
+        ctx.set_tuning("voxel_path", path)
+        per_path[label] = timed(ctx, ins, 10) - ms_clear0
+    ctx.set_tuning("voxel_path", 0)
     ms_both = timed(ctx, ins, 10)
+    per_path["auto_took_path"] = ctx.get_tuning("voxel_last_path")
     st = vs.stats()
     import time as _t
     codes = vs.codes()
@@ -117,14 +124,16 @@ def main():
                                           "what": "1.07 GB table -> compaction + 48-bit radix sort + D2H of the codes"}
     ms_clear = timed(ctx, vs.clear, 10)
     out["voxel_insert"] = {"ms": ms_both - ms_clear, "Gpts": n / (ms_both - ms_clear) / 1e6, "voxels": st["voxels"],
-                           "bound": "scattered 64-bit atomics (19 G/s measured ceiling)",
-                           "Gatomics": st["voxels"] / (ms_both - ms_clear) / 1e6}
+                           "paths_ms": per_path,
+                           "bound": "sort-merge insert: HBM streams (20 + 48 + 8 + 8 B/point + 8..16 B/table slot); the CAS path: scattered "
+                                    "64-bit atomics (19 G/s measured ceiling)",
+                           "Gatomics_if_cas": st["voxels"] / per_path["cas_lds_set"] / 1e6}
     # the cloud and its voxels from one launch (r3d_fuse_frames_voxel) on the same frames: the worst case for it (random depth)
     def one_launch():
         vs.clear()
         r3d.fuse_frames_voxel_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, None, d_xyz2.ptr, None, vs)
     ms_one = timed(ctx, one_launch, 10) - ms_clear
-    out["fuse_voxel_one_launch"] = {"ms": ms_one, "Gpts": n / ms_one / 1e6, "voxels": vs.stats()["voxels"],
+    out["fuse_voxel_one_launch"] = {"ms": ms_one, "Gpts": n / ms_one / 1e6, "voxels": vs.stats()["voxels"], "form_taken": ctx.get_tuning("voxel_last_path"),
                                     "two_calls_ms": out["fuse_u8_f32"]["ms"] + out["voxel_insert"]["ms"] if "fuse_u8_f32" in out else None}
     vs.close()
     d_xyz2.free()

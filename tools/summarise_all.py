@@ -32,6 +32,13 @@ ALGO = {
                                                       "the atomics' worst case)", N_C2 * 13),
     "voxel_compact_kernel": ("hash table (2^27 slots, 1.07 GB) -> dense list of its ~48 M codes (read table + write codes)", (1 << 27) * 8 + 48_000_000 * 8),
     "cache_touch_kernel": ("input staging sweep of the C2 raster (read-only, 49 MB)", N_C2),
+    "voxel_keys_kernel": ("sort-merge insert, stage 1: 12 B/point in, 8 B region-tagged key out (+ the first digit's histogram)", N_C2 * 20),
+    "voxel_bounds_kernel": ("sort-merge insert, stage 3: where each table region's run of keys starts (8 B/key read)", N_C2 * 8),
+    "voxel_merge_kernel": ("sort-merge insert, stage 4: keys (8 B) into their table regions in LDS; 2^27-slot table written back "
+                           "(and read first unless nothing was inserted since clear)", N_C2 * 8 + (1 << 27) * 8),
+    "digit_scatter_kernel": ("radix scatter pass, 49.2 M 64-bit words (8 B read + 8 B written per key); other sizes share the symbol: "
+                             "see calls / min / max", N_C2 * 16),
+    "digit_histogram_kernel": ("radix histogram pass, 49.2 M words (8 B read per key); other sizes share the symbol", N_C2 * 8),
     "bbox_kernel": ("bounding box of a 500k-point cloud (two-stage, no atomics; 6 MB read)", 500000 * 12),
     "normals_kernel": ("normals of a 480x640 organised cloud (12 B read + 12 B written per point; neighbours from cache)", 480 * 640 * 24),
     "plane_accumulate_kernel": ("29 point-to-plane sums over ~300k matched pairs (src 12 + idx 4 + d2 4 + tgt 12 + normal 12 B/pair)", 305000 * 44),
@@ -78,7 +85,7 @@ def pmc(dirname, counter):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r03")
+    ap.add_argument("--round", default="r04")
     a = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", "prof_" + a.round)
     dst = os.path.join(ROOT, "profiles")
@@ -91,7 +98,7 @@ def main():
     trace_file = stats.replace("_kernel_stats.csv", "_kernel_trace.csv")
     tr = [r for r in csv.DictReader(open(trace_file)) if "fuse_lane_kernel" in r["Kernel_Name"]]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
-    summary = {"round": a.round, "command": "python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline",
+    summary = {"round": a.round, "command": "python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-regimes --no-end-to-end",
                "rocprof_kernel_stats": {"name": row["Name"], "calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]),
                                         "min_ns": int(row["MinNs"]), "max_ns": int(row["MaxNs"])},
                "rocprof_kernel_trace": {"n": len(d), "median_ns": statistics.median(d), "last_half_mean_ns": statistics.mean(d[len(d) // 2:]),
@@ -101,34 +108,37 @@ def main():
     if touch:
         t = touch[0]
         summary["input_staging_sweep"] = {"name": t["Name"], "calls": int(t["Calls"]), "average_ns": float(t["AverageNs"]),
-                                          "note": "round 3: the library stages a launch's inputs above 8 MB through the Infinity "
-                                                  "Cache (a raster that a host upload has just written is not in it), so a step = "
-                                                  "this read-only sweep + the fused kernel"}
-        summary["step_average_ns_sweep_plus_fuse"] = float(t["AverageNs"]) + float(row["AverageNs"])
-        summary["algorithmic_TBps_at_kernel_average"] = N_C2 * 13 / float(row["AverageNs"]) / 1e3
-        summary["algorithmic_TBps_at_step_average"] = N_C2 * 13 / summary["step_average_ns_sweep_plus_fuse"] / 1e3
-    # the regimes child (same kernel symbols, other regimes): kept apart on purpose
-    child = [f for f in fresh(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)) if f != stats]
+                                          "note": "round 4: staging by provenance -- the sweep runs in front of the launches whose "
+                                                  "raster is not presumed cached (here: the first one), not in front of every launch"}
+    summary["algorithmic_TBps_at_kernel_average"] = N_C2 * 13 / float(row["AverageNs"]) / 1e3
+    summary["sweeps_per_fused_launch"] = (int(touch[0]["Calls"]) if touch else 0) / int(row["Calls"])
+    # the other regimes of the launch (same kernel symbols), profiled as their own command: kept apart on purpose
+    child = fresh(glob.glob(os.path.join(src, "trace_regimes", "**", "*_kernel_stats.csv"), recursive=True))
     if child:
-        shutil.copy(child[0], os.path.join(dst, "%s_fuse_regimes_child_kernel_stats.csv" % a.round))
+        shutil.copy(child[0], os.path.join(dst, "%s_fuse_regimes_kernel_stats.csv" % a.round))
+        for line in open(os.path.join(src, "trace_regimes.log")):
+            if line.startswith("{"):
+                summary["regimes_line_under_rocprof"] = json.loads(line)
     for line in open(os.path.join(src, "trace.log")):
         if line.startswith("{"):
             summary["bench_line_under_rocprof"] = json.loads(line)
     fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     kf = [k for k in fetch if "fuse_lane_kernel" in k][0]
     rd, wr = fetch[kf] * 1024 * 2, write[kf] * 1024
-    kt = [k for k in fetch if "cache_touch_kernel" in k]
-    rd_t, wr_t = (fetch[kt[0]] * 1024 * 2, write.get(kt[0], 0.0) * 1024) if kt else (0.0, 0.0)
+    # (the staging sweep runs once per ~4100 launches now: its bytes are not part of a step)
+    rd_t, wr_t = 0.0, 0.0
     summary.update({"pmc_raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf]}, "hbm_read_bytes_per_launch_corrected_x2": rd,
                     "hbm_write_bytes_per_launch": wr, "staging_sweep_hbm_read_bytes_x2": rd_t, "staging_sweep_hbm_write_bytes": wr_t,
                     "hbm_bytes_per_launch": rd + wr + rd_t + wr_t, "algorithmic_bytes_per_launch": N_C2 * 13,
                     "traffic_over_algorithmic": (rd + wr + rd_t + wr_t) / (N_C2 * 13),
-                    "traffic_note": "per step = input staging sweep + fused kernel (the PMC passes ran bench.py --no-regimes: a "
-                                    "profiled process must not start the regimes child)"})
+                    "traffic_note": "per step = the fused kernel (its raster is presumed cached from the previous launch: no sweep); "
+                                    "the PMC passes ran bench.py --no-regimes --no-end-to-end (a profiled process must not start "
+                                    "another program)"})
     rd, wr = rd + rd_t, wr + wr_t
     json.dump(summary, open(os.path.join(dst, "%s_fuse_summary.json" % a.round), "w"), indent=1)
     json.dump({"round": a.round, "config": {"frames": 100, "out_dtype": "float32", "depth": "u8"}, "hbm_bytes_per_launch": rd + wr,
                "read_bytes_x2_corrected": rd, "write_bytes": wr, "raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf]},
+               "collected": "round %s, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes" % a.round,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --gpus 1 --steps 20 --warmup 5`"},
               open(os.path.join(dst, "pmc_fuse_latest.json"), "w"), indent=1)
     # ---- every kernel
