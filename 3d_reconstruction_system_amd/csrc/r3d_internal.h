@@ -47,6 +47,8 @@ struct r3d_ctx {
   int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
   int voxel_path = 0;     // big inserts: 0 auto (a sample of the cloud decides), 1 LDS-set + CAS kernel, 2 sort-merge (r3d_voxel.hip)
+  int voxel_merge_blocks = 0; // sort-merge insert: workgroups of a merge launch (0 auto)
+  int voxel_merge_phases = 0; // sort-merge insert: phases of the merge (0 auto: ~96 MB of keys each; 1 = unphased, A/B)
   int voxel_last_path = 0; // read-only: the path the last r3d_voxelset_insert took (1 / 2)
   int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set; 3: on, with the
                           // flush barrier inside its `if` (A/B against DESIGN 4.5b's finding only)

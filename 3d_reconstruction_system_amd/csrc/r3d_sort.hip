@@ -119,22 +119,42 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
     const int64_t i = first + r * 64;
     key[r] = i < n ? keys[i] : 0;
   }
+  // Four rounds at a time, in three sweeps, so that a round does not wait for the LDS round trips of the one before it:
+  // (1) who shares my digit -- pure ALU; (2) the four counter bumps back to back (the LDS serves one wave's operations in
+  // order: the returned values ARE the running counts); (3) the four hand-overs from the lowest peer.  (All sixteen rounds in
+  // one group of sweeps kept 128 ballot masks alive: 399 VGPRs of spilled scalars.  One round per group -- the first form --
+  // spent its time in sixteen dependent pairs of LDS round trips per wave.)
+  constexpr int kGroup = 4;
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const bool live = first + r * 64 < n;
-    const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xff;
-    unsigned long long peers = __ballot(live);
+  for (int g = 0; g < kRounds; g += kGroup) {
+    uint32_t info[kGroup];   // rank among the peers | their number << 8 | the lowest peer's lane << 16 | live << 24
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long m = __ballot((digit >> b) & 1);
-      peers &= ((digit >> b) & 1) ? m : ~m;
+    for (int q = 0; q < kGroup; ++q) {
+      const int r = g + q;
+      const bool live = first + r * 64 < n;
+      const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xff;
+      unsigned long long peers = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long m = __ballot((digit >> b) & 1);
+        peers &= ((digit >> b) & 1) ? m : ~m;
+      }
+      const uint32_t rank = __popcll(peers & ((1ull << lane) - 1));
+      info[q] = rank | ((uint32_t)__popcll(peers) << 8) | ((peers ? (uint32_t)__ffsll((long long)peers) - 1u : 0u) << 16) | ((uint32_t)live << 24);
     }
-    const uint32_t rank = __popcll(peers & ((1ull << lane) - 1));
-    uint32_t before = 0;
-    if (live && rank == 0) before = atomicAdd(&wave_cnt[wave][digit], (uint32_t)__popcll(peers));
-    // (dead lanes have peers == 0 only when no lane is live with digit 0 ... they read lane 0, and never use the value)
-    before = __shfl(before, peers ? __ffsll((long long)peers) - 1 : 0, 64);
-    place[r] = before + rank;
+#pragma unroll
+    for (int q = 0; q < kGroup; ++q) {
+      const int r = g + q;
+      place[r] = 0;
+      if ((info[q] >> 24) && (info[q] & 0xff) == 0)   // live, and the lowest of its peers
+        place[r] = atomicAdd(&wave_cnt[wave][(uint32_t)(key[r] >> shift) & 0xff], (info[q] >> 8) & 0xff);
+    }
+#pragma unroll
+    for (int q = 0; q < kGroup; ++q) {
+      const int r = g + q;
+      place[r] = (uint32_t)__shfl((int)place[r], (int)((info[q] >> 16) & 0xff), 64) + (info[q] & 0xff);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the groups apart: merged, their ballot masks do not fit the scalar registers
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
   for (int j = threadIdx.x; j < n_tile; j += kThreads) {
     const uint64_t k = sorted[j];
     const uint32_t digit = (uint32_t)(k >> shift) & 0xff;
-    out[g_base[digit] + (uint32_t)(j - (int)bin_start[digit])] = k;
+    out[g_base[digit] + (uint32_t)(j - (int)bin_start[digit])] = k;   // (plain stores: nontemporal ones -- partial lines past the L2 -- took 431 us instead of 239)
   }
 }
 

@@ -86,6 +86,37 @@ __device__ __forceinline__ uint64_t prev_lane_u64(uint64_t v) {
 // hole in its ISA without ever failing a test).  tools/isa_barrier_check.py scans the compiled kernels for the pattern.
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// A workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is also a fence for global memory: hipcc puts
+// s_waitcnt vmcnt(0) in front of its s_barrier, i.e. every global load and store of the wave has to have completed -- which
+// ends any overlap between a loop iteration's write-back / the next iteration's prefetch and the LDS work in between.  Where a
+// barrier protects nothing but an LDS array this one leaves the wave's global operations in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Three per-thread counts reach three global counters as ONE atomicAdd per WORKGROUP and non-zero counter.  Adds to one
+// address complete at ~0.09 G/s on this chip (11 ns each, whoever issues them): a SHORT kernel with many workgroups that each
+// end with per-wave adds waits for them (the sort-merge insert's merge: 32768 adds = 360 of its 455 us; it now leaves per-
+// workgroup partials instead).  Long kernels whose waves end spread over milliseconds do not -- see voxel_insert_kernel.
+// `wg`: three words of LDS; every thread of the workgroup calls this once, at the end.
+__device__ __forceinline__ void flush_counts(unsigned n_new, unsigned n_ignored, unsigned n_over, unsigned* wg,
+                                             unsigned long long* __restrict__ counters) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_ignored += __shfl_down(n_ignored, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  lds_barrier();
+  if (threadIdx.x < 3) wg[threadIdx.x] = 0;
+  lds_barrier();
+  if ((threadIdx.x & 63) == 0) {
+    if (n_new) atomicAdd(&wg[0], n_new);
+    if (n_ignored) atomicAdd(&wg[1], n_ignored);
+    if (n_over) atomicAdd(&wg[2], n_over);
+  }
+  lds_barrier();
+  if (threadIdx.x < 3 && wg[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)wg[threadIdx.x]);
+}
+
 // One code into the global open-addressing table (64-bit CAS, linear probing).  Returns 1 new, 0 already there, -1 no slot.
 __device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64_t mask, int log2cap, uint64_t code) {
   uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);

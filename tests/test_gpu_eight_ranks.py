@@ -2,15 +2,15 @@
 transport (tests/c/mock_rccl.cpp bound through R3D_RCCL_PATH; RCCL itself refuses two ranks on one device).
 
 Why not eight ranks: the GPU boxes this suite runs on allow at most SIX processes on the card at once (the run is killed
-beyond that) and the test runner is one of them -- so the rehearsal uses up to FIVE ranks, and what needs eight (the shard
-arithmetic of a 1001-frame job over 8 ranks, the byte offsets of config 4 and 5 over 8 ranks) runs on the CPU in
-tests/test_dist_gloo.py.  Eight real ranks on eight GPUs are the driver's scaling run.
+beyond that: a five-rank version of this file was, with the test runner and the launcher counted in) -- so the rehearsal uses
+up to FOUR ranks, and what needs eight (the shard arithmetic of a 1001-frame job over 8 ranks, the byte offsets of config 4
+and 5 over 8 ranks) runs on the CPU in tests/test_dist_gloo.py.  Eight real ranks on eight GPUs are the driver's scaling run.
 
 What is covered here that the small multi-rank tests (test_gpu_comm.py, test_gpu_dropin.py) do not reach:
   * byte offsets beyond 2^32 inside ONE exchange (config 4's cloud is 5.9 GB): `recv + off[from]`, both assemblies;
-  * a ragged 1001-frame job over five ranks, all three all-gather algorithms where they apply, the map union, the all-reduce;
+  * a ragged 1001-frame job over four ranks, all three all-gather algorithms where they apply, the map union, the all-reduce;
   * bench.py --gpus 4 exactly as the driver launches it, every assembly strategy on the line;
-  * the sharded drop-in at five ranks (an empty last block included).
+  * the sharded drop-in at four ranks on a scene that leaves the last block empty.
 Ordered after every single-process parity test (tests/conftest.py)."""
 import json
 import os
@@ -58,23 +58,23 @@ def test_config4_bytes_offsets_beyond_2_32_in_one_exchange(tmp_path, mock_rccl):
     assert 760 * 384 * 1280 * 12 > 1 << 32
 
 
-def test_five_ranks_ragged_1001_frames(tmp_path, mock_rccl):
-    """1001 frames over five ranks (4 x 201 + 197): both assemblies, auto / direct all-gather, in-place slots, the voxel-set union
+def test_four_ranks_ragged_1001_frames(tmp_path, mock_rccl):
+    """1001 frames over four ranks (3 x 251 + 248): both assemblies, auto / direct all-gather, in-place slots, the voxel-set union
     and the all-reduce -- every rank's result against the single-GPU cloud (tests/_dist_mock_worker.py)."""
     out = str(tmp_path / "res")
-    r = launch(5, [os.path.join(ROOT, "tests", "_dist_mock_worker.py"), out, "1001"], mock_rccl)
+    r = launch(4, [os.path.join(ROOT, "tests", "_dist_mock_worker.py"), out, "1001"], mock_rccl)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    for rank in range(5):
+    for rank in range(4):
         line = open("%s.rank%d" % (out, rank)).read()
         assert "ok=1" in line and "R3D_RCCL_PATH" in line, line
-    assert "lo=0 hi=201" in open(out + ".rank0").read() and "lo=804 hi=1001" in open(out + ".rank4").read()
+    assert "lo=0 hi=251" in open(out + ".rank0").read() and "lo=753 hi=1001" in open(out + ".rank3").read()
 
 
-def test_five_ranks_equal_shards_take_the_nccl_allgather_too(tmp_path, mock_rccl):
+def test_four_ranks_equal_shards_take_the_nccl_allgather_too(tmp_path, mock_rccl):
     out = str(tmp_path / "res")
-    r = launch(5, [os.path.join(ROOT, "tests", "_dist_mock_worker.py"), out, "1000"], mock_rccl)
+    r = launch(4, [os.path.join(ROOT, "tests", "_dist_mock_worker.py"), out, "1000"], mock_rccl)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    for rank in range(5):
+    for rank in range(4):
         assert "ok=1" in open("%s.rank%d" % (out, rank)).read()
 
 
@@ -97,12 +97,12 @@ def test_bench_four_ranks_as_the_driver_launches_it(mock_rccl):
     assert abs(d["value"] - 4 * 16 * 384 * 1280 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
 
 
-def test_sharded_dropin_over_five_ranks(tmp_path, golden_dir, mock_rccl):
-    """`torch.distributed.run --nproc-per-node 5 camera_to_world.py` on an 11-frame scene (blocks of 3, 3, 3, 2 and an EMPTY
-    fifth): every file equals the single-process run's, byte for byte."""
+def test_sharded_dropin_over_four_ranks_with_an_empty_block(tmp_path, golden_dir, mock_rccl):
+    """`torch.distributed.run --nproc-per-node 4 camera_to_world.py` on a 9-frame scene (blocks of 3, 3, 3 and an EMPTY
+    fourth): every file equals the single-process run's, byte for byte."""
     from PIL import Image
     rng = np.random.default_rng(31)
-    F, H, W = 11, 40, 56
+    F, H, W = 9, 40, 56
     for sub in ("a", "b"):
         for d in ("depth", "point", "point_world", "ply", "camera_pose"):
             os.makedirs(tmp_path / sub / d)
@@ -117,9 +117,9 @@ def test_sharded_dropin_over_five_ranks(tmp_path, golden_dir, mock_rccl):
     script = os.path.join(ROOT, PKG, "transfer", "camera_to_world.py")
     one = subprocess.run([sys.executable, script], cwd=tmp_path / "a", capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stdout + one.stderr
-    five = launch(5, [script], mock_rccl, cwd=tmp_path / "b")
-    assert five.returncode == 0, five.stdout[-2000:] + five.stderr[-3000:]
-    assert five.stdout.count("Write into .ply file Done.") == 1
+    four = launch(4, [script], mock_rccl, cwd=tmp_path / "b")
+    assert four.returncode == 0, four.stdout[-2000:] + four.stderr[-3000:]
+    assert four.stdout.count("Write into .ply file Done.") == 1
     for rel in ["ply/small_035_p8.ply", "point_world/small_worldpoint_5_23_5.txt"] + ["point/%03d.txt" % k for k in range(F)]:
         assert (tmp_path / "a" / rel).read_bytes() == (tmp_path / "b" / rel).read_bytes(), rel
     # ... and the cloud itself against the oracle (the files above are the product's on both sides)
