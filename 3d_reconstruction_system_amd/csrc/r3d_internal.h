@@ -148,6 +148,7 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
                        uint64_t** d_result = nullptr, bool first_hist_done = false);
 constexpr int kSortTile = 4096;   // keys per workgroup of every sort kernel
 int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* n_blocks_out);
+static inline int r3d_sort_stride(int n_blocks) { return (n_blocks + 3) & ~3; }   // counters per histogram row (16-byte aligned rows)
 
 // r3d_nnindex.hip: the index's own copy of the target cloud (original order), its size and its context
 int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx);

@@ -21,18 +21,25 @@ constexpr int kTile = kThreads * kRounds;  // keys per workgroup
 constexpr int kBins = 256;
 
 __global__ __launch_bounds__(kThreads) void digit_histogram_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                                   uint32_t* __restrict__ hist, int n_blocks) {
+                                                                   uint32_t* __restrict__ hist, int stride) {
   __shared__ uint32_t bins[kBins];
   bins[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kTile;
-#pragma unroll 4
+  // all sixteen loads in flight, then the sixteen LDS adds (four at a time, each waiting for its load, left the read stream at
+  // 3.3 TB/s: 120 us for 49 M keys)
+  uint64_t k[kRounds];
+#pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int64_t i = base + r * kThreads + threadIdx.x;
-    if (i < n) atomicAdd(&bins[(keys[i] >> shift) & 0xff], 1u);
+    k[r] = keys[i < n ? i : n - 1];
   }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r)
+    if (base + r * kThreads + threadIdx.x < n) atomicAdd(&bins[(k[r] >> shift) & 0xff], 1u);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x] = bins[threadIdx.x];
+  hist[(int64_t)threadIdx.x * stride + blockIdx.x] = bins[threadIdx.x];
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -44,29 +51,48 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
   return v;
 }
 
-// grid = kBins workgroups of 256 threads: bin b's counts over the workgroups become exclusive prefixes in place.  Every
-// thread owns a CONTIGUOUS chunk of the row (local sum -> wave shuffle scan -> LDS across the 4 waves -> local rescan):
-// two passes over the row instead of a chain of 64-wide scans (one wave per bin walked 11.8 k counters of a 48 M-key sort
-// in 185 dependent steps: 95 us per pass).
-__global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restrict__ hist, int n_blocks, uint32_t* __restrict__ totals) {
-  __shared__ uint32_t wave_sum[kThreads / 64];
+// grid = kBins workgroups of 256 threads: bin b's counts over the workgroups become exclusive prefixes in place.  The row
+// (stride = the workgroup count rounded up to 4 counters: rows start 16-byte aligned) is walked in segments of 1024 counters:
+// one COALESCED 16-byte load per thread -- four consecutive counters -- a wave shuffle scan of the threads' sums, LDS across
+// the four waves, a carry from segment to segment; the next segment's load is in flight meanwhile.  (Rounds 2-4 gave every
+// thread a contiguous chunk of the row: 47 loads per thread on a 48 M-key sort, each wave instruction touching 64 different
+// cache lines -- 34 us per pass for 12 MB.)
+__global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restrict__ hist, int n_blocks, int stride, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_sum[2][kThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* row = hist + (int64_t)blockIdx.x * n_blocks;
-  const int per = (n_blocks + kThreads - 1) / kThreads;
-  const int lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
-  uint32_t mine = 0;
-  for (int b = lo; b < hi; ++b) mine += row[b];
-  const uint32_t inc = wave_inclusive_scan(mine, lane);
-  if (lane == 63) wave_sum[wave] = inc;
-  __syncthreads();
-  uint32_t before = inc - mine;
-  for (int w = 0; w < wave; ++w) before += wave_sum[w];
-  for (int b = lo; b < hi; ++b) {
-    const uint32_t v = row[b];
-    row[b] = before;
-    before += v;
+  uint4* row = reinterpret_cast<uint4*>(hist + (int64_t)blockIdx.x * stride);
+  const int n4 = stride / 4;
+  auto fetch = [&](int i4) -> uint4 {
+    uint4 v = i4 < n4 ? row[i4] : uint4{0, 0, 0, 0};
+    const int e = 4 * i4;   // counters beyond the last workgroup are padding: whatever they hold counts as zero
+    if (e + 0 >= n_blocks) v.x = 0;
+    if (e + 1 >= n_blocks) v.y = 0;
+    if (e + 2 >= n_blocks) v.z = 0;
+    if (e + 3 >= n_blocks) v.w = 0;
+    return v;
+  };
+  uint32_t carry = 0;
+  uint4 nxt = fetch((int)threadIdx.x);
+  int parity = 0;
+  for (int seg = 0; seg < n4; seg += kThreads, parity ^= 1) {
+    const int i4 = seg + (int)threadIdx.x;
+    const uint4 v = nxt;
+    nxt = fetch(i4 + kThreads);
+    const uint32_t mine = v.x + v.y + v.z + v.w;
+    const uint32_t inc = wave_inclusive_scan(mine, lane);
+    if (lane == 63) wave_sum[parity][wave] = inc;
+    __syncthreads();   // (the two copies of wave_sum alternate: one barrier per segment is enough)
+    uint32_t before = carry + inc - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+      const uint32_t t = wave_sum[parity][w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    if (i4 < n4) row[i4] = uint4{before, before + v.x, before + v.x + v.y, before + v.x + v.y + v.z};
+    carry += total;
   }
-  if (threadIdx.x == kThreads - 1) totals[blockIdx.x] = before;   // the last chunk ends at the row's total (empty chunks pass it on)
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 // The tile's 4096 keys leave in BIN ORDER: ranked without a workgroup barrier per round, staged in LDS, written out by
@@ -84,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restri
 // not the ranking: an any-order variant for first passes (place = a returning LDS add on the bin's cursor: 687 instructions per
 // thread and tile instead of 2627) ran in 222 us against 229 (round 4; not kept), nontemporal stores in 431.
 __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                                 const uint32_t* __restrict__ hist, int n_blocks,
+                                                                 const uint32_t* __restrict__ hist, int stride,
                                                                  const uint32_t* __restrict__ totals,
                                                                  uint64_t* __restrict__ out) {
   constexpr int kWaves = kThreads / 64, kPerWave = kTile / kWaves;
@@ -181,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
       wave_cnt[w][threadIdx.x] = off;
       off += c[w];
     }
-    g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
+    g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + blockIdx.x];
   }
   __syncthreads();
 #pragma unroll
@@ -208,14 +234,14 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
 // a Morton code) skips the passes over them.
 // d_tmp: scratch of n keys.  The result is in d_keys when the number of passes is even, else it is copied back -- unless the
 // caller asks where it ended up (d_result != NULL: *d_result = d_keys or d_tmp, no copy).
-// The workspace of a sort of n keys (scratch slot 3): hist[bin][workgroup] + the 256 bin totals.  A producer that writes the
+// The workspace of a sort of n keys (scratch slot 3): hist[bin][r3d_sort_stride(workgroups)] + the 256 bin totals.  A producer that writes the
 // keys tile by tile (kSortTile keys per workgroup, same tiling as the sort) can fill `hist` for the FIRST digit itself and
 // save the sort its first histogram pass (r3d_voxel.hip's key kernel does).
 int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* n_blocks_out) {
   const int64_t n_blocks64 = (n + kTile - 1) / kTile;
   R3D_REQUIRE(n_blocks64 < ((int64_t)1 << 31), "too many keys for one sort");
   void* ws = nullptr;
-  const size_t hist_bytes = (size_t)kBins * n_blocks64 * sizeof(uint32_t);
+  const size_t hist_bytes = (size_t)kBins * r3d_sort_stride((int)n_blocks64) * sizeof(uint32_t);
   int rc = r3d_scratch(ctx, 3, hist_bytes + kBins * sizeof(uint32_t) + 64, &ws);
   if (rc) return rc;
   *hist_out = static_cast<uint32_t*>(ws);
@@ -234,16 +260,17 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
   int n_blocks = 0;
   int rc = r3d_radix_sort_workspace(ctx, n, &hist, &n_blocks);
   if (rc) return rc;
-  const size_t hist_bytes = (size_t)kBins * n_blocks * sizeof(uint32_t);
+  const int stride = r3d_sort_stride(n_blocks);
+  const size_t hist_bytes = (size_t)kBins * stride * sizeof(uint32_t);
   uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + ((hist_bytes + 15) & ~(size_t)15));
   uint64_t* src = d_keys;
   uint64_t* dst = d_tmp;
   for (int p = 0; p < passes; ++p) {
     const int shift = first_bit + 8 * p;
     if (p > 0 || !first_hist_done)
-      hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks);
-    hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, totals);
-    hipLaunchKernelGGL(digit_scatter_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, n_blocks,
+      hipLaunchKernelGGL(digit_histogram_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, stride);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, stride, totals);
+    hipLaunchKernelGGL(digit_scatter_kernel, dim3(n_blocks), dim3(kThreads), 0, ctx->stream, src, n, shift, hist, stride,
                        (const uint32_t*)totals, dst);
     uint64_t* t = src;
     src = dst;

@@ -221,7 +221,7 @@ __device__ __forceinline__ uint64_t home_slot(uint64_t key, int log2cap) { retur
 // digit (bits 48..55) where the sort's first pass would have had to compute it from the words again (hist[bin][tile]).
 __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor, int log2cap,
                                                               int region_log2, uint64_t* __restrict__ words,
-                                                              uint32_t* __restrict__ hist, int n_tiles,
+                                                              uint32_t* __restrict__ hist, int hist_stride,
                                                               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
                                                               unsigned long long* __restrict__ counters) {
   __shared__ uint32_t bins[256];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
   if (lane == 0 && n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);   // (rare: non-finite / far points only)
   r3d_vox::lds_settle();
   __syncthreads();
-  hist[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = bins[threadIdx.x];
+  hist[(int64_t)threadIdx.x * hist_stride + blockIdx.x] = bins[threadIdx.x];
 }
 
 // starts[b] = index of the first word whose region is >= b, for b in [0, n_regions + 1]; words that carry no key sort behind
@@ -911,7 +911,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     int n_tiles = 0;
     if ((rc = r3d_radix_sort_workspace(ctx, m, &hist, &n_tiles))) return rc;
     hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, vs->log2cap, region_log2,
-                       words, hist, n_tiles, d_spill, d_spill_count, vs->d_counters);
+                       words, hist, r3d_sort_stride(n_tiles), d_spill, d_spill_count, vs->d_counters);
     R3D_HIP(hipGetLastError());
     uint64_t* sorted = nullptr;
     // both region digits, always: the words that carry no key (all ones) must end up behind every region.  The first
