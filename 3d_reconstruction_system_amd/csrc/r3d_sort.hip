@@ -95,6 +95,13 @@ __global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restri
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// workgroup b of a grid of g -> item x * (g / 8) + min(x, g % 8) + b / 8 with x = b % 8: the workgroups of one XCD walk a
+// contiguous eighth of the items, in order
+__device__ __forceinline__ int xcd_contiguous(unsigned b, unsigned g) {
+  const unsigned x = b & 7u, j = b >> 3, q = g >> 3, r = g & 7u;
+  return (int)(x * q + (x < r ? x : r) + j);
+}
+
 // The tile's 4096 keys leave in BIN ORDER: ranked without a workgroup barrier per round, staged in LDS, written out by
 // consecutive lanes.  (Until round 4 every round of 256 keys took four barriers and every lane stored its key where its
 // rank said -- a wave instruction of 64 eight-byte stores to ~56 different places: 490 us per pass on 49 M keys = 1.6 TB/s.)
@@ -139,7 +146,12 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
     bin_base = inc - mine;
     for (int w = 0; w < wave; ++w) bin_base += wave_total[w];
   }
-  const int64_t base = (int64_t)blockIdx.x * kTile;
+  // Which tile: workgroups are dealt to the chip's 8 XCDs round-robin (workgroup b -> XCD b % 8), each XCD behind an L2 of its
+  // own.  Tiles t and t + 1 write ADJACENT runs in every bin, and a run begins and ends inside a 128-byte line: dealt round-robin
+  // the two halves of such a line are written through two different L2s and reach HBM as two partial (read-modify-write)
+  // lines.  So an XCD takes a CONTIGUOUS eighth of the tiles: the neighbour of a partial line arrives in the same L2.
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int64_t base = (int64_t)tile * kTile;
   const int64_t first = base + (int64_t)wave * kPerWave + lane;
   uint64_t key[kRounds];
   uint32_t place[kRounds];   // rank inside the wave's quarter among the keys of the same digit
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
       wave_cnt[w][threadIdx.x] = off;
       off += c[w];
     }
-    g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + blockIdx.x];
+    g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
   }
   __syncthreads();
 #pragma unroll

@@ -27,8 +27,12 @@ from oracle import fusion_ref as O
 pytestmark = pytest.mark.gpu
 
 
+_launches = [0]
+
+
 def launch(world, args, mock, timeout=900, cwd=ROOT, env=None):
-    port = 29700 + (os.getpid() * 7 + world * 13 + len(args)) % 250
+    _launches[0] += 1                       # a port of its own for every launch of this file (no reuse inside TIME_WAIT)
+    port = 29700 + (os.getpid() * 7 + _launches[0] * 17) % 250
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=str(cwd),
