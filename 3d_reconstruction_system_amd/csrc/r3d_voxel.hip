@@ -202,8 +202,9 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
 //   r3d_radix_sort_u64    on the region bits only (two 8-bit passes for a 65536-region table): the words of one region
 //                         become one contiguous run;
 //   voxel_bounds_kernel   where each region's run starts;
-//   voxel_merge_kernel    one workgroup per region that received keys: the region's 2048..8192 table slots come into LDS with
-//                         16-byte loads, the run's keys are inserted THERE (LDS compare-and-swap, linear probing from the home
+//   voxel_merge_kernel    persistent workgroups walk the regions that received keys: a region's 2048..8192 table slots come into
+//                         LDS with 16-byte loads (or are just initialised when the table is known to be empty), the run's keys
+//                         are inserted THERE (LDS compare-and-swap, linear probing from the home
 //                         slot -- the same placement rule as table_insert, so later lookups and CAS inserts see a table they
 //                         understand), the region goes back with 16-byte stores.  A probe that runs off the region's end is
 //                         deferred to a spill list, inserted by voxel_spill_kernel with the ordinary CAS afterwards (~0.1 % of
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
                                                               int region_log2, uint64_t* __restrict__ words,
                                                               uint32_t* __restrict__ hist, int hist_stride,
                                                               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                              unsigned long long* __restrict__ counters) {
+                                                              unsigned long long spill_cap, unsigned long long* __restrict__ counters) {
   __shared__ uint32_t bins[256];
   const int lane = threadIdx.x & 63;
   unsigned n_ignored = 0;
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
       if (live) {
         word = ((home_slot(key, log2cap) >> region_log2) << 48) | key;
         if (word == kSkip) {   // voxel (65535, 65535, 65535) in region 65535 would read as "no key": it takes the deferred way in
-          spill[atomicAdd(spill_count, 1ull)] = key;   // (the list holds one entry per point: always room)
+          const unsigned long long at = atomicAdd(spill_count, 1ull);   // (the list holds one entry per point: always room)
+          if (at < spill_cap) spill[at] = key;
         }
       }
       if (i < n) {
@@ -312,9 +314,9 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
                                                                unsigned long long spill_cap, int pristine, uint32_t r_begin,
                                                                unsigned long long* __restrict__ partials) {
   constexpr int kSlots = 1 << REGION_LOG2;
-  constexpr int kAhead = 4;
+  constexpr int kAhead = 4;   // keys per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
   __shared__ unsigned wg_count[2];
-  if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;   // (ordered before its first use by the barriers of the loop / of the end)   // keys per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
+  if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;   // (ordered before its first use by the barrier in front of the adds at the end)
   __shared__ __attribute__((aligned(16))) unsigned long long region[kSlots];
   __shared__ unsigned changed;
   const int lane = threadIdx.x & 63;
@@ -911,7 +913,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     int n_tiles = 0;
     if ((rc = r3d_radix_sort_workspace(ctx, m, &hist, &n_tiles))) return rc;
     hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, vs->log2cap, region_log2,
-                       words, hist, r3d_sort_stride(n_tiles), d_spill, d_spill_count, vs->d_counters);
+                       words, hist, r3d_sort_stride(n_tiles), d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
     R3D_HIP(hipGetLastError());
     uint64_t* sorted = nullptr;
     // both region digits, always: the words that carry no key (all ones) must end up behind every region.  The first
