@@ -75,7 +75,10 @@ def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
         if rc == L.OK:
             img = np.empty((h.value, w.value), np.uint8)
             arr = (C.c_char_p * 1)(os.fsencode(path))
-            L.check(lib.r3d_png_gray8_decode_batch(arr, 1, img.ctypes.data, h.value, w.value, GRAY_RULES[rule]))
+            rc = lib.r3d_png_gray8_decode_batch(arr, 1, img.ctypes.data, h.value, w.value, GRAY_RULES[rule])
+            if rc == L.ERR_UNSUPPORTED:                 # e.g. real colour in a gamma-tagged file: the message says what to do
+                raise UnsupportedDepthFormat(L.last_error())
+            L.check(rc)
             return img
         if rc != L.ERR_UNSUPPORTED:
             L.check(rc)

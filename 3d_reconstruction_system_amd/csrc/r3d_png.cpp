@@ -29,6 +29,7 @@ namespace {
 struct PngInfo {
   uint32_t width = 0, height = 0;
   int bit_depth = 0, colour_type = 0, interlace = 0;
+  bool gamma_tagged = false;   // a gAMA / sRGB / iCCP chunk in front of the image data: libpng then converts colour to grey in linear light
 };
 
 uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
@@ -66,6 +67,8 @@ int read_png(const char* path, PngInfo* info, std::vector<unsigned char>* idat, 
       info->colour_type = data[9];
       info->interlace = data[12];
       have_ihdr = true;
+    } else if (!memcmp(type, "gAMA", 4) || !memcmp(type, "sRGB", 4) || !memcmp(type, "iCCP", 4)) {
+      if (idat->empty()) info->gamma_tagged = true;
     } else if (!memcmp(type, "IDAT", 4)) {
       idat->insert(idat->end(), data, data + len);
     } else if (!memcmp(type, "IEND", 4)) {
@@ -223,6 +226,16 @@ inline unsigned gray16(unsigned r, unsigned g, unsigned b) {   // libpng, 16-bit
   return (r == g && r == b) ? r : (9797u * r + 19234u * g + 3737u * b + 16384u) >> 15;
 }
 
+// A colour pixel in a file that carries gamma information: libpng (hence OpenCV's PNG reader) builds gamma tables and converts
+// in LINEAR light -- gamma_from_1[(9797 to_1[R] + 19234 to_1[G] + 3737 to_1[B] + 16384) >> 15] with tables from its own
+// fixed-point pow -- which is not restated here.  Refused, not approximated; pixels with R = G = B pass through unchanged
+// there too (no overall gamma correction is requested), so depth maps saved "in colour" by such tools still decode.
+int gamma_refusal(const char* path, std::string* msg) {
+  *msg = std::string("'") + path + "': a colour PNG with a gAMA / sRGB / iCCP chunk -- OpenCV (libpng) converts such files to grey in linear "
+         "light, which this build does not restate; strip the chunk (e.g. re-save with PIL) or ask for rule R3D_GRAY_CVTCOLOR explicitly";
+  return R3D_ERR_UNSUPPORTED;
+}
+
 // one PNG as the uint8 raster cv.imread(path, IMREAD_GRAYSCALE) returns; out == NULL: header query
 int decode_gray8_impl(const char* path, unsigned char* out, size_t cap_bytes, int rule, int* h_out, int* w_out, std::string* msg) {
   PngInfo info;
@@ -244,7 +257,10 @@ int decode_gray8_impl(const char* path, unsigned char* out, size_t cap_bytes, in
     } else if (channels == 2) {
       for (size_t k = 0; k < n; ++k) out[k] = s[2 * k];                       // alpha is stripped
     } else {
-      for (size_t k = 0; k < n; ++k, s += channels) out[k] = (unsigned char)gray8(s[0], s[1], s[2], rule);
+      for (size_t k = 0; k < n; ++k, s += channels) {
+        if (info.gamma_tagged && rule == R3D_GRAY_OPENCV_PNG && (s[0] != s[1] || s[1] != s[2])) return gamma_refusal(path, msg);
+        out[k] = (unsigned char)gray8(s[0], s[1], s[2], rule);
+      }
     }
   } else {  // 16-bit big-endian samples
     const size_t px_bytes = (size_t)channels * 2;
@@ -253,6 +269,7 @@ int decode_gray8_impl(const char* path, unsigned char* out, size_t cap_bytes, in
     } else {
       for (size_t k = 0; k < n; ++k, s += px_bytes) {
         const unsigned r = (s[0] << 8) | s[1], g = (s[2] << 8) | s[3], b = (s[4] << 8) | s[5];
+        if (info.gamma_tagged && rule == R3D_GRAY_OPENCV_PNG && (r != g || g != b)) return gamma_refusal(path, msg);
         out[k] = rule == R3D_GRAY_CVTCOLOR ? (unsigned char)gray8(r >> 8, g >> 8, b >> 8, rule) : (unsigned char)(gray16(r, g, b) >> 8);
       }
     }

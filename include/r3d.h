@@ -436,8 +436,9 @@ int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out
  *                        and later) calls instead of cvtColor; the reference's camera_to_world.py:160 on a PNG file;
  *   R3D_GRAY_CVTCOLOR    (4899 R + 9617 G + 1868 B + 8192) >> 14: cv.cvtColor(BGR2GRAY), imread's rule for the formats whose
  *                        decoders deliver colour (BMP, TIFF, WebP).
- * (Files carrying gamma information -- gAMA / sRGB / iCCP chunks -- make libpng convert in linear light: not restated here;
- * palette, interlaced and sub-byte PNGs: R3D_ERR_UNSUPPORTED.)  r3d_rgb_to_gray_u8: the rule alone, on [n][channels] 8-bit
+ * (Files carrying gamma information -- gAMA / sRGB / iCCP chunks -- make libpng convert in linear light: not restated; a pixel
+ * with differing channels in such a file -> R3D_ERR_UNSUPPORTED under R3D_GRAY_OPENCV_PNG, equal channels pass through as in libpng.
+ * Palette, interlaced and sub-byte PNGs: R3D_ERR_UNSUPPORTED.)  r3d_rgb_to_gray_u8: the rule alone, on [n][channels] 8-bit
  * R,G,B(,A) pixels already in memory. */
 #define R3D_GRAY_OPENCV_PNG 0
 #define R3D_GRAY_CVTCOLOR 1

@@ -509,3 +509,33 @@ def test_colour_depth_files_take_the_opencv_rules_not_pils(R, tmp_path, monkeypa
     Image.fromarray(rgb, "RGB").quantize(16).save(tmp_path / "p.png")
     with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
         R.cloud_io.read_depth_gray(str(tmp_path / "p.png"))
+
+
+def test_gamma_tagged_colour_png_is_refused_not_approximated(R, tmp_path):
+    """libpng converts colour to grey in LINEAR light when the file says what its gamma is (gAMA / sRGB / iCCP): that path is
+    not restated, so such a file with real colour in it is refused under the OpenCV-PNG rule (and still converts under the
+    cvtColor rule, which knows no gamma); the same file with R = G = B everywhere decodes, as it does in libpng."""
+    from PIL import Image
+    from PIL.PngImagePlugin import PngInfo
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV present: its own decode is used")
+    except ImportError:
+        pass
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    g = rng.integers(0, 256, (20, 30), dtype=np.uint8)
+    import struct
+    tag = PngInfo()
+    tag.add(b"gAMA", struct.pack(">I", 45455))                                           # file gamma 1 / 2.2
+    Image.fromarray(rgb, "RGB").save(tmp_path / "tagged.png", pnginfo=tag)
+    Image.fromarray(np.dstack([g, g, g]), "RGB").save(tmp_path / "tagged_grey.png", pnginfo=tag)
+    assert b"gAMA" in (tmp_path / "tagged.png").read_bytes()[:200]
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat) as e:
+        R.cloud_io.read_depth_gray(str(tmp_path / "tagged.png"))
+    assert "gAMA" in str(e.value) and "linear" in str(e.value)
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
+        R.cloud_io.read_depth_batch([str(tmp_path / "tagged.png")])
+    np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "tagged.png"), rule="cvtcolor"),
+                                  _gray_cvtcolor(rgb[..., 0], rgb[..., 1], rgb[..., 2]))
+    np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "tagged_grey.png")), g)
