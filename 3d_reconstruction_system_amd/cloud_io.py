@@ -35,6 +35,11 @@ def _is_png(path):
         raise FileNotFoundError("cannot read depth image %r" % path)
 
 
+def _is_jpeg(path):
+    with open(path, "rb") as f:
+        return f.read(3) == b"\xff\xd8\xff"
+
+
 def rgb_to_gray(rgb, rule="cvtcolor"):
     """[...,3|4] uint8 R,G,B(,A) -> [...] uint8 grey by one of OpenCV's two integer rules (include/r3d.h, R3D_GRAY_*):
     "opencv_png" = what cv.imread(<png>, IMREAD_GRAYSCALE) does (libpng's rgb_to_gray), "cvtcolor" = cv.cvtColor(BGR2GRAY)."""
@@ -53,9 +58,10 @@ def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
       * PNG (the reference's input): decoded natively -- 8-bit grey as stored, 16-bit -> high byte, alpha dropped, colour
         converted by `rule` ("opencv_png", the default: libpng's rgb_to_gray as OpenCV's PNG reader requests it; or
         "cvtcolor"; env R3D_GRAY_RULE).  PIL's 'L' weights are neither and are not used.
-      * JPEG (AirSim stores depth as 3-channel JPG): OpenCV asks libjpeg itself for grey output.  PIL can make the same
-        request (draft mode 'L'), but whether the two libjpeg builds agree to the bit cannot be checked here, so it is
-        refused unless allow_pil_jpeg=True / R3D_ALLOW_PIL_JPEG=1 says the caller accepts that.
+      * JPEG (AirSim stores depth as 3-channel JPG): OpenCV asks libjpeg itself for grey output -- the luma component through
+        libjpeg's integer IDCT.  Sequential Huffman files (what cv.imwrite and PIL write) are decoded natively by a restatement
+        of exactly that (csrc/r3d_jpeg.cpp; byte-identical to libjpeg-turbo, tests/test_host_logic.py).  Progressive / CMYK /
+        12-bit files are refused unless allow_pil_jpeg=True / R3D_ALLOW_PIL_JPEG=1 lets PIL decode them.
       * other formats PIL reads (BMP, TIFF, ...): decoded to RGB by PIL (lossless formats: the same samples), converted by
         the cvtColor rule, which is what imread does for them."""
     path = os.fspath(path)
@@ -84,6 +90,19 @@ def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
             L.check(rc)
         raise UnsupportedDepthFormat("%r: %s.  Palette / interlaced / sub-byte PNGs are not decoded natively and PIL's grey "
                                      "conversion is not OpenCV's; re-save the file as a plain 8/16-bit PNG" % (path, L.last_error()))
+    native_said = None
+    if _is_jpeg(path):
+        lib = L.load()
+        h, w = C.c_int(), C.c_int()
+        rc = lib.r3d_jpeg_gray_info(os.fsencode(path), C.byref(h), C.byref(w))
+        if rc == L.OK:
+            img = np.empty((h.value, w.value), np.uint8)
+            arr = (C.c_char_p * 1)(os.fsencode(path))
+            L.check(lib.r3d_jpeg_gray_decode_batch(arr, 1, img.ctypes.data, h.value, w.value))
+            return img
+        if rc != L.ERR_UNSUPPORTED:
+            L.check(rc)
+        native_said = L.last_error()
     from PIL import Image
     pil = Image.open(path)
     if pil.format in ("JPEG", "MPO"):
@@ -91,9 +110,10 @@ def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
             allow_pil_jpeg = os.environ.get("R3D_ALLOW_PIL_JPEG", "0") not in ("", "0")
         if not allow_pil_jpeg:
             raise UnsupportedDepthFormat(
-                "%r is a JPEG: this build has no JPEG decoder of its own and cannot promise OpenCV's IMREAD_GRAYSCALE bytes for it.  "
-                "Fallback: read_depth_gray(path, allow_pil_jpeg=True) or R3D_ALLOW_PIL_JPEG=1 decodes it through PIL asking libjpeg "
-                "for greyscale output (the request OpenCV makes); or convert the depth maps to PNG" % path)
+                "%s.  The native decoder takes sequential Huffman JPEGs (what OpenCV and PIL write) and restates libjpeg's grey output for "
+                "them; for this flavour it cannot promise OpenCV's IMREAD_GRAYSCALE bytes.  Fallback: read_depth_gray(path, "
+                "allow_pil_jpeg=True) or R3D_ALLOW_PIL_JPEG=1 decodes it through PIL (libjpeg asked for greyscale output, the request "
+                "OpenCV makes); or convert the depth maps to PNG" % (native_said or repr(path)))
         pil.draft("L", pil.size)
         return np.ascontiguousarray(np.array(pil.convert("L") if pil.mode != "L" else pil))
     if pil.mode == "L":
@@ -105,8 +125,8 @@ def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
 
 def read_depth_batch(paths, out=None, rule=None):
     """[F,H,W] raster batch for a list of depth files with IMREAD_GRAYSCALE meaning (c2w:160).  PNGs of any supported
-    flavour -- 8/16-bit, grey or colour (read_depth_gray has the rules) -- are inflated, unfiltered and converted by the
-    library's host threads straight into one contiguous (optionally pinned) buffer; other formats go file by file."""
+    flavour -- 8/16-bit, grey or colour (read_depth_gray has the rules) -- and sequential JPEGs are decoded by the library's
+    host threads straight into one contiguous (optionally pinned) buffer; other formats go file by file."""
     paths = [os.fspath(p) for p in paths]
     if not paths:
         return np.empty((0, 0, 0), np.uint8)
@@ -115,7 +135,11 @@ def read_depth_batch(paths, out=None, rule=None):
     h, w = C.c_int(), C.c_int()
     if not os.path.exists(paths[0]):
         raise FileNotFoundError("cannot read depth image %r" % paths[0])
-    rc = lib.r3d_png_gray8_info(os.fsencode(paths[0]), C.byref(h), C.byref(w)) if _is_png(paths[0]) else L.ERR_UNSUPPORTED
+    jpeg = not _is_png(paths[0]) and _is_jpeg(paths[0])
+    if jpeg:
+        rc = lib.r3d_jpeg_gray_info(os.fsencode(paths[0]), C.byref(h), C.byref(w))
+    else:
+        rc = lib.r3d_png_gray8_info(os.fsencode(paths[0]), C.byref(h), C.byref(w)) if _is_png(paths[0]) else L.ERR_UNSUPPORTED
     if rc == L.OK:
         shape = (len(paths), h.value, w.value)
         if out is None:
@@ -123,7 +147,10 @@ def read_depth_batch(paths, out=None, rule=None):
         elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        rc = lib.r3d_png_gray8_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value, GRAY_RULES[rule])
+        if jpeg:
+            rc = lib.r3d_jpeg_gray_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value)
+        else:
+            rc = lib.r3d_png_gray8_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value, GRAY_RULES[rule])
         if rc == L.OK:
             return out
         if rc != L.ERR_UNSUPPORTED:

@@ -1,0 +1,477 @@
+// f3 ingestion: JPEG -> the 8-bit grey raster `cv.imread(path, IMREAD_GRAYSCALE)` returns, on host threads.
+//
+// AirSim stores depth as 3-channel JPG (airsim/main.cpp:1369-1392, cv::imwrite); camera_to_world.py:160 reads depth files with
+// IMREAD_GRAYSCALE.  For a JPEG OpenCV does not decode colour and convert: its reader (grfmt_jpeg.cpp) asks libjpeg for
+// grey output (out_color_space = JCS_GRAYSCALE), and libjpeg then decodes the LUMA component alone -- entropy-decodes every
+// block, dequantises and inverse-transforms the Y blocks with its default "islow" integer IDCT (jidctint.c, bit-identical
+// in libjpeg-turbo's SIMD), adds 128, clamps.  Chroma never enters, so there is no upsampling and no colour matrix to get
+// wrong: the whole path is integer arithmetic with one published algorithm, restated here.
+//   * baseline / extended-sequential Huffman JPEG (SOF0 / SOF1), 8-bit, one interleaved scan (what cv::imwrite and PIL write),
+//     1 component (grey) or 3 (YCbCr; luma at full resolution: 4:4:4, 4:2:2, 4:2:0 ...), restart intervals;
+//   * progressive, arithmetic-coded, 12-bit, CMYK / Adobe-RGB files, multi-scan sequential files: R3D_ERR_UNSUPPORTED (the
+//     Python host names the PIL fallback).
+// PINNED against libjpeg-turbo itself through PIL's draft('L') decode (the same library request OpenCV makes):
+// tests/test_host_logic.py compares rasters byte for byte over sizes, qualities, subsamplings and restart intervals.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "r3d.h"
+#include "r3d_hostpool.h"
+
+namespace {
+
+const unsigned char kNatural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+  bool present = false;
+  // canonical code, JPEG Annex F.2.2.3: per length the smallest code, the largest, and where its symbols start
+  int32_t mincode[17], maxcode[18], valptr[17];
+  unsigned char vals[256];
+  // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
+  uint16_t look[512];
+};
+
+struct Component {
+  int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+};
+
+struct Jpeg {
+  int width = 0, height = 0, n_comp = 0;
+  Component comp[4];
+  uint16_t quant[4][64];   // in zigzag order, as stored
+  bool have_quant[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  int restart_interval = 0;
+  bool progressive = false, arithmetic = false, adobe = false;
+  int adobe_transform = -1, precision = 8;
+  size_t scan_begin = 0;   // first byte of the entropy-coded segment
+  bool have_sof = false, have_sos = false, scan_is_whole_image = false;
+};
+
+int fail(int code, const char* path, const std::string& why, std::string* msg) {
+  *msg = std::string("'") + path + "': " + why;
+  return code;
+}
+
+void build_huff(Huff* h, const unsigned char counts[16], const unsigned char* symbols, int n_symbols) {
+  h->present = true;
+  memcpy(h->vals, symbols, (size_t)n_symbols);
+  int code = 0, k = 0;
+  for (int len = 1; len <= 16; ++len) {
+    h->valptr[len] = k;
+    h->mincode[len] = code;
+    code += counts[len - 1];
+    k += counts[len - 1];
+    h->maxcode[len] = counts[len - 1] ? code - 1 : -1;
+    code <<= 1;
+  }
+  h->maxcode[17] = 0x7fffffff;
+  memset(h->look, 0, sizeof(h->look));
+  code = 0;
+  k = 0;
+  for (int len = 1; len <= 9; ++len) {
+    for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
+      const int first = code << (9 - len), n = 1 << (9 - len);
+      for (int j = 0; j < n; ++j) h->look[first + j] = (uint16_t)((len << 8) | symbols[k]);
+    }
+    code <<= 1;
+  }
+}
+
+// the marker segments up to (and including) the first SOS header
+int parse_headers(const char* path, const std::vector<unsigned char>& f, Jpeg* j, std::string* msg) {
+  if (f.size() < 4 || f[0] != 0xff || f[1] != 0xd8) return fail(R3D_ERR_INVALID, path, "not a JPEG file", msg);
+  size_t pos = 2;
+  while (pos + 4 <= f.size()) {
+    if (f[pos] != 0xff) return fail(R3D_ERR_INVALID, path, "marker expected", msg);
+    while (pos < f.size() && f[pos] == 0xff) ++pos;   // fill bytes
+    if (pos >= f.size()) break;
+    const int m = f[pos++];
+    if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) continue;   // stand-alone markers
+    if (m == 0xd9) break;
+    if (pos + 2 > f.size()) break;
+    const size_t len = ((size_t)f[pos] << 8) | f[pos + 1];
+    if (len < 2 || pos + len > f.size()) return fail(R3D_ERR_INVALID, path, "truncated marker segment", msg);
+    const unsigned char* d = &f[pos + 2];
+    const size_t n = len - 2;
+    if (m == 0xdb) {   // DQT
+      size_t at = 0;
+      while (at < n) {
+        const int pq = d[at] >> 4, tq = d[at] & 15;
+        ++at;
+        if (tq > 3 || at + (pq ? 128u : 64u) > n) return fail(R3D_ERR_INVALID, path, "bad quantisation table", msg);
+        for (int k = 0; k < 64; ++k) {
+          j->quant[tq][k] = pq ? (uint16_t)((d[at] << 8) | d[at + 1]) : d[at];
+          at += pq ? 2 : 1;
+        }
+        j->have_quant[tq] = true;
+      }
+    } else if (m == 0xc4) {   // DHT
+      size_t at = 0;
+      while (at + 17 <= n) {
+        const int tc = d[at] >> 4, th = d[at] & 15;
+        int total = 0;
+        for (int k = 0; k < 16; ++k) total += d[at + 1 + k];
+        if (tc > 1 || th > 3 || total > 256 || at + 17 + (size_t)total > n) return fail(R3D_ERR_INVALID, path, "bad Huffman table", msg);
+        build_huff(tc ? &j->ac[th] : &j->dc[th], &d[at + 1], &d[at + 17], total);
+        at += 17 + (size_t)total;
+      }
+    } else if (m == 0xc0 || m == 0xc1 || m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {   // SOFn
+      if (m == 0xc2 || m == 0xc6 || m == 0xca || m == 0xce) j->progressive = true;
+      if (m >= 0xc9) j->arithmetic = true;
+      if (m != 0xc0 && m != 0xc1 && m != 0xc2) return fail(R3D_ERR_UNSUPPORTED, path, "lossless / hierarchical / arithmetic-coded JPEG", msg);
+      if (n < 6) return fail(R3D_ERR_INVALID, path, "bad frame header", msg);
+      j->precision = d[0];
+      j->height = (d[1] << 8) | d[2];
+      j->width = (d[3] << 8) | d[4];
+      j->n_comp = d[5];
+      if (j->n_comp < 1 || j->n_comp > 4 || n < 6 + 3 * (size_t)j->n_comp) return fail(R3D_ERR_INVALID, path, "bad frame header", msg);
+      for (int c = 0; c < j->n_comp; ++c) {
+        j->comp[c].id = d[6 + 3 * c];
+        j->comp[c].h = d[7 + 3 * c] >> 4;
+        j->comp[c].v = d[7 + 3 * c] & 15;
+        j->comp[c].tq = d[8 + 3 * c];
+        if (j->comp[c].h < 1 || j->comp[c].h > 4 || j->comp[c].v < 1 || j->comp[c].v > 4 || j->comp[c].tq > 3)
+          return fail(R3D_ERR_INVALID, path, "bad sampling factors", msg);
+      }
+      j->have_sof = true;
+    } else if (m == 0xdd) {   // DRI
+      if (n >= 2) j->restart_interval = (d[0] << 8) | d[1];
+    } else if (m == 0xee) {   // APP14 "Adobe"
+      if (n >= 12 && !memcmp(d, "Adobe", 5)) {
+        j->adobe = true;
+        j->adobe_transform = d[11];
+      }
+    } else if (m == 0xda) {   // SOS
+      if (!j->have_sof) return fail(R3D_ERR_INVALID, path, "scan before frame header", msg);
+      const int ns = n ? d[0] : 0;
+      if (ns < 1 || ns > 4 || n < 4 + 2 * (size_t)ns) return fail(R3D_ERR_INVALID, path, "bad scan header", msg);
+      j->scan_is_whole_image = ns == j->n_comp;
+      for (int s = 0; s < ns; ++s) {
+        const int cid = d[1 + 2 * s];
+        bool found = false;
+        for (int c = 0; c < j->n_comp; ++c)
+          if (j->comp[c].id == cid) {
+            // the components of the one scan must come in frame order (libjpeg requires it too)
+            if (j->scan_is_whole_image && c != s) return fail(R3D_ERR_UNSUPPORTED, path, "scan components out of frame order", msg);
+            j->comp[c].td = d[2 + 2 * s] >> 4;
+            j->comp[c].ta = d[2 + 2 * s] & 15;
+            if (j->comp[c].td > 3 || j->comp[c].ta > 3) return fail(R3D_ERR_INVALID, path, "scan names a Huffman table beyond 3", msg);
+            found = true;
+          }
+        if (!found) return fail(R3D_ERR_INVALID, path, "scan names an unknown component", msg);
+      }
+      j->scan_begin = pos + len;
+      j->have_sos = true;
+      return R3D_OK;
+    }
+    pos += len;
+  }
+  return fail(R3D_ERR_INVALID, path, "no image data", msg);
+}
+
+struct Bits {
+  const unsigned char* p;
+  const unsigned char* end;
+  uint64_t buf = 0;
+  int n = 0;          // valid bits in buf (low end)
+  int marker = 0;     // a marker met in the data (its second byte); nothing is read past it
+  void fill() {
+    while (n <= 56) {
+      int byte = 0;
+      if (!marker && p < end) {
+        byte = *p;
+        if (byte == 0xff) {
+          if (p + 1 < end && p[1] == 0x00) {
+            p += 2;   // stuffed zero
+          } else {
+            // skip fill bytes, remember the marker, feed zeros from here on (libjpeg does the same)
+            const unsigned char* q = p + 1;
+            while (q < end && *q == 0xff) ++q;
+            marker = q < end ? *q : 0xd9;
+            p = q < end ? q + 1 : end;
+            byte = 0;
+          }
+        } else {
+          ++p;
+        }
+      }
+      buf = (buf << 8) | (uint64_t)byte;
+      n += 8;
+    }
+  }
+  inline int peek(int k) { return (int)((buf >> (n - k)) & ((1u << k) - 1)); }
+  inline void drop(int k) { n -= k; }
+  inline int get(int k) {
+    if (k == 0) return 0;
+    if (n < k) fill();
+    const int v = peek(k);
+    drop(k);
+    return v;
+  }
+};
+
+inline int decode_symbol(Bits& b, const Huff& h) {
+  if (b.n < 16) b.fill();
+  const uint16_t e = h.look[b.peek(9)];
+  if (e) {
+    b.drop(e >> 8);
+    return e & 0xff;
+  }
+  int code = b.peek(9), len = 9;
+  b.drop(9);
+  while (len <= 16 && code > h.maxcode[len]) {   // maxcode is -1 where a length has no codes: the loop moves on
+    if (b.n < 1) b.fill();
+    code = (code << 1) | b.get(1);
+    ++len;
+  }
+  if (len > 16) return -1;
+  return h.vals[h.valptr[len] + code - h.mincode[len]];
+}
+
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+// jidctint.c (IJG "islow", also libjpeg-turbo's reference for its SIMD): 13-bit constants, two passes, the first kept at 2
+// extra bits.  DESCALE(x, n) = (x + 2^(n-1)) >> n, arithmetic.
+constexpr int kConstBits = 13, kPass1Bits = 2;
+typedef int64_t wide;   // libjpeg's JLONG is `long`: 64 bits here, so hostile coefficients wrap nowhere (and UBSan stays quiet)
+constexpr wide F0_298631336 = 2446, F0_390180644 = 3196, F0_541196100 = 4433, F0_765366865 = 6270, F0_899976223 = 7373,
+               F1_175875602 = 9633, F1_501321110 = 12299, F1_847759065 = 15137, F1_961570560 = 16069, F2_053119869 = 16819,
+               F2_562915447 = 20995, F3_072711026 = 25172;
+inline wide descale(wide x, int n) { return (x + ((wide)1 << (n - 1))) >> n; }
+
+unsigned char g_range_limit[1024];   // index = value & 1023 (the value before the +128): libjpeg's table, wrap included
+struct RangeInit {
+  RangeInit() {
+    for (int i = 0; i < 1024; ++i) g_range_limit[i] = (unsigned char)(i < 128 ? 128 + i : i < 512 ? 255 : i < 896 ? 0 : i - 896);
+  }
+} g_range_init;
+
+// one 1-D pass over eight values; the two passes differ in where the values come from and how the results are scaled
+struct Idct8 {
+  wide o[8];
+  inline void run(wide c0, wide c1, wide c2, wide c3, wide c4, wide c5, wide c6, wide c7) {
+    wide z2 = c2, z3 = c6;
+    wide z1 = (z2 + z3) * F0_541196100;
+    wide tmp2 = z1 + z3 * (-F1_847759065);
+    wide tmp3 = z1 + z2 * F0_765366865;
+    wide tmp0 = (c0 + c4) * ((wide)1 << kConstBits);
+    wide tmp1 = (c0 - c4) * ((wide)1 << kConstBits);
+    const wide tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = c7;
+    tmp1 = c5;
+    tmp2 = c3;
+    tmp3 = c1;
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    wide z4 = tmp1 + tmp3;
+    const wide z5 = (z3 + z4) * F1_175875602;
+    tmp0 *= F0_298631336;
+    tmp1 *= F2_053119869;
+    tmp2 *= F3_072711026;
+    tmp3 *= F1_501321110;
+    z1 *= -F0_899976223;
+    z2 *= -F2_562915447;
+    z3 *= -F1_961570560;
+    z4 *= -F0_390180644;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    o[0] = tmp10 + tmp3;
+    o[7] = tmp10 - tmp3;
+    o[1] = tmp11 + tmp2;
+    o[6] = tmp11 - tmp2;
+    o[2] = tmp12 + tmp1;
+    o[5] = tmp12 - tmp1;
+    o[3] = tmp13 + tmp0;
+    o[4] = tmp13 - tmp0;
+  }
+};
+
+void idct_islow(const int16_t* coef, const uint16_t* quant_natural, unsigned char* out, size_t stride) {
+  wide ws[64];
+  Idct8 t;
+  for (int c = 0; c < 8; ++c) {   // pass 1: columns of the dequantised block -> workspace, 2 extra bits kept
+    const int16_t* in = coef + c;
+    const uint16_t* q = quant_natural + c;
+    t.run((wide)in[0] * q[0], (wide)in[8] * q[8], (wide)in[16] * q[16], (wide)in[24] * q[24], (wide)in[32] * q[32], (wide)in[40] * q[40],
+          (wide)in[48] * q[48], (wide)in[56] * q[56]);
+    for (int k = 0; k < 8; ++k) ws[8 * k + c] = descale(t.o[k], kConstBits - kPass1Bits);
+  }
+  for (int r = 0; r < 8; ++r) {   // pass 2: rows of the workspace -> samples (+128, clamped through libjpeg's table)
+    const wide* w = ws + 8 * r;
+    t.run(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+    unsigned char* o = out + stride * r;
+    for (int k = 0; k < 8; ++k) o[k] = g_range_limit[(int)(descale(t.o[k], kConstBits + kPass1Bits + 3) & 1023)];
+  }
+}
+
+int read_file(const char* path, std::vector<unsigned char>* file, std::string* msg) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(R3D_ERR_INVALID, path, "cannot open", msg);
+  unsigned char buf[1 << 16];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) file->insert(file->end(), buf, buf + n);
+  fclose(f);
+  return R3D_OK;
+}
+
+// out == NULL: header query
+int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, std::string* msg) {
+  std::vector<unsigned char> file;
+  int rc = read_file(path, &file, msg);
+  if (rc) return rc;
+  Jpeg j;
+  if ((rc = parse_headers(path, file, &j, msg))) return rc;
+  if (h_out) *h_out = j.height;
+  if (w_out) *w_out = j.width;
+  if (j.progressive) return fail(R3D_ERR_UNSUPPORTED, path, "progressive JPEG (only sequential Huffman files are decoded natively)", msg);
+  if (j.precision != 8) return fail(R3D_ERR_UNSUPPORTED, path, "12-bit JPEG", msg);
+  if (j.width < 1 || j.height < 1) return fail(R3D_ERR_UNSUPPORTED, path, "JPEG without its height in the frame header (DNL)", msg);
+  if (j.n_comp != 1 && j.n_comp != 3) return fail(R3D_ERR_UNSUPPORTED, path, "a JPEG of 2 or 4 components (CMYK / YCCK)", msg);
+  if (j.n_comp == 3 && j.adobe && j.adobe_transform == 0)
+    return fail(R3D_ERR_UNSUPPORTED, path, "an Adobe RGB JPEG (no luma component to take)", msg);
+  if (j.n_comp == 3 && !j.adobe && j.comp[0].id == 'R' && j.comp[1].id == 'G' && j.comp[2].id == 'B')
+    return fail(R3D_ERR_UNSUPPORTED, path, "an RGB JPEG (no luma component to take)", msg);
+  if (!j.scan_is_whole_image) return fail(R3D_ERR_UNSUPPORTED, path, "a multi-scan sequential JPEG", msg);
+  int hmax = 1, vmax = 1;
+  for (int c = 0; c < j.n_comp; ++c) {
+    hmax = std::max(hmax, j.comp[c].h);
+    vmax = std::max(vmax, j.comp[c].v);
+  }
+  if (j.n_comp == 1) {   // a single-component scan is not interleaved: one block per "MCU", whatever the sampling factors say
+    j.comp[0].h = j.comp[0].v = 1;
+    hmax = vmax = 1;
+  }
+  if (j.comp[0].h != hmax || j.comp[0].v != vmax)
+    return fail(R3D_ERR_UNSUPPORTED, path, "luma stored below full resolution", msg);
+  for (int c = 0; c < j.n_comp; ++c)
+    if (!j.have_quant[j.comp[c].tq] || !j.dc[j.comp[c].td].present || !j.ac[j.comp[c].ta].present)
+      return fail(R3D_ERR_INVALID, path, "a table the scan needs is missing", msg);
+  if (!out) return R3D_OK;
+  const size_t need = (size_t)j.width * j.height;
+  if (cap_bytes < need) return fail(R3D_ERR_NOMEM, path, "output buffer too small", msg);
+  const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+  const int mcus_x = (j.width + mcu_w - 1) / mcu_w, mcus_y = (j.height + mcu_h - 1) / mcu_h;
+  const size_t plane_w = (size_t)mcus_x * mcu_w;
+  std::vector<unsigned char> rows(plane_w * mcu_h);   // one MCU row of luma at a time
+  uint16_t q_nat[64];
+  for (int k = 0; k < 64; ++k) q_nat[kNatural[k]] = j.quant[j.comp[0].tq][k];
+  Bits b{file.data() + j.scan_begin, file.data() + file.size()};
+  int pred[4] = {0, 0, 0, 0};
+  int until_restart = j.restart_interval, next_rst = 0;
+  int16_t coef[64];
+  for (int my = 0; my < mcus_y; ++my) {
+    for (int mx = 0; mx < mcus_x; ++mx) {
+      if (j.restart_interval) {
+        if (until_restart == 0) {
+          // byte-align, expect RSTn
+          b.n = 0;
+          b.buf = 0;
+          if (!b.marker) {   // the marker has not been met yet: it must be right here
+            const unsigned char* q = b.p;
+            while (q < b.end && *q == 0xff) ++q;
+            if (q == b.p || q >= b.end) return fail(R3D_ERR_INVALID, path, "restart marker missing", msg);
+            b.marker = *q;
+            b.p = q + 1;
+          }
+          if (b.marker != 0xd0 + next_rst) return fail(R3D_ERR_INVALID, path, "restart marker out of sequence", msg);
+          b.marker = 0;
+          next_rst = (next_rst + 1) & 7;
+          pred[0] = pred[1] = pred[2] = pred[3] = 0;
+          until_restart = j.restart_interval;
+        }
+        --until_restart;
+      }
+      for (int c = 0; c < j.n_comp; ++c) {
+        const Component& cp = j.comp[c];
+        const Huff &hd = j.dc[cp.td], &ha = j.ac[cp.ta];
+        for (int by = 0; by < cp.v; ++by)
+          for (int bx = 0; bx < cp.h; ++bx) {
+            const bool keep = c == 0;
+            if (keep) memset(coef, 0, sizeof(coef));
+            int s = decode_symbol(b, hd);
+            if (s < 0 || s > 15) return fail(R3D_ERR_INVALID, path, "corrupt entropy-coded data", msg);
+            if (s) pred[c] = (int)((unsigned)pred[c] + (unsigned)extend(b.get(s), s));   // (hostile data may wrap, never overflow)
+            if (keep) coef[0] = (int16_t)pred[c];
+            for (int k = 1; k < 64; ++k) {
+              const int rs = decode_symbol(b, ha);
+              if (rs < 0) return fail(R3D_ERR_INVALID, path, "corrupt entropy-coded data", msg);
+              const int r = rs >> 4;
+              s = rs & 15;
+              if (s == 0) {
+                if (r != 15) break;   // end of block
+                k += 15;
+                continue;
+              }
+              k += r;
+              if (k > 63) return fail(R3D_ERR_INVALID, path, "corrupt entropy-coded data", msg);
+              const int v = extend(b.get(s), s);
+              if (keep) coef[kNatural[k]] = (int16_t)v;
+            }
+            if (keep) idct_islow(coef, q_nat, rows.data() + (size_t)by * 8 * plane_w + (size_t)mx * mcu_w + (size_t)bx * 8, plane_w);
+          }
+      }
+    }
+    const int y0 = my * mcu_h, ny = std::min(mcu_h, j.height - y0);
+    for (int y = 0; y < ny; ++y) memcpy(out + (size_t)(y0 + y) * j.width, rows.data() + (size_t)y * plane_w, (size_t)j.width);
+  }
+  return R3D_OK;
+}
+
+int decode_gray(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, std::string* msg) {
+  try {
+    return decode_gray_impl(path, out, cap_bytes, h_out, w_out, msg);
+  } catch (const std::exception& e) {
+    try {
+      *msg = std::string("'") + path + "': " + e.what();
+    } catch (...) {
+    }
+    return R3D_ERR_NOMEM;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_jpeg_gray_info(const char* path, int* height, int* width) {
+  if (!path) {
+    r3d_set_error("r3d_jpeg_gray_info: path is NULL");
+    return R3D_ERR_INVALID;
+  }
+  std::string msg;
+  const int rc = decode_gray(path, nullptr, 0, height, width, &msg);
+  if (rc) r3d_set_error("%s", msg.c_str());
+  return rc;
+}
+
+int r3d_jpeg_gray_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width) {
+  if (n_files < 0 || (n_files > 0 && (!paths || !h_out)) || height <= 0 || width <= 0) {
+    r3d_set_error("r3d_jpeg_gray_decode_batch: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  const size_t frame_bytes = (size_t)height * width;
+  return r3d_host::run_batch(n_files, "JPEG decode failed", [&](int k, std::string* msg) -> int {
+    int h = 0, w = 0;
+    int rc = paths[k] ? decode_gray(paths[k], h_out + frame_bytes * k, frame_bytes, &h, &w, msg) : R3D_ERR_INVALID;
+    if (rc == R3D_OK && (h != height || w != width)) {
+      rc = R3D_ERR_INVALID;
+      *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + ", the batch expects " +
+             std::to_string(width) + "x" + std::to_string(height);
+    }
+    return rc;
+  });
+}
+
+}  // extern "C"

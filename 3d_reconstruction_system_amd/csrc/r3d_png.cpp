@@ -21,8 +21,7 @@
 #include <vector>
 
 #include "r3d.h"
-
-void r3d_set_error(const char* fmt, ...);
+#include "r3d_hostpool.h"
 
 namespace {
 
@@ -332,41 +331,6 @@ int decode_rgb(const char* path, unsigned char* out, size_t cap_bytes, int* h_ou
   }
 }
 
-// runs decode_one(k) for k in [0, n) on a thread pool; first failure wins
-template <typename F>
-int run_batch(int n_files, const char* what, F&& decode_one) {
-  unsigned hw = std::thread::hardware_concurrency();
-  const unsigned n_threads = std::max(1u, std::min<unsigned>(hw == 0 ? 1 : hw, std::min(32, n_files)));
-  std::atomic<int> next{0}, first_rc{R3D_OK};
-  std::string first_msg;
-  std::atomic<bool> have_msg{false};
-  auto worker = [&]() {
-    for (;;) {
-      const int k = next.fetch_add(1);
-      if (k >= n_files || first_rc.load() != R3D_OK) return;
-      std::string msg;
-      const int rc = decode_one(k, &msg);
-      if (rc != R3D_OK) {
-        int expected = R3D_OK;
-        if (first_rc.compare_exchange_strong(expected, rc)) {
-          first_msg = msg.empty() ? "bad path" : msg;
-          have_msg.store(true);
-        }
-        return;
-      }
-    }
-  };
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto& t : pool) t.join();
-  if (first_rc.load() != R3D_OK) {
-    r3d_set_error("%s", have_msg.load() ? first_msg.c_str() : what);
-    return first_rc.load();
-  }
-  return R3D_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -388,7 +352,7 @@ int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out
     return R3D_ERR_INVALID;
   }
   const size_t frame_bytes = (size_t)height * width * (bit_depth / 8);
-  return run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
+  return r3d_host::run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
     int h = 0, w = 0, bits = 0;
     int rc = paths[k] ? decode_gray(paths[k], static_cast<char*>(h_out) + frame_bytes * k, frame_bytes, &h, &w, &bits, msg)
                       : R3D_ERR_INVALID;
@@ -429,7 +393,7 @@ int r3d_png_gray8_decode_batch(const char* const* paths, int n_files, unsigned c
     return R3D_ERR_INVALID;
   }
   const size_t frame_bytes = (size_t)height * width;
-  return run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
+  return r3d_host::run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
     int h = 0, w = 0;
     int rc = paths[k] ? decode_gray8(paths[k], h_out + frame_bytes * k, frame_bytes, rule, &h, &w, msg) : R3D_ERR_INVALID;
     if (rc == R3D_OK && (h != height || w != width)) {
@@ -458,7 +422,7 @@ int r3d_png_rgb_decode_batch(const char* const* paths, int n_files, unsigned cha
     return R3D_ERR_INVALID;
   }
   const size_t frame_bytes = (size_t)height * width * 3;
-  return run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
+  return r3d_host::run_batch(n_files, "PNG decode failed", [&](int k, std::string* msg) -> int {
     int h = 0, w = 0, ch = 0;
     int rc = paths[k] ? decode_rgb(paths[k], h_out + frame_bytes * k, frame_bytes, &h, &w, &ch, msg) : R3D_ERR_INVALID;
     if (rc == R3D_OK && (h != height || w != width)) {

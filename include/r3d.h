@@ -445,6 +445,13 @@ int r3d_png_gray_decode_batch(const char* const* paths, int n_files, void* h_out
 int r3d_png_gray8_info(const char* path, int* height, int* width);
 int r3d_png_gray8_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width, int rule);
 int r3d_rgb_to_gray_u8(const unsigned char* pixels, int64_t n_pixels, int channels, int rule, unsigned char* gray_out);
+/* The same for JPEG depth files (AirSim writes its depth images as 3-channel JPG, airsim/main.cpp:1369-1392): OpenCV's JPEG reader
+ * asks libjpeg for GREY output, i.e. the luma component alone through libjpeg's default integer IDCT ("islow", jidctint.c), + 128,
+ * clamped -- restated here, pinned byte for byte against libjpeg-turbo (PIL's draft('L') decode makes the same request).
+ * Sequential Huffman JPEGs of 1 or 3 (YCbCr) components with full-resolution luma, restart intervals included; progressive,
+ * arithmetic-coded, 12-bit, CMYK and RGB-tagged files: R3D_ERR_UNSUPPORTED.  n files into one [n][height][width] buffer. */
+int r3d_jpeg_gray_info(const char* path, int* height, int* width);
+int r3d_jpeg_gray_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width);
 /* The colour images of the RGBD path (the `Image.open(imgpath)` of genply_noRGB, pixel_to_camera.py:58-60): non-interlaced
  * 8-bit PNGs -- RGB, RGBA (alpha dropped) or grey (replicated) -- as R,G,B bytes, n files into one [n][height][width][3]
  * buffer, which is what r3d_fuse_frames_rgb takes.  *channels = samples per pixel in the file. */

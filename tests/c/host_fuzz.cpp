@@ -1,7 +1,9 @@
-// ASan/UBSan driver for the host-only translation units of the library (formatters, PNG decoder):
+// ASan/UBSan driver for the host-only translation units of the library (formatters, PNG and JPEG decoders):
 //   g++ -std=c++17 -g -fsanitize=address,undefined -Iinclude tests/c/host_fuzz.cpp \
-//       3d_reconstruction_system_amd/csrc/r3d_format.cpp 3d_reconstruction_system_amd/csrc/r3d_png.cpp -lz -lpthread -o host_fuzz
+//       3d_reconstruction_system_amd/csrc/r3d_format.cpp 3d_reconstruction_system_amd/csrc/r3d_png.cpp \
+//       3d_reconstruction_system_amd/csrc/r3d_jpeg.cpp -lz -lpthread -o host_fuzz
 // (GPU sanitizers are not available on the pool; the host code is where unchecked buffers could hide.)
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -117,6 +119,8 @@ int main(int argc, char** argv) {
     }
     // colour files given as further arguments: valid decode, then corrupted copies
     for (int a = 2; a < argc; ++a) {
+      const size_t alen = strlen(argv[a]);
+      if (alen > 4 && !strcmp(argv[a] + alen - 4, ".jpg")) continue;   // JPEG files: below
       int ch = 0, ch2 = 0, h2 = 0, w2 = 0;
       if (r3d_png_rgb_info(argv[a], &h2, &w2, &ch) != R3D_OK) return 5;
       std::vector<unsigned char> rgb_out((size_t)h2 * w2 * 3);
@@ -139,7 +143,69 @@ int main(int argc, char** argv) {
       }
     }
     printf("corrupted PNG trials decoded without error: %d of 400 (no crash either way)\n", survived);
+    // the IMREAD_GRAYSCALE raster of every PNG argument (grey, colour, alpha), both rules, then corrupted copies
+    for (int a = 1; a < argc; ++a) {
+      const size_t alen = strlen(argv[a]);
+      if (alen > 4 && !strcmp(argv[a] + alen - 4, ".jpg")) continue;
+      int h2 = 0, w2 = 0;
+      if (r3d_png_gray8_info(argv[a], &h2, &w2) != R3D_OK) return 7;
+      std::vector<unsigned char> g8((size_t)h2 * w2);
+      const char* one2[1] = {argv[a]};
+      for (int rule : {R3D_GRAY_OPENCV_PNG, R3D_GRAY_CVTCOLOR})
+        if (r3d_png_gray8_decode_batch(one2, 1, g8.data(), h2, w2, rule) != R3D_OK) return 8;
+      FILE* f2 = fopen(argv[a], "rb");
+      std::vector<unsigned char> png2;
+      while ((k = fread(tmp, 1, sizeof(tmp), f2)) > 0) png2.insert(png2.end(), tmp, tmp + k);
+      fclose(f2);
+      for (int trial = 0; trial < 150; ++trial) {
+        std::vector<unsigned char> bad = png2;
+        for (int j = 0; j < 1 + (int)(rng() % 6); ++j) bad[rng() % bad.size()] = (unsigned char)rng();
+        if (trial % 5 == 0) bad.resize(rng() % bad.size());
+        FILE* g = fopen("/tmp/r3d_fuzz_g8.png", "wb");
+        fwrite(bad.data(), 1, bad.size(), g);
+        fclose(g);
+        const char* p[1] = {"/tmp/r3d_fuzz_g8.png"};
+        int hh = 0, ww = 0;
+        if (r3d_png_gray8_info(p[0], &hh, &ww) == R3D_OK && hh == h2 && ww == w2) (void)r3d_png_gray8_decode_batch(p, 1, g8.data(), h2, w2, trial & 1);
+      }
+    }
   }
+  // JPEG decoder: every *.jpg argument decodes, then hostile copies of it (flipped bytes anywhere -- tables, frame header,
+  // entropy-coded data -- and truncations) must come back with a status, not with a crash or an out-of-bounds access
+  int jpeg_trials = 0, jpeg_decoded = 0;
+  for (int a = 1; a < argc; ++a) {
+    const size_t alen = strlen(argv[a]);
+    if (!(alen > 4 && !strcmp(argv[a] + alen - 4, ".jpg"))) continue;
+    int h2 = 0, w2 = 0;
+    if (r3d_jpeg_gray_info(argv[a], &h2, &w2) != R3D_OK) return 30;
+    std::vector<unsigned char> y((size_t)h2 * w2);
+    const char* one2[1] = {argv[a]};
+    if (r3d_jpeg_gray_decode_batch(one2, 1, y.data(), h2, w2) != R3D_OK) return 31;
+    FILE* f2 = fopen(argv[a], "rb");
+    if (!f2) return 32;
+    std::vector<unsigned char> jpg;
+    unsigned char tmp2[4096];
+    size_t k2;
+    while ((k2 = fread(tmp2, 1, sizeof(tmp2), f2)) > 0) jpg.insert(jpg.end(), tmp2, tmp2 + k2);
+    fclose(f2);
+    for (int trial = 0; trial < 500; ++trial, ++jpeg_trials) {
+      std::vector<unsigned char> bad = jpg;
+      const int flips = 1 + (int)(rng() % 10);
+      // half of the trials aim at the headers (the first 700 bytes hold the tables and the frame / scan headers)
+      for (int j = 0; j < flips; ++j) bad[(trial & 1) ? rng() % std::min<size_t>(bad.size(), 700) : rng() % bad.size()] = (unsigned char)rng();
+      if (trial % 6 == 0) bad.resize(rng() % bad.size());
+      FILE* g = fopen("/tmp/r3d_fuzz.jpg", "wb");
+      fwrite(bad.data(), 1, bad.size(), g);
+      fclose(g);
+      const char* p[1] = {"/tmp/r3d_fuzz.jpg"};
+      int hh = 0, ww = 0;
+      if (r3d_jpeg_gray_info(p[0], &hh, &ww) == R3D_OK && hh > 0 && ww > 0 && (int64_t)hh * ww <= (int64_t)1 << 22) {
+        std::vector<unsigned char> yy((size_t)hh * ww);
+        jpeg_decoded += r3d_jpeg_gray_decode_batch(p, 1, yy.data(), hh, ww) == R3D_OK;
+      }
+    }
+  }
+  if (jpeg_trials) printf("corrupted JPEG trials decoded without error: %d of %d (no crash either way)\n", jpeg_decoded, jpeg_trials);
   printf("host fuzz OK: %lld points formatted\n", (long long)n);
   return 0;
 }

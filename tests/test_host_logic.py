@@ -494,17 +494,22 @@ def test_colour_depth_files_take_the_opencv_rules_not_pils(R, tmp_path, monkeypa
     # BMP: decoded in colour, converted by cvtColor's rule
     Image.fromarray(rgb, "RGB").save(tmp_path / "c.bmp")
     np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "c.bmp")), _gray_cvtcolor(r, g, b))
-    # JPEG: refused by default, with the way out in the message
+    # JPEG: sequential files decode natively (libjpeg's grey output = the luma channel; tests below pin the bytes); a
+    # progressive one is refused by default, with the way out in the message
     Image.fromarray(rgb, "RGB").save(tmp_path / "c.jpg", quality=95)
-    with pytest.raises(R.cloud_io.UnsupportedDepthFormat) as e:
-        R.cloud_io.read_depth_gray(str(tmp_path / "c.jpg"))
-    assert e.value.code == L.ERR_UNSUPPORTED and "allow_pil_jpeg" in str(e.value) and "R3D_ALLOW_PIL_JPEG" in str(e.value)
-    with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
-        R.cloud_io.read_depth_batch([str(tmp_path / "c.jpg")])
-    j = R.cloud_io.read_depth_gray(str(tmp_path / "c.jpg"), allow_pil_jpeg=True)
+    j = R.cloud_io.read_depth_gray(str(tmp_path / "c.jpg"))
     assert j.shape == (H, W) and j.dtype == np.uint8 and np.abs(j.astype(int) - _gray_cvtcolor(r, g, b)).mean() < 12
-    monkeypatch.setenv("R3D_ALLOW_PIL_JPEG", "1")
     np.testing.assert_array_equal(R.cloud_io.read_depth_batch([str(tmp_path / "c.jpg")])[0], j)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "p.jpg", quality=95, progressive=True)
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat) as e:
+        R.cloud_io.read_depth_gray(str(tmp_path / "p.jpg"))
+    assert e.value.code == L.ERR_UNSUPPORTED and "allow_pil_jpeg" in str(e.value) and "R3D_ALLOW_PIL_JPEG" in str(e.value) and "progressive" in str(e.value)
+    with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
+        R.cloud_io.read_depth_batch([str(tmp_path / "p.jpg")])
+    jp = R.cloud_io.read_depth_gray(str(tmp_path / "p.jpg"), allow_pil_jpeg=True)
+    assert jp.shape == (H, W) and np.abs(jp.astype(int) - j).max() <= 2          # the same image, another coding
+    monkeypatch.setenv("R3D_ALLOW_PIL_JPEG", "1")
+    np.testing.assert_array_equal(R.cloud_io.read_depth_batch([str(tmp_path / "p.jpg")])[0], jp)
     # a palette PNG is not guessed at either
     Image.fromarray(rgb, "RGB").quantize(16).save(tmp_path / "p.png")
     with pytest.raises(R.cloud_io.UnsupportedDepthFormat):
@@ -539,3 +544,77 @@ def test_gamma_tagged_colour_png_is_refused_not_approximated(R, tmp_path):
     np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "tagged.png"), rule="cvtcolor"),
                                   _gray_cvtcolor(rgb[..., 0], rgb[..., 1], rgb[..., 2]))
     np.testing.assert_array_equal(R.cloud_io.read_depth_gray(str(tmp_path / "tagged_grey.png")), g)
+
+
+def _pil_luma(path):
+    """libjpeg(-turbo) asked for greyscale output through PIL's draft mode: what OpenCV's JPEG reader requests for IMREAD_GRAYSCALE."""
+    from PIL import Image
+    im = Image.open(path)
+    im.draft("L", im.size)
+    return np.array(im)
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (8, 8), (16, 16), (37, 53), (100, 300), (384, 1280), (1080, 1920)])
+def test_native_jpeg_grey_equals_libjpeg_byte_for_byte(R, tmp_path, hw):
+    """f3 / config 5's depth files: csrc/r3d_jpeg.cpp restates libjpeg's grey output (luma alone, "islow" integer IDCT) -- the
+    request OpenCV's JPEG reader makes for IMREAD_GRAYSCALE (c2w:160 on AirSim's JPG depth).  Pinned against libjpeg-turbo itself
+    (PIL's draft('L') decode): every raster byte for byte, over sizes that are not multiples of the MCU, qualities 5..100, the
+    three usual chroma subsamplings and grey files, optimised Huffman tables, restart intervals; batches too."""
+    from PIL import Image
+    H, W = hw
+    rng = np.random.default_rng(H * 7 + W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (np.stack([128 + 100 * np.sin(xx / 17.0 + yy / 9.0), 128 + 90 * np.cos(xx / 5.0), 100 + yy % 97], 2)
+           + rng.normal(0, 15, (H, W, 3))).clip(0, 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    big = H * W > 500_000
+    variants = [dict(quality=q, subsampling=sub) for q in ((75, 95) if big else (5, 30, 75, 95, 100)) for sub in (0, 1, 2)]
+    variants += [dict(quality=90, optimize=True), dict(quality=85, restart_marker_blocks=7), dict(quality=85, restart_marker_rows=1, subsampling=2)]
+    paths = []
+    for k, kw in enumerate(variants):
+        p = str(tmp_path / ("v%d.jpg" % k))
+        try:
+            Image.fromarray(noise if k % 5 == 4 else img, "RGB").save(p, **kw)
+        except (TypeError, ValueError, OSError):          # an older Pillow without the restart options
+            continue
+        paths.append(p)
+    for k, q in enumerate((20, 90)):
+        p = str(tmp_path / ("g%d.jpg" % k))
+        Image.fromarray(img[..., 0], "L").save(p, quality=q)
+        paths.append(p)
+    assert len(paths) >= 9
+    for p in paths:
+        np.testing.assert_array_equal(R.cloud_io.read_depth_gray(p), _pil_luma(p), err_msg=p)
+    got = R.cloud_io.read_depth_batch(paths)
+    assert got.shape == (len(paths), H, W)
+    for k, p in enumerate(paths):
+        np.testing.assert_array_equal(got[k], _pil_luma(p))
+
+
+def test_native_jpeg_refuses_what_it_does_not_restate(R, tmp_path):
+    from PIL import Image
+    import ctypes as C
+    L = importlib.import_module(R.__name__ + "._lib")
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    lib = R.load_library()
+    h, w = C.c_int(), C.c_int()
+    Image.fromarray(img, "RGB").save(tmp_path / "p.jpg", progressive=True)
+    Image.fromarray(img, "RGB").convert("CMYK").save(tmp_path / "c.jpg")
+    (tmp_path / "t.jpg").write_bytes(b"\xff\xd8\xff\xe0\x00\x10JFIF")
+    (tmp_path / "n.jpg").write_bytes(b"not a jpeg at all")
+    assert lib.r3d_jpeg_gray_info(os.fsencode(str(tmp_path / "p.jpg")), C.byref(h), C.byref(w)) == L.ERR_UNSUPPORTED
+    assert (h.value, w.value) == (40, 56)                                  # the size is still reported
+    assert lib.r3d_jpeg_gray_info(os.fsencode(str(tmp_path / "c.jpg")), C.byref(h), C.byref(w)) == L.ERR_UNSUPPORTED
+    assert lib.r3d_jpeg_gray_info(os.fsencode(str(tmp_path / "t.jpg")), C.byref(h), C.byref(w)) == L.ERR_INVALID
+    assert lib.r3d_jpeg_gray_info(os.fsencode(str(tmp_path / "n.jpg")), C.byref(h), C.byref(w)) == L.ERR_INVALID
+    assert lib.r3d_jpeg_gray_info(os.fsencode(str(tmp_path / "missing.jpg")), C.byref(h), C.byref(w)) == L.ERR_INVALID
+    # truncated entropy data: zeros are fed behind the end like libjpeg does -- no crash, a raster comes back
+    Image.fromarray(img, "RGB").save(tmp_path / "ok.jpg", quality=90)
+    data = (tmp_path / "ok.jpg").read_bytes()
+    (tmp_path / "cut.jpg").write_bytes(data[: len(data) * 2 // 3])
+    out = np.empty((40, 56), np.uint8)
+    arr = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "cut.jpg")))
+    assert lib.r3d_jpeg_gray_decode_batch(arr, 1, out.ctypes.data, 40, 56) in (L.OK, L.ERR_INVALID)
+    arr = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "ok.jpg")))
+    assert lib.r3d_jpeg_gray_decode_batch(arr, 1, out.ctypes.data, 41, 56) == L.ERR_INVALID      # another size than the batch's

@@ -1,5 +1,5 @@
-"""CPU: the host-only translation units (text formatters, PNG decoder) under AddressSanitizer + UBSan with hostile
-inputs (random bit patterns as doubles, corrupted PNG files).  GPU sanitizers are unavailable on the pool."""
+"""CPU: the host-only translation units (text formatters, PNG and JPEG decoders) under AddressSanitizer + UBSan with hostile
+inputs (random bit patterns as doubles, corrupted PNG and JPEG files).  GPU sanitizers are unavailable on the pool."""
 import os
 import subprocess
 
@@ -14,7 +14,7 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path, golden_dir):
     build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                             "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"),
                             os.path.join(ROOT, "tests", "c", "host_fuzz.cpp"), os.path.join(src, "r3d_format.cpp"),
-                            os.path.join(src, "r3d_png.cpp"), "-lz", "-lpthread", "-o", exe],
+                            os.path.join(src, "r3d_png.cpp"), os.path.join(src, "r3d_jpeg.cpp"), "-I", src, "-lz", "-lpthread", "-o", exe],
                            capture_output=True, text=True)
     if build.returncode != 0 and "sanitize" in build.stderr:
         pytest.skip("this g++ has no sanitizer runtime")
@@ -24,8 +24,15 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path, golden_dir):
     rng = np.random.default_rng(0)
     Image.fromarray(rng.integers(0, 256, (33, 47, 3), dtype=np.uint8), "RGB").save(tmp_path / "c.png")
     Image.fromarray(rng.integers(0, 256, (33, 47, 4), dtype=np.uint8), "RGBA").save(tmp_path / "a.png")
+    yy, xx = np.mgrid[0:61, 0:83]
+    smooth = (np.stack([128 + 100 * np.sin(xx / 7.0 + yy / 5.0), 128 + 90 * np.cos(xx / 3.0), 100 + yy % 97], 2)
+              + rng.normal(0, 10, (61, 83, 3))).clip(0, 255).astype(np.uint8)
+    Image.fromarray(smooth, "RGB").save(tmp_path / "s420.jpg", quality=85, subsampling=2)
+    Image.fromarray(smooth, "RGB").save(tmp_path / "s444.jpg", quality=95, subsampling=0, optimize=True)
+    Image.fromarray(smooth[..., 0], "L").save(tmp_path / "grey.jpg", quality=60)
     run = subprocess.run([exe, os.path.join(golden_dir, "scene3", "depth", "000.png"), str(tmp_path / "c.png"),
-                          str(tmp_path / "a.png")], capture_output=True, text=True,
+                          str(tmp_path / "a.png"), str(tmp_path / "s420.jpg"), str(tmp_path / "s444.jpg"), str(tmp_path / "grey.jpg")],
+                         capture_output=True, text=True,
                          timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
-    assert "host fuzz OK" in run.stdout
+    assert "host fuzz OK" in run.stdout and "corrupted JPEG trials" in run.stdout
