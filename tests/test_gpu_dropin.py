@@ -250,3 +250,42 @@ def test_pixel_to_camera_script_writes_the_coloured_ply_when_the_image_exists(tm
     out = run_script("transfer/pixel_to_camera.py", str(tmp_path))
     assert "Write into .ply file Done." in out
     assert (tmp_path / "ply" / "24.ply").read_bytes() == O.format_ply_rgb(O.unproject(depth), rgb.reshape(-1, 3)).encode()
+
+
+def test_camera_to_world_script_on_jpeg_depth_files(tmp_path):
+    """Config 5's input flavour: AirSim writes its depth images as 3-channel JPG (airsim/main.cpp:1369-1392) and
+    camera_to_world.py:160 reads depth with IMREAD_GRAYSCALE, which for a JPEG is libjpeg's grey output (the luma channel).
+    The drop-in decodes them natively; every file it writes must equal the oracle's loops on the rasters libjpeg itself
+    (through PIL's draft mode) gives for the same files -- camera txts and PLY byte for byte."""
+    from PIL import Image
+    rng = np.random.default_rng(41)
+    F, H, W = 4, 40, 72
+    for d in ("depth", "camera_pose", "point", "point_world", "ply"):
+        os.makedirs(tmp_path / d)
+    yy, xx = np.mgrid[0:H, 0:W]
+    rasters = []
+    with open(tmp_path / "camera_pose" / "image_colmap_simi_2.txt", "w") as f:
+        f.write("id,tx,ty,tz,qx,qy,qz,qw,name,extra\n")
+        for k in range(F):
+            img = (np.stack([90 + 60 * np.sin(xx / 9.0 + k), 120 + 50 * np.cos(yy / 7.0), 100 + (xx + yy) % 80], 2)
+                   + rng.normal(0, 6, (H, W, 3))).clip(0, 255).astype(np.uint8)
+            p = tmp_path / "depth" / ("%03d.jpg" % k)
+            Image.fromarray(img, "RGB").save(p, quality=(95, 80, 60, 90)[k], subsampling=(0, 2, 1, 2)[k])
+            im = Image.open(p)
+            im.draft("L", im.size)
+            rasters.append(np.array(im))
+            q, t = rng.normal(size=4), rng.normal(size=3) * 10
+            f.write(",".join([str(k)] + [repr(float(x)) for x in t] + [repr(float(x)) for x in q] + ["%03d.jpg" % k, "x"]) + "\n")
+    out = run_script("transfer/camera_to_world.py", str(tmp_path))
+    assert "Write into .ply file Done." in out
+    names, quats, ts = O.parse_pose_file(str(tmp_path / "camera_pose" / "image_colmap_simi_2.txt"))
+    ref = tmp_path / "ref"
+    os.makedirs(ref)
+    xs, ys, zs = [], [], []
+    for k in range(F):
+        cam = str(ref / ("%03d.txt" % k))
+        O.gentxtcord_loop(cam, rasters[k])
+        O.get_pointdata_loop(cam, quats[k], ts[k], xs, ys, zs, str(ref / "world.txt"))
+        assert (tmp_path / "point" / ("%03d.txt" % k)).read_bytes() == open(cam, "rb").read(), k
+    O.genply_loop([xs, ys, zs], str(ref / "fused.ply"))
+    assert (tmp_path / "ply" / "small_035_p8.ply").read_bytes() == open(ref / "fused.ply", "rb").read()
