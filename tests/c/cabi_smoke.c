@@ -94,6 +94,23 @@ int main(void) {
     }
     free(txt);
   }
+  /* the colour -> grey rules of the depth-file readers, straight on pixels: known answers (include/r3d.h, R3D_GRAY_*) */
+  {
+    const unsigned char px[4 * 3] = {255, 0, 0, 0, 255, 0, 12, 200, 77, 9, 9, 9};
+    unsigned char g[4];
+    CK(r3d_rgb_to_gray_u8(px, 4, 3, R3D_GRAY_OPENCV_PNG, g));
+    if (g[0] != 76 || g[1] != 149 || g[2] != 129 || g[3] != 9) { fprintf(stderr, "libpng grey rule: %d %d %d %d\n", g[0], g[1], g[2], g[3]); return 1; }
+    CK(r3d_rgb_to_gray_u8(px, 4, 3, R3D_GRAY_CVTCOLOR, g));
+    if (g[0] != 76 || g[1] != 150 || g[2] != 130 || g[3] != 9) { fprintf(stderr, "cvtColor grey rule: %d %d %d %d\n", g[0], g[1], g[2], g[3]); return 1; }
+    if (r3d_rgb_to_gray_u8(px, 4, 3, 5, g) != R3D_ERR_INVALID) { fprintf(stderr, "unknown grey rule accepted\n"); return 1; }
+    {
+      int h = 0, w = 0;
+      if (r3d_jpeg_gray_info("/nonexistent/depth.jpg", &h, &w) != R3D_ERR_INVALID || r3d_png_gray8_info("/nonexistent/depth.png", &h, &w) == R3D_OK) {
+        fprintf(stderr, "missing depth file not reported\n");
+        return 1;
+      }
+    }
+  }
   /* staging sweep + colour-carrying launch on device memory */
   {
     void *d_depth = NULL, *d_pose = NULL, *d_rgb = NULL, *d_xyz = NULL, *d_rgba = NULL;
