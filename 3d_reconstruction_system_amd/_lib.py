@@ -125,6 +125,8 @@ SIGNATURES = {
     "r3d_rgb_to_gray_u8": (_i, [_vp, C.c_int64, _i, _i, _vp]),
     "r3d_jpeg_gray_info": (_i, [C.c_char_p, _pi, _pi]),
     "r3d_jpeg_gray_decode_batch": (_i, [_vp, _i, _vp, _i, _i]),
+    "r3d_jpeg_rgb_info": (_i, [C.c_char_p, _pi, _pi, _pi]),
+    "r3d_jpeg_rgb_decode_batch": (_i, [_vp, _i, _vp, _i, _i]),
     "r3d_png_rgb_info": (_i, [C.c_char_p, _pi, _pi, _pi]),
     "r3d_png_rgb_decode_batch": (_i, [_vp, _i, _vp, _i, _i]),
     "r3d_voxelset_create": (_i, [_vp, _d, _i64, _pvp]),

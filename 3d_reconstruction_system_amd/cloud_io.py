@@ -170,14 +170,17 @@ def read_depth_batch(paths, out=None, rule=None):
 
 def read_rgb_batch(paths, out=None):
     """[F,H,W,3] uint8 (R,G,B) for a list of colour images -- the colour planes of the RGBD path (fuse_frames_rgb).
-    8-bit RGB / RGBA / grey PNGs are decoded by the library's host threads into one contiguous (optionally pinned) buffer;
-    anything else goes through PIL file by file."""
+    8-bit RGB / RGBA / grey PNGs and sequential YCbCr / grey JPEGs (4:4:4, 4:2:2, 4:2:0 -- the bytes PIL's Image.open gives,
+    which is what the reference reads colour with, p2c:58-60) are decoded by the library's host threads into one contiguous
+    (optionally pinned) buffer; anything else goes through PIL file by file."""
     paths = [os.fspath(p) for p in paths]
     if not paths:
         return np.empty((0, 0, 0, 3), np.uint8)
     lib = L.load()
     h, w, ch = C.c_int(), C.c_int(), C.c_int()
-    rc = lib.r3d_png_rgb_info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch))
+    jpeg = os.path.exists(paths[0]) and not _is_png(paths[0]) and _is_jpeg(paths[0])
+    info = lib.r3d_jpeg_rgb_info if jpeg else lib.r3d_png_rgb_info
+    rc = info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch))
     if rc == L.OK:
         shape = (len(paths), h.value, w.value, 3)
         if out is None:
@@ -185,7 +188,8 @@ def read_rgb_batch(paths, out=None):
         elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        rc = lib.r3d_png_rgb_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value)
+        decode = lib.r3d_jpeg_rgb_decode_batch if jpeg else lib.r3d_png_rgb_decode_batch
+        rc = decode(arr, len(paths), out.ctypes.data, h.value, w.value)
         if rc == L.OK:
             return out
         if rc != L.ERR_UNSUPPORTED:

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "r3d.h"
+#include "r3d_hostpool.h"
 
 void r3d_set_error(const char* fmt, ...);
 
@@ -241,6 +242,7 @@ int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, 
   if (hw == 0) hw = 1;
   int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
   chunks->assign((size_t)n_chunks, std::string());
+  const r3d_host::Spread spread;
   std::vector<std::thread> pool;
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int64_t lo = n * c / n_chunks, hi = n * (c + 1) / n_chunks;
@@ -253,7 +255,10 @@ int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, 
     if (n_chunks == 1)
       work();
     else
-      pool.emplace_back(work);
+      pool.emplace_back([work, c, &spread]() {
+        spread.place((unsigned)c);   // the creator only waits: chunk 0 may have its CPU
+        work();
+      });
   }
   for (auto& t : pool) t.join();
   return R3D_OK;
@@ -330,6 +335,7 @@ static int write_ply_colour(const char* path, const void* h_xyz, int dtype, cons
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 1;
     const int64_t slab = (int64_t)4 << 20;
+    const r3d_host::Spread spread;
     for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
       const int64_t cnt = std::min(slab, n_points - s0);
       const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 65536));
@@ -346,7 +352,10 @@ static int write_ply_colour(const char* path, const void* h_xyz, int dtype, cons
         if (n_chunks == 1)
           work();
         else
-          pool.emplace_back(work);
+          pool.emplace_back([work, c, &spread]() {
+            spread.place((unsigned)c);
+            work();
+          });
       }
       for (auto& t : pool) t.join();
       for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
@@ -425,6 +434,7 @@ static void txt_chunks(const void* h_xyz, int dtype, int64_t s0, int64_t cnt, co
   if (hw == 0) hw = 1;
   const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 32768));
   chunks->assign((size_t)n_chunks, std::string());
+  const r3d_host::Spread spread;
   std::vector<std::thread> pool;
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
@@ -437,7 +447,10 @@ static void txt_chunks(const void* h_xyz, int dtype, int64_t s0, int64_t cnt, co
     if (n_chunks == 1)
       work();
     else
-      pool.emplace_back(work);
+      pool.emplace_back([work, c, &spread]() {
+        spread.place((unsigned)c);   // the creator only waits: chunk 0 may have its CPU
+        work();
+      });
   }
   for (auto& t : pool) t.join();
 }
@@ -699,6 +712,7 @@ int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double
       spans.push_back(sp);
       lo = hi;
     }
+    const r3d_host::Spread spread;
     auto count = [](ParseSpan* sp) {
       const char* p = sp->lo;
       while (p < sp->hi) {
@@ -711,7 +725,11 @@ int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double
     };
     {
       std::vector<std::thread> pool;
-      for (size_t t = 1; t < spans.size(); ++t) pool.emplace_back(count, &spans[t]);
+      for (size_t t = 1; t < spans.size(); ++t)
+        pool.emplace_back([&, t]() {
+          spread.place((unsigned)t);
+          count(&spans[t]);
+        });
       count(&spans[0]);
       for (auto& th : pool) th.join();
     }
@@ -733,7 +751,10 @@ int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double
     {
       std::vector<std::thread> pool;
       for (size_t t = 1; t < spans.size(); ++t)
-        pool.emplace_back([&, t]() { bad[t] = parse_span(spans[t], (char)separator, h_xyz_out + 3 * row0[t]); });
+        pool.emplace_back([&, t]() {
+          spread.place((unsigned)t);
+          bad[t] = parse_span(spans[t], (char)separator, h_xyz_out + 3 * row0[t]);
+        });
       bad[0] = parse_span(spans[0], (char)separator, h_xyz_out);
       for (auto& th : pool) th.join();
     }

@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 
+#include "r3d_hostpool.h"
 #include "r3d_internal.h"
 
 namespace {
@@ -22,13 +23,17 @@ void parallel_memcpy(void* dst, const void* src, size_t bytes, unsigned n_thread
     memcpy(dst, src, bytes);
     return;
   }
+  const r3d_host::Spread spread;
   std::vector<std::thread> pool;
   const size_t per = ((bytes / n_threads) + 4095) & ~(size_t)4095;
   for (unsigned t = 0; t < n_threads; ++t) {
     const size_t lo = (size_t)t * per;
     if (lo >= bytes) break;
     const size_t n = std::min(per, bytes - lo);
-    pool.emplace_back([=]() { memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, n); });
+    pool.emplace_back([=, &spread]() {
+      spread.place(t);   // the creator only waits
+      memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, n);
+    });
   }
   for (auto& th : pool) th.join();
 }

@@ -1,8 +1,14 @@
 // Host thread pool shared by the file decoders (r3d_png.cpp, r3d_jpeg.cpp): n files, one task each, first failure wins.
 #pragma once
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -13,6 +19,89 @@ void r3d_set_error(const char* fmt, ...);
 
 namespace r3d_host {
 
+// Where a pool's workers START.  A thread is born on its creator's CPU and the kernel's load balancer moves it later --
+// on some guests much later: on the build container of this repo (8 vCPUs, Linux 6.18) eight fresh threads of 15 ms of pure
+// arithmetic each ran one after the other on ONE CPU (117 ms; 16 ms once placed), so every short pool of this library --
+// file decoders, staging copies, text formatters -- ran serially.  place(t), called by worker t first thing, moves it to the
+// t-th CPU of the creator's affinity mask, counted from the creator's own CPU, by narrowing the thread's mask to that CPU
+// and restoring the full mask at once: a placement, not a pin -- the balancer stays free to move it.  The creator keeps its
+// CPU (it is worker 0 where it works too).  R3D_HOST_SPREAD=0 turns the hint off.
+struct Spread {
+  cpu_set_t allowed;
+  int cpus[CPU_SETSIZE];
+  int n = 0, home = 0;
+  Spread() {
+    const char* e = getenv("R3D_HOST_SPREAD");
+    if (e && e[0] == '0') return;
+    CPU_ZERO(&allowed);
+    if (pthread_getaffinity_np(pthread_self(), sizeof(allowed), &allowed) != 0) return;
+    const int here = sched_getcpu();
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &allowed)) {
+        if (c == here) home = n;
+        cpus[n++] = c;
+      }
+  }
+  void place(unsigned t) const {
+    if (n < 2) return;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpus[(home + t) % (unsigned)n], &one);
+    if (pthread_setaffinity_np(pthread_self(), sizeof(one), &one) == 0) pthread_setaffinity_np(pthread_self(), sizeof(allowed), &allowed);
+  }
+};
+
+// Scratch memory of the decoders (file bytes, inflated rows, component planes), recycled across frames AND batches.  A frame
+// needs a few buffers of 0.5 ... 6 MB; as fresh std::vectors each is an mmap, a run of first-touch page faults and a munmap
+// -- per frame and thread, all of them through the process's one address-space lock.  With recycled buffers a worker touches
+// fresh pages once per process, not once per frame.  Vectors keep their capacity; users clear() / resize() them as if they
+// were new.  At most kKeep scratches of at most kKeepBytes each are held.
+struct Scratch {
+  std::vector<unsigned char> buf[6];
+  size_t capacity() const {
+    size_t c = 0;
+    for (const auto& b : buf) c += b.capacity();
+    return c;
+  }
+};
+constexpr size_t kKeep = 64, kKeepBytes = (size_t)256 << 20;
+inline std::mutex g_scratch_mutex;
+inline std::vector<std::unique_ptr<Scratch>> g_scratch_free;
+inline thread_local Scratch* t_scratch = nullptr;
+
+// The calling thread holds a scratch for the lifetime of the outermost ScratchScope on its stack.
+struct ScratchScope {
+  bool own = false;
+  ScratchScope() {
+    if (t_scratch) return;
+    {
+      std::lock_guard<std::mutex> lock(g_scratch_mutex);
+      if (!g_scratch_free.empty()) {
+        t_scratch = g_scratch_free.back().release();
+        g_scratch_free.pop_back();
+      }
+    }
+    if (!t_scratch) t_scratch = new Scratch;
+    own = true;
+  }
+  ~ScratchScope() {
+    if (!own) return;
+    std::unique_ptr<Scratch> s(t_scratch);
+    t_scratch = nullptr;
+    if (s->capacity() > kKeepBytes) return;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_free.size() < kKeep) g_scratch_free.push_back(std::move(s));
+  }
+  ScratchScope(const ScratchScope&) = delete;
+  ScratchScope& operator=(const ScratchScope&) = delete;
+};
+// buffer i of the calling thread's scratch, emptied (capacity kept); a ScratchScope must be alive
+inline std::vector<unsigned char>& scratch(int i) {
+  std::vector<unsigned char>& b = t_scratch->buf[i];
+  b.clear();
+  return b;
+}
+
 // runs decode_one(k) for k in [0, n) on a thread pool; first failure wins
 template <typename F>
 inline int run_batch(int n_files, const char* what, F&& decode_one) {
@@ -21,7 +110,10 @@ inline int run_batch(int n_files, const char* what, F&& decode_one) {
   std::atomic<int> next{0}, first_rc{R3D_OK};
   std::string first_msg;
   std::atomic<bool> have_msg{false};
-  auto worker = [&]() {
+  const Spread spread;
+  auto worker = [&](unsigned t) {
+    if (t) spread.place(t);
+    ScratchScope scope;   // one scratch per worker for the whole batch
     for (;;) {
       const int k = next.fetch_add(1);
       if (k >= n_files || first_rc.load() != R3D_OK) return;
@@ -38,8 +130,8 @@ inline int run_batch(int n_files, const char* what, F&& decode_one) {
     }
   };
   std::vector<std::thread> pool;
-  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
-  worker();
+  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+  worker(0);
   for (auto& t : pool) t.join();
   if (first_rc.load() != R3D_OK) {
     r3d_set_error("%s", have_msg.load() ? first_msg.c_str() : what);

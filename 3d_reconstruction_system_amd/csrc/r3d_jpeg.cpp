@@ -326,15 +326,24 @@ int read_file(const char* path, std::vector<unsigned char>* file, std::string* m
   return R3D_OK;
 }
 
-// out == NULL: header query
-int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, std::string* msg) {
-  std::vector<unsigned char> file;
+struct Planes {
+  int width = 0, height = 0, n_comp = 0, hmax = 1, vmax = 1;
+  int h[3] = {1, 1, 1}, v[3] = {1, 1, 1};
+  size_t stride[3] = {0, 0, 0};                 // samples per row of each decoded plane (whole blocks)
+  unsigned char* data[3] = {nullptr, nullptr, nullptr};   // in the calling thread's scratch (buffers 1..3)
+};
+
+// Checks the file, and (decode) entropy-decodes it and inverse-transforms the first `keep` components into planes of whole
+// blocks.  keep = 1: luma only.  header query: decode = false.
+int decode_components(const char* path, bool decode, int keep, Planes* P, std::string* msg) {
+  std::vector<unsigned char>& file = r3d_host::scratch(0);
   int rc = read_file(path, &file, msg);
   if (rc) return rc;
   Jpeg j;
   if ((rc = parse_headers(path, file, &j, msg))) return rc;
-  if (h_out) *h_out = j.height;
-  if (w_out) *w_out = j.width;
+  P->width = j.width;
+  P->height = j.height;
+  P->n_comp = j.n_comp;
   if (j.progressive) return fail(R3D_ERR_UNSUPPORTED, path, "progressive JPEG (only sequential Huffman files are decoded natively)", msg);
   if (j.precision != 8) return fail(R3D_ERR_UNSUPPORTED, path, "12-bit JPEG", msg);
   if (j.width < 1 || j.height < 1) return fail(R3D_ERR_UNSUPPORTED, path, "JPEG without its height in the frame header (DNL)", msg);
@@ -358,15 +367,24 @@ int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int
   for (int c = 0; c < j.n_comp; ++c)
     if (!j.have_quant[j.comp[c].tq] || !j.dc[j.comp[c].td].present || !j.ac[j.comp[c].ta].present)
       return fail(R3D_ERR_INVALID, path, "a table the scan needs is missing", msg);
-  if (!out) return R3D_OK;
-  const size_t need = (size_t)j.width * j.height;
-  if (cap_bytes < need) return fail(R3D_ERR_NOMEM, path, "output buffer too small", msg);
+  P->hmax = hmax;
+  P->vmax = vmax;
+  keep = std::min(keep, j.n_comp);
+  for (int c = 0; c < j.n_comp && c < 3; ++c) {
+    P->h[c] = j.comp[c].h;
+    P->v[c] = j.comp[c].v;
+  }
+  if (!decode) return R3D_OK;
   const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
   const int mcus_x = (j.width + mcu_w - 1) / mcu_w, mcus_y = (j.height + mcu_h - 1) / mcu_h;
-  const size_t plane_w = (size_t)mcus_x * mcu_w;
-  std::vector<unsigned char> rows(plane_w * mcu_h);   // one MCU row of luma at a time
-  uint16_t q_nat[64];
-  for (int k = 0; k < 64; ++k) q_nat[kNatural[k]] = j.quant[j.comp[0].tq][k];
+  uint16_t q_nat[3][64];
+  for (int c = 0; c < keep; ++c) {
+    P->stride[c] = (size_t)mcus_x * 8 * j.comp[c].h;
+    std::vector<unsigned char>& plane = r3d_host::scratch(1 + c);
+    plane.resize(P->stride[c] * (size_t)mcus_y * 8 * j.comp[c].v);
+    P->data[c] = plane.data();
+    for (int k = 0; k < 64; ++k) q_nat[c][kNatural[k]] = j.quant[j.comp[c].tq][k];
+  }
   Bits b{file.data() + j.scan_begin, file.data() + file.size()};
   int pred[4] = {0, 0, 0, 0};
   int until_restart = j.restart_interval, next_rst = 0;
@@ -396,14 +414,14 @@ int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int
       for (int c = 0; c < j.n_comp; ++c) {
         const Component& cp = j.comp[c];
         const Huff &hd = j.dc[cp.td], &ha = j.ac[cp.ta];
+        const bool kept = c < keep;
         for (int by = 0; by < cp.v; ++by)
           for (int bx = 0; bx < cp.h; ++bx) {
-            const bool keep = c == 0;
-            if (keep) memset(coef, 0, sizeof(coef));
+            if (kept) memset(coef, 0, sizeof(coef));
             int s = decode_symbol(b, hd);
             if (s < 0 || s > 15) return fail(R3D_ERR_INVALID, path, "corrupt entropy-coded data", msg);
             if (s) pred[c] = (int)((unsigned)pred[c] + (unsigned)extend(b.get(s), s));   // (hostile data may wrap, never overflow)
-            if (keep) coef[0] = (int16_t)pred[c];
+            if (kept) coef[0] = (int16_t)pred[c];
             for (int k = 1; k < 64; ++k) {
               const int rs = decode_symbol(b, ha);
               if (rs < 0) return fail(R3D_ERR_INVALID, path, "corrupt entropy-coded data", msg);
@@ -417,21 +435,157 @@ int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int
               k += r;
               if (k > 63) return fail(R3D_ERR_INVALID, path, "corrupt entropy-coded data", msg);
               const int v = extend(b.get(s), s);
-              if (keep) coef[kNatural[k]] = (int16_t)v;
+              if (kept) coef[kNatural[k]] = (int16_t)v;
             }
-            if (keep) idct_islow(coef, q_nat, rows.data() + (size_t)by * 8 * plane_w + (size_t)mx * mcu_w + (size_t)bx * 8, plane_w);
+            if (kept)
+              idct_islow(coef, q_nat[c],
+                         P->data[c] + ((size_t)my * cp.v + by) * 8 * P->stride[c] + ((size_t)mx * cp.h + bx) * 8, P->stride[c]);
           }
       }
     }
-    const int y0 = my * mcu_h, ny = std::min(mcu_h, j.height - y0);
-    for (int y = 0; y < ny; ++y) memcpy(out + (size_t)(y0 + y) * j.width, rows.data() + (size_t)y * plane_w, (size_t)j.width);
   }
   return R3D_OK;
 }
 
-int decode_gray(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, std::string* msg) {
+// out == NULL: header query
+int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, std::string* msg) {
+  r3d_host::ScratchScope scope;
+  Planes P;
+  const int rc = decode_components(path, out != nullptr, 1, &P, msg);
+  if (h_out) *h_out = P.height;
+  if (w_out) *w_out = P.width;
+  if (rc || !out) return rc;
+  if (cap_bytes < (size_t)P.width * P.height) return fail(R3D_ERR_NOMEM, path, "output buffer too small", msg);
+  for (int y = 0; y < P.height; ++y) memcpy(out + (size_t)y * P.width, P.data[0] + (size_t)y * P.stride[0], (size_t)P.width);
+  return R3D_OK;
+}
+
+// ---- colour: what PIL's Image.open(path) (the reference's genply_noRGB, pixel_to_camera.py:58-60) gets from libjpeg --------
+// libjpeg's default colour decode: every component through the islow IDCT, chroma brought to full resolution by "fancy"
+// (triangle-filter) upsampling (jdsample.c: h2v1 / h2v2; plain replication when a chroma row has fewer than three samples),
+// then YCbCr -> RGB with 16-bit fixed-point tables (jdcolor.c).
+inline unsigned char clamp255(int v) { return (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// one chroma row pair -> one full-resolution row.  near / far: the chroma rows this output row lies between (the nearer one
+// weighs 3, the other 1; the same row twice when the component is not subsampled vertically); dw real samples per row.
+// (h1v2 -- 4:4:0 -- is refused by the caller.)
+void upsample_row(const unsigned char* near_, const unsigned char* far_, int dw, bool h2, bool v2, bool fancy, unsigned char* out, int out_w,
+                  unsigned char* tmp /* 2 dw bytes */) {
+  if (!h2 && !v2) {
+    memcpy(out, near_, (size_t)out_w);
+    return;
+  }
+  if (!fancy) {   // replication
+    for (int x = 0; x < out_w; ++x) out[x] = near_[h2 ? x >> 1 : x];
+    return;
+  }
+  if (h2 && !v2) {   // h2v1_fancy_upsample
+    int o = 0;
+    int invalue = near_[0];
+    tmp[o++] = (unsigned char)invalue;
+    tmp[o++] = (unsigned char)((invalue * 3 + near_[1] + 2) >> 2);
+    for (int x = 1; x < dw - 1; ++x) {
+      invalue = near_[x] * 3;
+      tmp[o++] = (unsigned char)((invalue + near_[x - 1] + 1) >> 2);
+      tmp[o++] = (unsigned char)((invalue + near_[x + 1] + 2) >> 2);
+    }
+    invalue = near_[dw - 1];
+    tmp[o++] = (unsigned char)((invalue * 3 + near_[dw - 2] + 1) >> 2);
+    tmp[o++] = (unsigned char)invalue;
+    memcpy(out, tmp, (size_t)out_w);
+    return;
+  }
+  // h2v2_fancy_upsample
+  int o = 0;
+  int thiscolsum = near_[0] * 3 + far_[0], nextcolsum = near_[1] * 3 + far_[1], lastcolsum;
+  tmp[o++] = (unsigned char)((thiscolsum * 4 + 8) >> 4);
+  tmp[o++] = (unsigned char)((thiscolsum * 3 + nextcolsum + 7) >> 4);
+  lastcolsum = thiscolsum;
+  thiscolsum = nextcolsum;
+  for (int x = 1; x < dw - 1; ++x) {
+    nextcolsum = near_[x + 1] * 3 + far_[x + 1];
+    tmp[o++] = (unsigned char)((thiscolsum * 3 + lastcolsum + 8) >> 4);
+    tmp[o++] = (unsigned char)((thiscolsum * 3 + nextcolsum + 7) >> 4);
+    lastcolsum = thiscolsum;
+    thiscolsum = nextcolsum;
+  }
+  tmp[o++] = (unsigned char)((thiscolsum * 3 + lastcolsum + 8) >> 4);
+  tmp[o++] = (unsigned char)((thiscolsum * 4 + 7) >> 4);
+  memcpy(out, tmp, (size_t)out_w);
+}
+
+int g_cr_r[256], g_cb_b[256], g_cr_g[256], g_cb_g[256];   // jdcolor.c build_ycc_rgb_table
+struct YccInit {
+  YccInit() {
+    for (int i = 0; i < 256; ++i) {
+      const int x = i - 128;
+      g_cr_r[i] = (int)((91881LL * x + 32768) >> 16);     // FIX(1.40200)
+      g_cb_b[i] = (int)((116130LL * x + 32768) >> 16);    // FIX(1.77200)
+      g_cr_g[i] = (int)(-46802LL * x);                    // FIX(0.71414)
+      g_cb_g[i] = (int)(-22554LL * x + 32768);            // FIX(0.34414), + ONE_HALF
+    }
+  }
+} g_ycc_init;
+
+// out == NULL: header query.  R,G,B bytes, [H][W][3].
+int decode_rgb_impl(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, int* comps_out, std::string* msg) {
+  r3d_host::ScratchScope scope;
+  Planes P;
+  const int rc = decode_components(path, out != nullptr, 3, &P, msg);
+  if (h_out) *h_out = P.height;
+  if (w_out) *w_out = P.width;
+  if (comps_out) *comps_out = P.n_comp;
+  if (rc) return rc;
+  if (P.n_comp == 3) {
+    if (P.h[1] != P.h[2] || P.v[1] != P.v[2] || !((P.hmax == P.h[1] || P.hmax == 2 * P.h[1]) && (P.vmax == P.v[1] || P.vmax == 2 * P.v[1])) ||
+        (P.hmax == P.h[1] && P.vmax == 2 * P.v[1]))
+      return fail(R3D_ERR_UNSUPPORTED, path, "a chroma layout other than 4:4:4, 4:2:2 or 4:2:0", msg);
+  }
+  if (!out) return R3D_OK;
+  const size_t W = (size_t)P.width, H = (size_t)P.height;
+  if (cap_bytes < W * H * 3) return fail(R3D_ERR_NOMEM, path, "output buffer too small", msg);
+  if (P.n_comp == 1) {
+    for (size_t y = 0; y < H; ++y) {
+      const unsigned char* src = P.data[0] + y * P.stride[0];
+      unsigned char* o = out + y * W * 3;
+      for (size_t x = 0; x < W; ++x) o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = src[x];
+    }
+    return R3D_OK;
+  }
+  const bool h2 = P.hmax == 2 * P.h[1], v2 = P.vmax == 2 * P.v[1];
+  const int dw = h2 ? (P.width + 1) / 2 : P.width, dh = v2 ? (P.height + 1) / 2 : P.height;   // real chroma samples
+  const bool fancy = dw > 2;   // jinit_upsampler: fancy upsampling needs more than two samples in a row
+  std::vector<unsigned char> cb(W + 2), cr(W + 2), tmp((size_t)2 * dw + 2);
+  for (size_t y = 0; y < H; ++y) {
+    // chroma rows this output row lies between: row y/2 and its neighbour above (even y) or below (odd y), edges replicated
+    const int cy = v2 ? (int)(y >> 1) : (int)y;
+    int other = cy;
+    if (v2) {
+      other = (y & 1) ? cy + 1 : cy - 1;
+      if (other < 0) other = 0;
+      if (other > dh - 1) other = dh - 1;
+    }
+    for (int c = 1; c <= 2; ++c) {
+      const unsigned char* near_ = P.data[c] + (size_t)cy * P.stride[c];
+      const unsigned char* far_ = P.data[c] + (size_t)other * P.stride[c];
+      upsample_row(near_, far_, dw, h2, v2, fancy, c == 1 ? cb.data() : cr.data(), (int)W, tmp.data());
+    }
+    const unsigned char* yrow = P.data[0] + y * P.stride[0];
+    unsigned char* o = out + y * W * 3;
+    for (size_t x = 0; x < W; ++x) {
+      const int yy = yrow[x], b_ = cb[x], r_ = cr[x];
+      o[3 * x] = clamp255(yy + g_cr_r[r_]);
+      o[3 * x + 1] = clamp255(yy + ((g_cb_g[b_] + g_cr_g[r_]) >> 16));
+      o[3 * x + 2] = clamp255(yy + g_cb_b[b_]);
+    }
+  }
+  return R3D_OK;
+}
+
+template <typename F>
+int guarded(const char* path, std::string* msg, F&& f) {
   try {
-    return decode_gray_impl(path, out, cap_bytes, h_out, w_out, msg);
+    return f();
   } catch (const std::exception& e) {
     try {
       *msg = std::string("'") + path + "': " + e.what();
@@ -439,6 +593,13 @@ int decode_gray(const char* path, unsigned char* out, size_t cap_bytes, int* h_o
     }
     return R3D_ERR_NOMEM;
   }
+}
+
+int decode_gray(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, std::string* msg) {
+  return guarded(path, msg, [&] { return decode_gray_impl(path, out, cap_bytes, h_out, w_out, msg); });
+}
+int decode_rgb(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, int* comps_out, std::string* msg) {
+  return guarded(path, msg, [&] { return decode_rgb_impl(path, out, cap_bytes, h_out, w_out, comps_out, msg); });
 }
 
 }  // namespace
@@ -465,6 +626,35 @@ int r3d_jpeg_gray_decode_batch(const char* const* paths, int n_files, unsigned c
   return r3d_host::run_batch(n_files, "JPEG decode failed", [&](int k, std::string* msg) -> int {
     int h = 0, w = 0;
     int rc = paths[k] ? decode_gray(paths[k], h_out + frame_bytes * k, frame_bytes, &h, &w, msg) : R3D_ERR_INVALID;
+    if (rc == R3D_OK && (h != height || w != width)) {
+      rc = R3D_ERR_INVALID;
+      *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + ", the batch expects " +
+             std::to_string(width) + "x" + std::to_string(height);
+    }
+    return rc;
+  });
+}
+
+int r3d_jpeg_rgb_info(const char* path, int* height, int* width, int* components) {
+  if (!path) {
+    r3d_set_error("r3d_jpeg_rgb_info: path is NULL");
+    return R3D_ERR_INVALID;
+  }
+  std::string msg;
+  const int rc = decode_rgb(path, nullptr, 0, height, width, components, &msg);
+  if (rc) r3d_set_error("%s", msg.c_str());
+  return rc;
+}
+
+int r3d_jpeg_rgb_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width) {
+  if (n_files < 0 || (n_files > 0 && (!paths || !h_out)) || height <= 0 || width <= 0) {
+    r3d_set_error("r3d_jpeg_rgb_decode_batch: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  const size_t frame_bytes = (size_t)height * width * 3;
+  return r3d_host::run_batch(n_files, "JPEG decode failed", [&](int k, std::string* msg) -> int {
+    int h = 0, w = 0, nc = 0;
+    int rc = paths[k] ? decode_rgb(paths[k], h_out + frame_bytes * k, frame_bytes, &h, &w, &nc, msg) : R3D_ERR_INVALID;
     if (rc == R3D_OK && (h != height || w != width)) {
       rc = R3D_ERR_INVALID;
       *msg = std::string("'") + paths[k] + "' is " + std::to_string(w) + "x" + std::to_string(h) + ", the batch expects " +

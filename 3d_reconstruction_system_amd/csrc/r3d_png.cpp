@@ -40,7 +40,7 @@ int read_png(const char* path, PngInfo* info, std::vector<unsigned char>* idat, 
     *msg = std::string("cannot open '") + path + "'";
     return R3D_ERR_INVALID;
   }
-  std::vector<unsigned char> file;
+  std::vector<unsigned char>& file = r3d_host::scratch(0);
   {
     unsigned char buf[1 << 16];
     size_t n;
@@ -92,7 +92,8 @@ inline int paeth(int a, int b, int c) {
 // depths -> R3D_ERR_UNSUPPORTED.  header_only: stop after IHDR checks.
 int decode_png(const char* path, bool header_only, PngInfo* info, int* channels_out, std::vector<unsigned char>* pixels,
                std::string* msg) {
-  std::vector<unsigned char> idat;
+  r3d_host::ScratchScope scope;
+  std::vector<unsigned char>& idat = r3d_host::scratch(1);
   int rc = read_png(path, info, &idat, msg);
   if (rc) return rc;
   if (info->width == 0 || info->height == 0 || info->width > (1u << 20) || info->height > (1u << 20)) {
@@ -114,7 +115,8 @@ int decode_png(const char* path, bool header_only, PngInfo* info, int* channels_
   *channels_out = channels;
   if (header_only) return R3D_OK;
   const size_t bpp = (size_t)channels * info->bit_depth / 8, stride = (size_t)info->width * bpp;
-  std::vector<unsigned char> raw((stride + 1) * info->height);
+  std::vector<unsigned char>& raw = r3d_host::scratch(2);
+  raw.resize((stride + 1) * info->height);
   uLongf raw_len = (uLongf)raw.size();
   const int z = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
   if (z != Z_OK || raw_len != raw.size()) {
@@ -152,7 +154,8 @@ int decode_png(const char* path, bool header_only, PngInfo* info, int* channels_
 int decode_gray_impl(const char* path, void* out, size_t cap_bytes, int* h_out, int* w_out, int* bits_out, std::string* msg) {
   PngInfo info;
   int channels = 0;
-  std::vector<unsigned char> px;
+  r3d_host::ScratchScope scope;
+  std::vector<unsigned char>& px = r3d_host::scratch(3);
   // one pass over the file: the pixels are decoded only when there is somewhere to put them and the file is grey
   int rc = decode_png(path, out == nullptr, &info, &channels, &px, msg);
   if (h_out) *h_out = (int)info.height;
@@ -239,7 +242,8 @@ int gamma_refusal(const char* path, std::string* msg) {
 int decode_gray8_impl(const char* path, unsigned char* out, size_t cap_bytes, int rule, int* h_out, int* w_out, std::string* msg) {
   PngInfo info;
   int channels = 0;
-  std::vector<unsigned char> px;
+  r3d_host::ScratchScope scope;
+  std::vector<unsigned char>& px = r3d_host::scratch(3);
   int rc = decode_png(path, out == nullptr, &info, &channels, &px, msg);
   if (h_out) *h_out = (int)info.height;
   if (w_out) *w_out = (int)info.width;
@@ -293,7 +297,8 @@ int decode_rgb(const char* path, unsigned char* out, size_t cap_bytes, int* h_ou
   try {
     PngInfo info;
     int channels = 0;
-    std::vector<unsigned char> px;
+    r3d_host::ScratchScope scope;
+  std::vector<unsigned char>& px = r3d_host::scratch(3);
     int rc = decode_png(path, out == nullptr, &info, &channels, &px, msg);
     if (h_out) *h_out = (int)info.height;
     if (w_out) *w_out = (int)info.width;

@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include "r3d_hostpool.h"
 #include "r3d_internal.h"
 #include "r3d_voxel_dev.h"
 
@@ -705,8 +706,10 @@ void build_parallel(const uint64_t* codes, int64_t n, std::string* body, int64_t
   const unsigned n_workers = std::max(1u, std::min(hw == 0 ? 1u : hw, 32u));
   std::vector<std::thread> pool;
   std::atomic<size_t> next{0};
+  const r3d_host::Spread spread;
   for (unsigned w = 0; w < n_workers; ++w)
-    pool.emplace_back([&]() {
+    pool.emplace_back([&, w]() {
+      spread.place(w);
       for (;;) {
         const size_t i = next.fetch_add(1);
         if (i >= pieces.size()) return;

@@ -457,6 +457,14 @@ int r3d_jpeg_gray_decode_batch(const char* const* paths, int n_files, unsigned c
  * buffer, which is what r3d_fuse_frames_rgb takes.  *channels = samples per pixel in the file. */
 int r3d_png_rgb_info(const char* path, int* height, int* width, int* channels);
 int r3d_png_rgb_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width);
+/* The same for JPEG colour files (AirSim's scene images, airsim/main.cpp:1369-1392): the bytes PIL / libjpeg(-turbo) give by
+ * default -- every component through the islow IDCT, chroma to full resolution by libjpeg's "fancy" triangle upsampling
+ * (jdsample.c h2v1 / h2v2; replication when a chroma row has fewer than three samples), YCbCr -> RGB through jdcolor.c's
+ * 16-bit fixed-point tables; a grey JPEG is replicated.  Pinned byte for byte against PIL over sizes, qualities and
+ * 4:4:4 / 4:2:2 / 4:2:0.  Same refusals as the grey reader, plus any other chroma layout: R3D_ERR_UNSUPPORTED (the Python
+ * host then lets PIL decode, which IS the reference's reader for colour).  *components = 1 or 3. */
+int r3d_jpeg_rgb_info(const char* path, int* height, int* width, int* components);
+int r3d_jpeg_rgb_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width);
 
 /* ---- f2: occupied-voxel set + OctoMap binary export.  Replaces the per-point tree.updateNode(xyz, True) loop,
  * updateInnerOccupancy() and writeBinary() of octomap/txt_transfer_octomap.py:16-36 and

@@ -181,6 +181,10 @@ int main(int argc, char** argv) {
     std::vector<unsigned char> y((size_t)h2 * w2);
     const char* one2[1] = {argv[a]};
     if (r3d_jpeg_gray_decode_batch(one2, 1, y.data(), h2, w2) != R3D_OK) return 31;
+    int h3 = 0, w3 = 0, c3 = 0;
+    if (r3d_jpeg_rgb_info(argv[a], &h3, &w3, &c3) != R3D_OK || h3 != h2 || w3 != w2) return 33;
+    std::vector<unsigned char> rgb((size_t)h2 * w2 * 3);
+    if (r3d_jpeg_rgb_decode_batch(one2, 1, rgb.data(), h2, w2) != R3D_OK) return 34;
     FILE* f2 = fopen(argv[a], "rb");
     if (!f2) return 32;
     std::vector<unsigned char> jpg;
@@ -202,6 +206,11 @@ int main(int argc, char** argv) {
       if (r3d_jpeg_gray_info(p[0], &hh, &ww) == R3D_OK && hh > 0 && ww > 0 && (int64_t)hh * ww <= (int64_t)1 << 22) {
         std::vector<unsigned char> yy((size_t)hh * ww);
         jpeg_decoded += r3d_jpeg_gray_decode_batch(p, 1, yy.data(), hh, ww) == R3D_OK;
+      }
+      int cc = 0;
+      if (r3d_jpeg_rgb_info(p[0], &hh, &ww, &cc) == R3D_OK && hh > 0 && ww > 0 && (int64_t)hh * ww <= (int64_t)1 << 22) {
+        std::vector<unsigned char> cc3((size_t)hh * ww * 3);
+        jpeg_decoded += r3d_jpeg_rgb_decode_batch(p, 1, cc3.data(), hh, ww) == R3D_OK;
       }
     }
   }

@@ -618,3 +618,68 @@ def test_native_jpeg_refuses_what_it_does_not_restate(R, tmp_path):
     assert lib.r3d_jpeg_gray_decode_batch(arr, 1, out.ctypes.data, 40, 56) in (L.OK, L.ERR_INVALID)
     arr = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "ok.jpg")))
     assert lib.r3d_jpeg_gray_decode_batch(arr, 1, out.ctypes.data, 41, 56) == L.ERR_INVALID      # another size than the batch's
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (2, 3), (4, 6), (8, 8), (17, 33), (61, 83), (144, 256), (480, 640), (1080, 1920)])
+def test_native_jpeg_colour_equals_pil_byte_for_byte(R, tmp_path, hw):
+    """The colour planes of the RGBD path: the reference opens them with PIL (p2c:58-60), AirSim writes them as JPG.  The native
+    decoder (islow IDCT on every component, libjpeg's fancy chroma upsampling, jdcolor's fixed-point YCbCr->RGB) gives PIL's
+    bytes: sizes that are not multiples of the MCU (and ones whose chroma rows hold one or two samples: replication instead of the
+    triangle filter), qualities, 4:4:4 / 4:2:2 / 4:2:0, grey files, restart intervals; batches through read_rgb_batch."""
+    from PIL import Image
+    H, W = hw
+    rng = np.random.default_rng(H * 11 + W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (np.stack([128 + 100 * np.sin(xx / 7.0 + yy / 5.0), 128 + 90 * np.cos(xx / 3.0), 100 + yy % 97], 2)
+           + rng.normal(0, 25, (H, W, 3))).clip(0, 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    big = H * W > 500_000
+    variants = [dict(quality=q, subsampling=sub) for q in ((85,) if big else (10, 85, 100)) for sub in (0, 1, 2)]
+    variants += [dict(quality=90, optimize=True, subsampling=2), dict(quality=85, restart_marker_blocks=5, subsampling=1),
+                 dict(quality=85, restart_marker_rows=1, subsampling=2)]
+    paths = []
+    for k, kw in enumerate(variants):
+        p = str(tmp_path / ("v%d.jpg" % k))
+        try:
+            Image.fromarray(noise if k % 4 == 3 else img, "RGB").save(p, **kw)
+        except (TypeError, ValueError, OSError):          # an older Pillow without the restart options / tiny optimised files
+            continue
+        paths.append(p)
+    p = str(tmp_path / "g.jpg")
+    Image.fromarray(img[..., 0], "L").save(p, quality=80)
+    paths.append(p)
+    assert len(paths) >= 4
+    got = R.cloud_io.read_rgb_batch(paths)
+    assert got.shape == (len(paths), H, W, 3) and got.dtype == np.uint8
+    for k, p in enumerate(paths):
+        np.testing.assert_array_equal(got[k], np.asarray(Image.open(p).convert("RGB")), err_msg=p)
+
+
+def test_native_jpeg_colour_refusals_fall_back_to_pil(R, tmp_path):
+    """What the native colour decoder does not restate goes to PIL -- for colour that IS the reference's reader, so the bytes
+    are the reference's either way; a corrupt or missing file is an error, not a fallback."""
+    from PIL import Image
+    import ctypes as C
+    L = importlib.import_module(R.__name__ + "._lib")
+    lib = R.load_library()
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    Image.fromarray(img, "RGB").save(tmp_path / "p.jpg", progressive=True)
+    h, w, c = C.c_int(), C.c_int(), C.c_int()
+    assert lib.r3d_jpeg_rgb_info(os.fsencode(str(tmp_path / "p.jpg")), C.byref(h), C.byref(w), C.byref(c)) == L.ERR_UNSUPPORTED
+    assert (h.value, w.value, c.value) == (24, 40, 3)
+    got = R.cloud_io.read_rgb_batch([str(tmp_path / "p.jpg")])
+    np.testing.assert_array_equal(got[0], np.asarray(Image.open(tmp_path / "p.jpg").convert("RGB")))
+    # a sequential first file and a progressive second one: the batch decoder refuses, PIL takes the list
+    Image.fromarray(img, "RGB").save(tmp_path / "s.jpg")
+    got = R.cloud_io.read_rgb_batch([str(tmp_path / "s.jpg"), str(tmp_path / "p.jpg")])
+    for k, n in enumerate(("s.jpg", "p.jpg")):
+        np.testing.assert_array_equal(got[k], np.asarray(Image.open(tmp_path / n).convert("RGB")))
+    (tmp_path / "t.jpg").write_bytes(b"\xff\xd8\xff\xe0\x00\x10JFIF")
+    assert lib.r3d_jpeg_rgb_info(os.fsencode(str(tmp_path / "t.jpg")), C.byref(h), C.byref(w), C.byref(c)) == L.ERR_INVALID
+    with pytest.raises(R.R3DError):
+        R.cloud_io.read_rgb_batch([str(tmp_path / "t.jpg")])
+    out = np.empty((1, 25, 40, 3), np.uint8)
+    arr = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "s.jpg")))
+    assert lib.r3d_jpeg_rgb_decode_batch(arr, 1, out.ctypes.data, 25, 40) == L.ERR_INVALID       # another size than the batch's
+    assert lib.r3d_jpeg_rgb_decode_batch(None, 1, out.ctypes.data, 25, 40) == L.ERR_INVALID

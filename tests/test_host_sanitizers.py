@@ -30,8 +30,11 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path, golden_dir):
     Image.fromarray(smooth, "RGB").save(tmp_path / "s420.jpg", quality=85, subsampling=2)
     Image.fromarray(smooth, "RGB").save(tmp_path / "s444.jpg", quality=95, subsampling=0, optimize=True)
     Image.fromarray(smooth[..., 0], "L").save(tmp_path / "grey.jpg", quality=60)
+    Image.fromarray(smooth, "RGB").save(tmp_path / "s422.jpg", quality=70, subsampling=1)
+    Image.fromarray(smooth[:3, :4], "RGB").save(tmp_path / "tiny.jpg", quality=70, subsampling=2)
     run = subprocess.run([exe, os.path.join(golden_dir, "scene3", "depth", "000.png"), str(tmp_path / "c.png"),
-                          str(tmp_path / "a.png"), str(tmp_path / "s420.jpg"), str(tmp_path / "s444.jpg"), str(tmp_path / "grey.jpg")],
+                          str(tmp_path / "a.png"), str(tmp_path / "s420.jpg"), str(tmp_path / "s444.jpg"), str(tmp_path / "grey.jpg"),
+                          str(tmp_path / "s422.jpg"), str(tmp_path / "tiny.jpg")],
                          capture_output=True, text=True,
                          timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
