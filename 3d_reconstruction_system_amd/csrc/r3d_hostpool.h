@@ -19,20 +19,22 @@ void r3d_set_error(const char* fmt, ...);
 
 namespace r3d_host {
 
-// Where a pool's workers START.  A thread is born on its creator's CPU and the kernel's load balancer moves it later --
-// on some guests much later: on the build container of this repo (8 vCPUs, Linux 6.18) eight fresh threads of 15 ms of pure
-// arithmetic each ran one after the other on ONE CPU (117 ms; 16 ms once placed), so every short pool of this library --
-// file decoders, staging copies, text formatters -- ran serially.  place(t), called by worker t first thing, moves it to the
-// t-th CPU of the creator's affinity mask, counted from the creator's own CPU, by narrowing the thread's mask to that CPU
-// and restoring the full mask at once: a placement, not a pin -- the balancer stays free to move it.  The creator keeps its
-// CPU (it is worker 0 where it works too).  R3D_HOST_SPREAD=0 turns the hint off.
+// Where a pool's workers START -- an OPT-IN hint (R3D_HOST_SPREAD=1).  A thread is born on its creator's CPU and the kernel's
+// load balancer moves it later -- on some guests much later: on the build container of this repo (8 vCPUs, Linux 6.18) eight
+// fresh threads of 15 ms of pure arithmetic each ran one after the other on ONE CPU (117 ms; 16 ms once placed), so every
+// short pool of this library -- file decoders, staging copies, text formatters -- ran serially (8 x 1080p JPEG: 120 ms, 21 ms
+// with the hint).  place(t), called by worker t first thing, moves it to the t-th CPU of the creator's affinity mask, counted
+// from the creator's own CPU, by narrowing the thread's mask to that CPU and restoring the full mask at once: a placement,
+// not a pin.  Off by default because a host whose balancer works loses by it: on the MI355X box (256 CPUs allowed, a quota of
+// 16) concurrent pools land on the same CPUs -- the drop-in's 100-frame run took 1.40-1.67 s with the hint, 1.25-1.27 s
+// without, the PLY formatter 73-137 ms vs 61-65 ms, the decoders the same either way (tools/host_spread_ab.py).
 struct Spread {
   cpu_set_t allowed;
   int cpus[CPU_SETSIZE];
   int n = 0, home = 0;
   Spread() {
     const char* e = getenv("R3D_HOST_SPREAD");
-    if (e && e[0] == '0') return;
+    if (!e || e[0] != '1') return;
     CPU_ZERO(&allowed);
     if (pthread_getaffinity_np(pthread_self(), sizeof(allowed), &allowed) != 0) return;
     const int here = sched_getcpu();
