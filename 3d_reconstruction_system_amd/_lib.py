@@ -117,6 +117,7 @@ SIGNATURES = {
     "r3d_write_ply_rgb": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),
     "r3d_write_ply_rgba": (_i, [C.c_char_p, _vp, _i, _vp, _i64]),
     "r3d_write_xyz_txt": (_i, [C.c_char_p, _vp, _i, _i64, _vp, _i, _i]),
+    "r3d_write_xyz_txt_batch": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i]),
     "r3d_format_xyz_txt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _sz, _psz]),
     "r3d_png_gray_info": (_i, [C.c_char_p, _pi, _pi, _pi]),
     "r3d_png_gray_decode_batch": (_i, [_vp, _i, _vp, _i, _i, _i]),

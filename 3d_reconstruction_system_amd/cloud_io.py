@@ -242,6 +242,23 @@ def write_xyz_txt(path, xyz, z_raw=None, append=False):
                                        zp, zc, 1 if append else 0))
 
 
+def write_xyz_txt_batch(paths, xyz, z_raw=None):
+    """One `X,Y,Z\\n` file per frame: file k takes rows [k*P, (k+1)*P) of xyz ([F*P,3]; P = rows / len(paths)) -- the
+    ./point/<stem>.txt files of the frame loop (c2w:163-165), written by the library's host threads, one file per thread at a
+    time.  Same bytes as write_xyz_txt per file."""
+    paths = [os.fspath(p) for p in paths]
+    xyz = _cloud(xyz)
+    if not paths:
+        if xyz.shape[0]:
+            raise ValueError("points but no files to put them in")
+        return
+    if xyz.shape[0] % len(paths):
+        raise ValueError("%d points do not divide into %d files" % (xyz.shape[0], len(paths)))
+    keep, zp, zc = _z_raw_args(xyz, z_raw)
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    L.check(L.load().r3d_write_xyz_txt_batch(arr, len(paths), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0] // len(paths), zp, zc))
+
+
 def _z_raw_args(xyz, z_raw):
     if z_raw is None:
         return None, None, 0

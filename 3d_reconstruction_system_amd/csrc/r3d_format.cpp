@@ -15,26 +15,71 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "r3d.h"
 #include "r3d_hostpool.h"
+#include "r3d_pow10_table.h"
 
 void r3d_set_error(const char* fmt, ...);
 
 namespace {
 
+// A chunk of formatted text.  Not a std::string: resize() would zero-fill the worst-case size (64-80 bytes per point, twice
+// what the text takes) and a fresh string per slab would map, fault in and unmap that memory every time; this one hands out
+// uninitialised room and keeps it for the next slab.
+struct TextBuf {
+  std::unique_ptr<char[]> mem;
+  size_t cap = 0, len = 0;
+  char* room(size_t n) {   // at least n bytes, contents undefined
+    if (n > cap) {
+      mem.reset(new char[n]);
+      cap = n;
+    }
+    len = 0;
+    return mem.get();
+  }
+  char* grow(size_t n, size_t used) {   // at least n bytes, the first `used` kept
+    if (n > cap) {
+      std::unique_ptr<char[]> bigger(new char[n]);
+      memcpy(bigger.get(), mem.get(), used);
+      mem = std::move(bigger);
+      cap = n;
+    }
+    return mem.get();
+  }
+  const char* data() const { return mem.get(); }
+  size_t size() const { return len; }
+};
+
+constexpr char kDigitPairs[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263"
+    "646566676869707172737475767778798081828384858687888990919293949596979899";
+
 inline char* put_uint(char* p, uint64_t v) {
+  if (v < 10) {
+    *p = (char)('0' + v);
+    return p + 1;
+  }
   char tmp[24];
-  int n = 0;
-  do {
-    tmp[n++] = (char)('0' + v % 10);
-    v /= 10;
-  } while (v);
-  while (n) *p++ = tmp[--n];
-  return p;
+  int n = 24;
+  while (v >= 100) {
+    const unsigned two = (unsigned)(v % 100);
+    v /= 100;
+    n -= 2;
+    memcpy(tmp + n, kDigitPairs + 2 * two, 2);
+  }
+  if (v >= 10) {
+    n -= 2;
+    memcpy(tmp + n, kDigitPairs + 2 * v, 2);
+  } else {
+    tmp[--n] = (char)('0' + v);
+  }
+  memcpy(p, tmp + n, 24 - n);
+  return p + (24 - n);
 }
 
 // writes "%.4f" of x at p, returns the new end
@@ -53,14 +98,22 @@ inline char* fmt4(char* p, double x) {
     }
     return p + snprintf(p, 400, "%.4f", x);
   }
-  uint64_t scaled;  // round_half_even(ax * 10^4), exact
-  if (ax == 0.0) {
+  uint64_t scaled;  // round_half_even(ax * 10^4) of the EXACT product, which is what printf's "%.4f" prints
+  // Fast way: t = fl(ax * 10^4) is within half an ulp of the product; when t is further from a rounding boundary (.5) than
+  // that -- delta = t * 2^-52 is twice the bound -- the product rounds the way t does.  Large t (no fraction bits left) and
+  // real ties fail the test and take the exact way below.
+  const double t = ax * 10000.0;
+  const double r = (t + 0x1p52) - 0x1p52;   // t to the nearest integer, ties to even, for t < 2^51 (default rounding mode)
+  if (t < 0x1p51 && std::fabs(t - r) < 0.5 - t * 0x1p-52) {
+    scaled = (uint64_t)r;
+  } else if (ax == 0.0) {
     scaled = 0;
   } else {
-    int e;
-    const double fr = std::frexp(ax, &e);              // ax = fr * 2^e, fr in [0.5,1)
-    const uint64_t m = (uint64_t)std::ldexp(fr, 53);   // 53-bit integer mantissa, exact
-    e -= 53;                                           // ax = m * 2^e
+    uint64_t bits;
+    memcpy(&bits, &ax, 8);
+    const int biased = (int)(bits >> 52);
+    const uint64_t m = biased ? ((bits & 0xfffffffffffffull) | (1ull << 52)) : (bits & 0xfffffffffffffull);   // ax = m * 2^e
+    const int e = (biased ? biased : 1) - 1075;
     const unsigned __int128 prod = (unsigned __int128)m * 10000u;
     if (e >= 0) {
       scaled = (uint64_t)(prod << e);  // ax < 2^40 keeps this below 2^54
@@ -89,16 +142,14 @@ inline char* fmt4(char* p, double x) {
 }
 
 template <typename T>
-void format_rows(const T* xyz, int64_t lo, int64_t hi, std::string* out) {
+void format_rows(const T* xyz, int64_t lo, int64_t hi, TextBuf* out) {
   // worst case per value below 2^40: sign + 13 digits + '.' + 4 = 19; plus separators
-  out->resize((size_t)(hi - lo) * 64 + 1300);
-  char* base = &(*out)[0];
+  char* base = out->room((size_t)(hi - lo) * 64 + 1300);
   char* p = base;
   for (int64_t i = lo; i < hi; ++i) {
-    if ((size_t)(p - base) + 1300 > out->size()) {  // only after snprintf-path giants
+    if ((size_t)(p - base) + 1300 > out->cap) {  // only after snprintf-path giants
       const size_t used = p - base;
-      out->resize(out->size() * 2 + 1300);
-      base = &(*out)[0];
+      base = out->grow(out->cap * 2 + 1300, used);
       p = base + used;
     }
     p = fmt4(p, (double)xyz[i * 3 + 0]);
@@ -109,7 +160,84 @@ void format_rows(const T* xyz, int64_t lo, int64_t hi, std::string* out) {
     *p++ = ' ';
     *p++ = '\n';
   }
-  out->resize(p - base);
+  out->len = p - base;
+}
+
+// exactly eight digits of v < 10^8, leading zeros included
+inline void put_8_digits(char* p, uint32_t v) {
+  const uint32_t hi = v / 10000, lo = v % 10000;
+  memcpy(p, kDigitPairs + 2 * (hi / 100), 2);
+  memcpy(p + 2, kDigitPairs + 2 * (hi % 100), 2);
+  memcpy(p + 4, kDigitPairs + 2 * (lo / 100), 2);
+  memcpy(p + 6, kDigitPairs + 2 * (lo % 100), 2);
+}
+
+// decimal digits of v, 1 <= v < 10^17
+inline int count_digits(uint64_t v) {
+  static constexpr uint64_t kPow10[18] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull,
+                                          1000000000ull, 10000000000ull, 100000000000ull, 1000000000000ull, 10000000000000ull,
+                                          100000000000000ull, 1000000000000000ull, 10000000000000000ull, 100000000000000000ull};
+  const int t = ((64 - __builtin_clzll(v | 1)) * 1233) >> 12;   // floor(log10 v) or one more
+  return t + (v >= kPow10[t] ? 1 : 0);
+}
+
+// ---- shortest decimal that reads back as the same double --------------------------------------------------------------
+// What repr(float) prints (CPython: David Gay's dtoa mode 0) is the shortest digit string in the double's rounding interval,
+// the closest to the double among those of that length.  Computed here by the Schubfach algorithm (R. Giulietti, "The
+// Schubfach way to render doubles", 2020; also behind Java's Double.toString since JDK 19): pick k with 10^k <= 2^q <
+// 10^(k+1) so that the interval holds one or two multiples of 10^k, and decide with three 64 x 128-bit products against
+// g = ceil(10^-k 2^...) (r3d_pow10_table.h; round-to-odd keeps every comparison with the even candidates exact).  One
+// integer routine, ~4x cheaper than std::to_chars + re-parsing its text (80 -> 20 ns per number on the build host).
+// Pinned against Python's repr and std::to_chars: tests/test_host_logic.py (every table entry recomputed from its definition,
+// the exponent formulas for every q, boundary doubles, random bit patterns) and tests/c/host_fuzz.cpp.
+struct ShortestDecimal {
+  uint64_t digits;   // value = digits * 10^exp10
+  int exp10;
+};
+
+inline uint64_t round_to_odd(r3d_pow10::U128 g, uint64_t cp) {
+  // bits 128..191 of the 192-bit product g * cp, with bit 0 set when anything non-zero lies below (g is rounded UP by less
+  // than one unit, the product by less than cp < 2^64: a low word of 0 or 1 is an exact integer)
+  const unsigned __int128 x = (unsigned __int128)cp * g.lo;
+  const unsigned __int128 y = (unsigned __int128)cp * g.hi + (uint64_t)(x >> 64);
+  const uint64_t y0 = (uint64_t)y, y1 = (uint64_t)(y >> 64);
+  return y1 | (uint64_t)(y0 > 1);
+}
+
+inline int floor_log10_pow2(int e) { return (e * 1262611) >> 22; }                      // floor(e log10 2), |e| <= 1500
+inline int floor_log10_three_quarters_pow2(int e) { return (e * 1262611 - 524031) >> 22; }   // floor(log10(3/4 2^e))
+inline int floor_log2_pow10(int e) { return (e * 1741647) >> 19; }                      // floor(e log2 10), |e| <= 1233
+
+inline ShortestDecimal shortest_decimal(uint64_t significand, int biased_exponent) {
+  uint64_t c;
+  int q;
+  if (biased_exponent != 0) {
+    c = (1ull << 52) | significand;
+    q = biased_exponent - 1075;
+    if (0 <= -q && -q < 53 && (c & ((1ull << -q) - 1)) == 0) return {c >> -q, 0};   // an integer below 2^53: its own digits
+  } else {
+    c = significand;
+    q = -1074;
+  }
+  const bool even = (c & 1) == 0;                                      // the interval's ends round to c only for even c
+  const bool lower_is_closer = significand == 0 && biased_exponent > 1;   // a power of two: the gap below is half the gap above
+  const uint64_t cbl = 4 * c - 2 + (lower_is_closer ? 1 : 0), cb = 4 * c, cbr = 4 * c + 2;   // the interval and c in quarter units
+  const int k = lower_is_closer ? floor_log10_three_quarters_pow2(q) : floor_log10_pow2(q);
+  const int h = q + floor_log2_pow10(-k) + 1;
+  const r3d_pow10::U128 g = r3d_pow10::kG[-k - r3d_pow10::kMin];
+  const uint64_t vbl = round_to_odd(g, cbl << h), vb = round_to_odd(g, cb << h), vbr = round_to_odd(g, cbr << h);   // 4 x / 10^k
+  const uint64_t lower = vbl + (even ? 0 : 1), upper = vbr - (even ? 0 : 1);
+  const uint64_t s = vb / 4;
+  if (s >= 10) {   // a multiple of 10^(k+1) inside the interval is one digit shorter
+    const uint64_t sp = s / 10;
+    const bool up_inside = lower <= 40 * sp, wp_inside = 40 * sp + 40 <= upper;
+    if (up_inside != wp_inside) return {sp + (wp_inside ? 1 : 0), k + 1};
+  }
+  const bool u_inside = lower <= 4 * s, w_inside = 4 * s + 4 <= upper;
+  if (u_inside != w_inside) return {s + (w_inside ? 1 : 0), k};
+  const uint64_t mid = 4 * s + 2;   // both inside: the closer one, the even one on a tie
+  const bool round_up = vb > mid || (vb == mid && (s & 1) != 0);
+  return {s + (round_up ? 1 : 0), k};
 }
 
 // Python's repr(float) ("short" float_repr_style): shortest round-trip digits; fixed notation when
@@ -132,29 +260,32 @@ inline char* fmt_repr(char* p, double x) {
     memcpy(p, "0.0", 3);
     return p + 3;
   }
-  char sci[40];
-  const auto res = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);
-  // sci = d[.ddd]e[+-]XX
-  char digits[24];
-  int nd = 0;
-  const char* c = sci;
-  for (; c < res.ptr && *c != 'e'; ++c)
-    if (*c != '.') digits[nd++] = *c;
-  int e10 = 0;
-  {
-    ++c;  // 'e'
-    const bool eneg = (*c == '-');
-    ++c;
-    for (; c < res.ptr; ++c) e10 = e10 * 10 + (*c - '0');
-    if (eneg) e10 = -e10;
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  ShortestDecimal d = shortest_decimal(bits & 0xfffffffffffffull, (int)(bits >> 52) & 0x7ff);
+  while (d.digits % 10 == 0) {   // the algorithm stops at the shortest LENGTH; zeros at its end belong to the exponent
+    d.digits /= 10;
+    ++d.exp10;
   }
-  const int decpt = e10 + 1;
+  // the digits, 17 places zero-padded, then the start moved past the padding: no loop over the digits, no length-dependent
+  // copy (every copy below is a fixed 24 bytes -- it runs past the number's end into space the next number overwrites; the
+  // callers leave 64 bytes of slack behind the last one)
+  char pad[48];
+  const uint64_t top = d.digits / 100000000u;
+  put_8_digits(pad + 9, (uint32_t)(d.digits % 100000000u));
+  put_8_digits(pad + 1, (uint32_t)(top % 100000000u));
+  pad[0] = (char)('0' + top / 100000000u);
+  const int nd = count_digits(d.digits);
+  const char* digits = pad + 17 - nd;
+  const int decpt = d.exp10 + nd;
   if (decpt <= -4 || decpt > 16) {
-    *p++ = digits[0];
+    p[0] = digits[0];
     if (nd > 1) {
-      *p++ = '.';
-      memcpy(p, digits + 1, nd - 1);
-      p += nd - 1;
+      p[1] = '.';
+      memcpy(p + 2, digits + 1, 24);
+      p += nd + 1;
+    } else {
+      ++p;
     }
     *p++ = 'e';
     int e = decpt - 1;
@@ -164,31 +295,26 @@ inline char* fmt_repr(char* p, double x) {
     return put_uint(p, (uint64_t)e);
   }
   if (decpt <= 0) {
-    *p++ = '0';
-    *p++ = '.';
-    for (int k = 0; k < -decpt; ++k) *p++ = '0';
-    memcpy(p, digits, nd);
-    return p + nd;
+    memcpy(p, "0.000", 5);
+    memcpy(p + 2 - decpt, digits, 24);
+    return p + 2 - decpt + nd;
   }
   if (decpt >= nd) {
-    memcpy(p, digits, nd);
-    p += nd;
-    for (int k = 0; k < decpt - nd; ++k) *p++ = '0';
-    *p++ = '.';
-    *p++ = '0';
-    return p;
+    memcpy(p, digits, 24);
+    memcpy(p + nd, "0000000000000000", 16);
+    p[decpt] = '.';
+    p[decpt + 1] = '0';
+    return p + decpt + 2;
   }
-  memcpy(p, digits, decpt);
-  p += decpt;
-  *p++ = '.';
-  memcpy(p, digits + decpt, nd - decpt);
-  return p + (nd - decpt);
+  memcpy(p, digits, 24);
+  memcpy(p + decpt + 1, digits + decpt, 24);
+  p[decpt] = '.';
+  return p + nd + 1;
 }
 
 template <typename T>
-void txt_rows(const T* xyz, const void* z_raw, int z_dtype, int64_t lo, int64_t hi, std::string* out) {
-  out->resize((size_t)(hi - lo) * 80 + 16);  // 3 x (sign + 17 digits + point + e-308) + 2 commas + newline < 80
-  char* base = &(*out)[0];
+void txt_rows(const T* xyz, const void* z_raw, int z_dtype, int64_t lo, int64_t hi, TextBuf* out) {
+  char* base = out->room((size_t)(hi - lo) * 80 + 64);  // 3 x (sign + 17 digits + point + e-308) + 2 commas + newline < 80; fmt_repr's slack
   char* p = base;
   for (int64_t i = lo; i < hi; ++i) {
     p = fmt_repr(p, (double)xyz[i * 3 + 0]);
@@ -202,19 +328,17 @@ void txt_rows(const T* xyz, const void* z_raw, int z_dtype, int64_t lo, int64_t 
       p = fmt_repr(p, (double)xyz[i * 3 + 2]);
     *p++ = '\n';
   }
-  out->resize(p - base);
+  out->len = p - base;
 }
 
 template <typename T>
-void format_rows_rgb(const T* xyz, const unsigned char* rgb, int stride, int64_t lo, int64_t hi, std::string* out) {
-  out->resize((size_t)(hi - lo) * 80 + 1300);
-  char* base = &(*out)[0];
+void format_rows_rgb(const T* xyz, const unsigned char* rgb, int stride, int64_t lo, int64_t hi, TextBuf* out) {
+  char* base = out->room((size_t)(hi - lo) * 80 + 1300);
   char* p = base;
   for (int64_t i = lo; i < hi; ++i) {
-    if ((size_t)(p - base) + 1300 > out->size()) {
+    if ((size_t)(p - base) + 1300 > out->cap) {
       const size_t used = p - base;
-      out->resize(out->size() * 2 + 1300);
-      base = &(*out)[0];
+      base = out->grow(out->cap * 2 + 1300, used);
       p = base + used;
     }
     for (int a = 0; a < 3; ++a) {
@@ -228,20 +352,20 @@ void format_rows_rgb(const T* xyz, const unsigned char* rgb, int stride, int64_t
     *p++ = '0';
     *p++ = '\n';
   }
-  out->resize(p - base);
+  out->len = p - base;
 }
 
-int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, std::vector<std::string>* chunks) {
+int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, std::vector<TextBuf>* chunks) {
   char head[256];
   snprintf(head, sizeof(head),
            "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
            "    property float z\n    end_header\n    ",
            (long long)n);
   *header = head;
-  unsigned hw = std::thread::hardware_concurrency();
+  unsigned hw = r3d_host::cpu_budget();
   if (hw == 0) hw = 1;
   int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
-  chunks->assign((size_t)n_chunks, std::string());
+  chunks->resize((size_t)n_chunks);   // buffers of earlier slabs are kept and reused
   const r3d_host::Spread spread;
   std::vector<std::thread> pool;
   for (int64_t c = 0; c < n_chunks; ++c) {
@@ -275,7 +399,7 @@ int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, 
     return R3D_ERR_INVALID;
   }
   std::string header;
-  std::vector<std::string> chunks;
+  std::vector<TextBuf> chunks;
   try {
     format_chunks(h_xyz, dtype, n_points, &header, &chunks);
   } catch (const std::bad_alloc&) {
@@ -332,14 +456,15 @@ static int write_ply_colour(const char* path, const void* h_xyz, int dtype, cons
              "    property uchar alpha\n    end_header\n    ",
              (long long)n_points);
     ok = fwrite(head, 1, strlen(head), f) == strlen(head);
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = r3d_host::cpu_budget();
     if (hw == 0) hw = 1;
     const int64_t slab = (int64_t)4 << 20;
     const r3d_host::Spread spread;
+    std::vector<TextBuf> chunks;
     for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
       const int64_t cnt = std::min(slab, n_points - s0);
       const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 65536));
-      std::vector<std::string> chunks((size_t)n_chunks);
+      chunks.resize((size_t)n_chunks);
       std::vector<std::thread> pool;
       for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
@@ -387,7 +512,7 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
   // format and write in slabs of 8 M points so the text never needs more than ~0.5 GB of host memory
   const int64_t slab = (int64_t)8 << 20;
   std::string header;
-  std::vector<std::string> buf[2];
+  std::vector<TextBuf> buf[2];
   std::thread writer;  // outside the try: it must be joined on every way out
   bool wrote_ok = true;
   bool ok = true;
@@ -406,7 +531,7 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
       format_chunks(static_cast<const char*>(h_xyz) + (size_t)lo * 3 * esz, dtype, cnt, &header, &buf[cur]);
       if (writer.joinable()) writer.join();  // the other buffer is free again once its slab is on disk
       ok = ok && wrote_ok;
-      const std::vector<std::string>* src = &buf[cur];
+      const std::vector<TextBuf>* src = &buf[cur];
       writer = std::thread([src, f, &wrote_ok]() {
         for (const auto& c : *src) wrote_ok = wrote_ok && fwrite(c.data(), 1, c.size(), f) == c.size();
       });
@@ -429,11 +554,11 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
 }
 
 static void txt_chunks(const void* h_xyz, int dtype, int64_t s0, int64_t cnt, const void* h_z_raw, int z_raw_dtype,
-                       std::vector<std::string>* chunks) {
-  unsigned hw = std::thread::hardware_concurrency();
+                       std::vector<TextBuf>* chunks) {
+  unsigned hw = r3d_host::cpu_budget();
   if (hw == 0) hw = 1;
   const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 32768));
-  chunks->assign((size_t)n_chunks, std::string());
+  chunks->resize((size_t)n_chunks);   // buffers of earlier slabs are kept and reused
   const r3d_host::Spread spread;
   std::vector<std::thread> pool;
   for (int64_t c = 0; c < n_chunks; ++c) {
@@ -462,7 +587,7 @@ int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const voi
     r3d_set_error("r3d_format_xyz_txt: bad argument");
     return R3D_ERR_INVALID;
   }
-  std::vector<std::string> chunks;
+  std::vector<TextBuf> chunks;
   try {
     txt_chunks(h_xyz, dtype, 0, n_points, h_z_raw, z_raw_dtype, &chunks);
   } catch (const std::bad_alloc&) {
@@ -500,7 +625,7 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
   bool ok = true;
   try {
     const int64_t slab = (int64_t)4 << 20;
-    std::vector<std::string> chunks;
+    std::vector<TextBuf> chunks;
     for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
       txt_chunks(h_xyz, dtype, s0, std::min(slab, n_points - s0), h_z_raw, z_raw_dtype, &chunks);
       for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
@@ -516,6 +641,70 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
     return R3D_ERR_INVALID;
   }
   return R3D_OK;
+}
+
+// One txt file per frame (the ./point/<stem>.txt of camera_to_world.py:80-81, one per pose line): file k holds points
+// [k * points_per_file, (k + 1) * points_per_file).  The files are the unit of parallelism -- cpu_budget() workers, each
+// formatting whole files block by block into one buffer of its own and writing them -- instead of one pool of threads per
+// file.  Same bytes as n_files calls of r3d_write_xyz_txt.
+int r3d_write_xyz_txt_batch(const char* const* paths, int n_files, const void* h_xyz, int dtype, int64_t points_per_file,
+                            const void* h_z_raw, int z_raw_dtype) {
+  if (n_files < 0 || points_per_file < 0 || (n_files > 0 && !paths) || (n_files > 0 && points_per_file > 0 && !h_xyz) ||
+      (dtype != R3D_F32 && dtype != R3D_F64) || (h_z_raw && z_raw_dtype != R3D_DEPTH_U8 && z_raw_dtype != R3D_DEPTH_U16)) {
+    r3d_set_error("r3d_write_xyz_txt_batch: bad argument");
+    return R3D_ERR_INVALID;
+  }
+  for (int k = 0; k < n_files; ++k)
+    if (!paths[k]) {
+      r3d_set_error("r3d_write_xyz_txt_batch: path %d is NULL", k);
+      return R3D_ERR_INVALID;
+    }
+  const unsigned budget = r3d_host::cpu_budget();
+  if ((unsigned)n_files * 2 <= budget) {   // few files: the threads go inside each file
+    for (int k = 0; k < n_files; ++k) {
+      const size_t esz = dtype == R3D_F32 ? 4 : 8, zsz = z_raw_dtype == R3D_DEPTH_U16 ? 2 : 1;
+      const int rc = r3d_write_xyz_txt(paths[k], static_cast<const char*>(h_xyz) + (size_t)k * points_per_file * 3 * esz, dtype, points_per_file,
+                                       h_z_raw ? static_cast<const char*>(h_z_raw) + (size_t)k * points_per_file * zsz : nullptr, z_raw_dtype, 0);
+      if (rc) return rc;
+    }
+    return R3D_OK;
+  }
+  try {
+    return r3d_host::run_batch(n_files, "txt write failed", [&](int k, std::string* msg) -> int {
+      thread_local TextBuf text;   // one per worker thread; gone with the thread
+      FILE* f = fopen(paths[k], "wb");
+      if (!f) {
+        *msg = std::string("r3d_write_xyz_txt_batch: cannot open '") + paths[k] + "' for writing";
+        return R3D_ERR_INVALID;
+      }
+      setvbuf(f, nullptr, _IONBF, 0);   // every fwrite below is a whole block
+      bool ok = true;
+      const int64_t lo = (int64_t)k * points_per_file, hi = lo + points_per_file, block = 65536;
+      try {
+        for (int64_t b = lo; ok && b < hi; b += block) {
+          const int64_t e = std::min(hi, b + block);
+          if (dtype == R3D_F32)
+            txt_rows(static_cast<const float*>(h_xyz), h_z_raw, z_raw_dtype, b, e, &text);
+          else
+            txt_rows(static_cast<const double*>(h_xyz), h_z_raw, z_raw_dtype, b, e, &text);
+          ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+        }
+      } catch (const std::bad_alloc&) {
+        fclose(f);
+        *msg = "r3d_write_xyz_txt_batch: out of host memory";
+        return R3D_ERR_NOMEM;
+      }
+      if (fclose(f) != 0) ok = false;
+      if (!ok) {
+        *msg = std::string("r3d_write_xyz_txt_batch: short write to '") + paths[k] + "'";
+        return R3D_ERR_INVALID;
+      }
+      return R3D_OK;
+    });
+  } catch (const std::exception&) {   // no thread to be had
+    r3d_set_error("r3d_write_xyz_txt_batch: out of host memory");
+    return R3D_ERR_NOMEM;
+  }
 }
 
 // ---- the way back: "x,y,z[,...]\n" lines (camera / world txt; read by get_pointdata c2w:92-98 and local_world
@@ -692,7 +881,7 @@ int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double
   if (bad_line_out) *bad_line_out = 0;
   if (n_bytes == 0) return R3D_OK;
   try {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = r3d_host::cpu_budget();
     unsigned n_threads = std::max(1u, std::min(hw == 0 ? 1u : hw, 16u));
     if (n_bytes < ((size_t)1 << 20)) n_threads = 1;
     // spans end just after a newline

@@ -71,7 +71,7 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
   R3D_REQUIRE(n_in >= 1 && n_in <= r3d_ctx::kPipeBufs && n_out >= 1 && n_out <= r3d_ctx::kPipeBufs,
               "host pipeline takes 1..%d arrays per direction", r3d_ctx::kPipeBufs);
   int rc;
-  unsigned n_threads = std::thread::hardware_concurrency();
+  unsigned n_threads = r3d_host::cpu_budget();
   n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
   bool in_pinned[r3d_ctx::kPipeBufs], out_pinned[r3d_ctx::kPipeBufs];
   size_t big = 0;
@@ -176,7 +176,7 @@ int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t b
     return R3D_OK;
   }
   int rc;
-  unsigned n_threads = std::thread::hardware_concurrency();
+  unsigned n_threads = r3d_host::cpu_budget();
   n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
   const size_t chunk = (size_t)32 << 20;
   void* pin[2] = {};

@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -18,6 +20,41 @@
 void r3d_set_error(const char* fmt, ...);
 
 namespace r3d_host {
+
+// How many threads a pool may usefully run: the CPUs this process is ALLOWED, not the ones the machine has --
+// hardware_concurrency() capped by the affinity mask and by the cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us).  The MI355X
+// box shows 256 CPUs and grants 16: pools sized by the first number started 128 formatter threads per slab (and 15 per txt
+// file, four files at a time) for the work 16 can do -- measured the same speed within noise either way (PLY 306-315 ms with 16
+// threads, 314-327 with 128), so the smaller number is the one to create.  R3D_HOST_THREADS overrides.  Read once.
+inline unsigned cpu_budget() {
+  static const unsigned budget = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (pthread_getaffinity_np(pthread_self(), sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+      fclose(g);
+      if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(h, "%lld", &period) != 1) period = 0;
+        fclose(h);
+      }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    if (const char* e = getenv("R3D_HOST_THREADS")) {
+      const int v = atoi(e);
+      if (v > 0) n = (unsigned)std::min(v, 1024);
+    }
+    return n;
+  }();
+  return budget;
+}
 
 // Where a pool's workers START -- an OPT-IN hint (R3D_HOST_SPREAD=1).  A thread is born on its creator's CPU and the kernel's
 // load balancer moves it later -- on some guests much later: on the build container of this repo (8 vCPUs, Linux 6.18) eight
@@ -107,8 +144,7 @@ inline std::vector<unsigned char>& scratch(int i) {
 // runs decode_one(k) for k in [0, n) on a thread pool; first failure wins
 template <typename F>
 inline int run_batch(int n_files, const char* what, F&& decode_one) {
-  unsigned hw = std::thread::hardware_concurrency();
-  const unsigned n_threads = std::max(1u, std::min<unsigned>(hw == 0 ? 1 : hw, std::min(32, n_files)));
+  const unsigned n_threads = std::max(1u, std::min<unsigned>(cpu_budget(), std::min(32, n_files)));
   std::atomic<int> next{0}, first_rc{R3D_OK};
   std::string first_msg;
   std::atomic<bool> have_msg{false};

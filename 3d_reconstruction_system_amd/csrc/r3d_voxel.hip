@@ -702,7 +702,7 @@ void build_parallel(const uint64_t* codes, int64_t n, std::string* body, int64_t
     for (int k = n_inner - 1; k >= 0; --k) stack.push_back({inner[k][0], inner[k][1], f.depth + 1});  // DFS order
   }
   if (!top.body.empty()) pieces.push_back({false, 0, 0, std::move(top.body), 0});
-  unsigned hw = std::thread::hardware_concurrency();
+  unsigned hw = r3d_host::cpu_budget();
   const unsigned n_workers = std::max(1u, std::min(hw == 0 ? 1u : hw, 32u));
   std::vector<std::thread> pool;
   std::atomic<size_t> next{0};

@@ -10,6 +10,7 @@ Environment (all optional; the defaults are the reference's hard-coded values):
                                 `transfer_T_icp.py --estimate-rigid --colmap ...` writes): every pose translation is multiplied
                                 by it -- COLMAP's unit brought to the depth maps' unit (readme.md:25).  Default 1 = the reference.
   WORLD_SIZE RANK LOCAL_RANK    set by a one-process-per-GPU launcher (torch.distributed.run ...): frames are sharded
+  R3D_TIMING=1                  stage times on stderr (stamp() below)
 """
 import importlib
 import os
@@ -17,6 +18,21 @@ import sys
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ROOT = os.path.dirname(_PKG_DIR)
+
+
+_t_last = None
+
+
+def stamp(label):
+    """R3D_TIMING=1: milliseconds since the previous stamp, on stderr."""
+    global _t_last
+    if os.environ.get("R3D_TIMING", "0") in ("", "0"):
+        return
+    import time
+    now = time.perf_counter()
+    if _t_last is not None:
+        sys.stderr.write("[r3d timing] %8.1f ms  %s\n" % ((now - _t_last) * 1e3, label))
+    _t_last = now
 
 
 def package():

@@ -115,27 +115,26 @@ def genply(gtxyz, pc_file, lenth_point):
 def fuse_pose_file(qt_path, depth_dir='./depth/', out_dtype=np.float64):
     """Parse the pose file, load every depth raster and fuse all frames in one launch.
     Returns (names, depths [F,H,W], world [F*H*W,3])."""
+    _common.stamp(None)
     names, quats, ts = r3d.read_pose_file(qt_path)
     if not names:
         return names, np.empty((0, 0, 0), np.uint8), np.empty((0, 3), out_dtype)
     depths = r3d.cloud_io.read_depth_batch([os.path.join(depth_dir, n) for n in names])
+    _common.stamp("pose file + %d depth files decoded" % len(names))
     ts = ts * _common.pose_scale()               # 1 unless R3D_POSE_SCALE says otherwise (COLMAP unit -> depth unit)
-    world = r3d.fuse_frames(depths, quats, ts, intrinsics=_common.intrinsics(), out_dtype=out_dtype,
-                            ctx=_common.context())
+    ctx = _common.context()
+    _common.stamp("GPU context")
+    world = r3d.fuse_frames(depths, quats, ts, intrinsics=_common.intrinsics(), out_dtype=out_dtype, ctx=ctx)
+    _common.stamp("fused launch, world cloud in host memory")
     return names, depths, world
 
 
 def _write_camera_txts(names, cam, depths, per):
-    """./point/<stem>.txt for every frame: a few files at a time (the native formatter releases the GIL; one 491,520-point
-    frame keeps ~7 of its threads busy, so four in flight fill the host without oversubscribing it)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """./point/<stem>.txt for every frame, one native call: the files are spread over the host threads (one whole file per
+    thread at a time)."""
     integral = depths.dtype in (np.uint8, np.uint16)
-
-    def one(k):
-        r3d.cloud_io.write_xyz_txt('./point/' + names[k][0:-4] + '.txt', cam[k * per:(k + 1) * per],
-                                   z_raw=depths[k] if integral else None)
-    with ThreadPoolExecutor(max_workers=4) as pool:
-        list(pool.map(one, range(len(names))))
+    r3d.cloud_io.write_xyz_txt_batch(['./point/' + n[0:-4] + '.txt' for n in names], cam[:len(names) * per],
+                                     z_raw=depths[:len(names)] if integral else None)
 
 
 def _get_file_name_sharded(qt_path):
@@ -148,6 +147,7 @@ def _get_file_name_sharded(qt_path):
     names, lo, hi, depths, world = D.fuse_pose_file_sharded(qt_path, './depth/', _common.intrinsics(), np.float64, ctx, comm,
                                                             pose_scale=_common.pose_scale())
     n_frames = len(names)
+    ply_done = _ply_in_background(world, './ply/small_035_p8.ply') if comm.rank == 0 else None
     try:        # a rank that fails while writing its files must still meet the others at the barrier, then raise
         if n_frames and not _common.skip_intermediate():
             if hi > lo:
@@ -161,10 +161,31 @@ def _get_file_name_sharded(qt_path):
         if comm.rank == 0:
             print('##################')
             print("%d frames cost ." % n_frames, t2 - t1)
-            genply(world, './ply/small_035_p8.ply', world.shape[0])
     finally:
-        comm.barrier()                         # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
-        comm.close()
+        try:
+            if ply_done is not None:
+                ply_done()
+        finally:
+            comm.barrier()                         # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
+            comm.close()
+
+
+def _ply_in_background(world, pc_file):
+    """genply's file, written by a helper thread while the caller goes on (the native writer releases the GIL): the fused
+    PLY is one file and its writer one thread -- 1.3 GB in 0.3 s on the MI355X box's host, with the formatter threads half
+    idle -- so it runs beside the per-frame txt files instead of after them.  Returns a function that waits for it, re-raises
+    what it raised and prints genply's line."""
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+    job = pool.submit(r3d.cloud_io.write_ply, pc_file, world)
+
+    def wait():
+        try:
+            job.result()
+        finally:
+            pool.shutdown()
+        print("Write into .ply file Done.")
+    return wait
 
 
 def get_file_name(qt_path):
@@ -174,16 +195,23 @@ def get_file_name(qt_path):
     t1 = time.time()
     names, depths, world = fuse_pose_file(qt_path)
     n_frames = len(names)
-    if n_frames and not _common.skip_intermediate():
-        per = depths.shape[1] * depths.shape[2]
-        cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=_common.context())
-        _write_camera_txts(names, cam, depths, per)   # the per-frame camera txt the reference leaves in ./point/
-        # the reference reopens this file with 'w' for every frame: it ends up holding the last one
-        r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
-    t2 = time.time()
-    print('##################')
-    print("%d frames cost ." % n_frames, t2 - t1)
-    genply(world, './ply/small_035_p8.ply', world.shape[0])
+    ply_done = _ply_in_background(world, './ply/small_035_p8.ply')      # the same bytes genply(world, ...) writes
+    try:
+        if n_frames and not _common.skip_intermediate():
+            per = depths.shape[1] * depths.shape[2]
+            cam = r3d.unproject(depths, intrinsics=_common.intrinsics(), out_dtype=np.float64, ctx=_common.context())
+            _common.stamp("camera clouds in host memory")
+            _write_camera_txts(names, cam, depths, per)   # the per-frame camera txt the reference leaves in ./point/
+            _common.stamp("%d camera txt files (PLY being written beside them)" % n_frames)
+            # the reference reopens this file with 'w' for every frame: it ends up holding the last one
+            r3d.cloud_io.write_xyz_txt('./point_world/small_worldpoint_5_23_5.txt', world[(n_frames - 1) * per:])
+            _common.stamp("world txt")
+        t2 = time.time()
+        print('##################')
+        print("%d frames cost ." % n_frames, t2 - t1)
+    finally:
+        ply_done()
+        _common.stamp("rest of the PLY")
 
 
 def main():

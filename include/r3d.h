@@ -410,6 +410,11 @@ int r3d_write_ply_rgba(const char* path, const void* h_xyz, int dtype, const uin
  * z_raw_dtype is R3D_DEPTH_U8 or R3D_DEPTH_U16.  append: 0 truncates ('w'), 1 appends ('a'). */
 int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw,
                       int z_raw_dtype, int append);
+/* One such file per frame -- the ./point/<stem>.txt that camera_to_world.py:163-165 leaves for every pose line: file k takes
+ * points [k * points_per_file, (k + 1) * points_per_file) of h_xyz (and of h_z_raw).  Files are spread over the host threads
+ * the process may use; same bytes as n_files calls of r3d_write_xyz_txt(..., append = 0). */
+int r3d_write_xyz_txt_batch(const char* const* paths, int n_files, const void* h_xyz, int dtype, int64_t points_per_file,
+                            const void* h_z_raw, int z_raw_dtype);
 /* The same text into a caller buffer; two-call protocol like r3d_format_ply. */
 int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
                        char* h_buf, size_t buf_cap, size_t* n_bytes_out);

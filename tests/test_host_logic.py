@@ -683,3 +683,130 @@ def test_native_jpeg_colour_refusals_fall_back_to_pil(R, tmp_path):
     arr = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "s.jpg")))
     assert lib.r3d_jpeg_rgb_decode_batch(arr, 1, out.ctypes.data, 25, 40) == L.ERR_INVALID       # another size than the batch's
     assert lib.r3d_jpeg_rgb_decode_batch(None, 1, out.ctypes.data, 25, 40) == L.ERR_INVALID
+
+
+@pytest.mark.parametrize("n_files", [1, 3, 40])
+def test_txt_batch_writer_equals_one_call_per_file(R, tmp_path, n_files):
+    """The per-frame camera txts of the frame loop (c2w:163-165) in one native call: same bytes as one write_xyz_txt per
+    file -- with the integer third column of the camera txt and without, f32 and f64, few files (threads inside each file)
+    and many (one file per thread at a time), values that take every branch of the repr() formatter."""
+    rng = np.random.default_rng(n_files)
+    per = 70_001 if n_files <= 3 else 1_013                # more than one 65536-point block per file / many small files
+    xyz = rng.normal(0, 50, (n_files * per, 3))
+    xyz[::97] *= 1e-7
+    xyz[5::89] *= 1e18
+    xyz[3::211, 0] = 0.0
+    xyz[7::223, 1] = -0.0
+    xyz[11::227, 2] = np.inf
+    xyz[13::229, 0] = np.nan
+    z = rng.integers(0, 65536, n_files * per).astype(np.uint16)
+    for dtype in (np.float64, np.float32):
+        for z_raw in (None, z, (z & 255).astype(np.uint8)):
+            a = xyz.astype(dtype)
+            paths = [str(tmp_path / ("b%d.txt" % k)) for k in range(n_files)]
+            R.cloud_io.write_xyz_txt_batch(paths, a, z_raw=z_raw)
+            for k, p in enumerate(paths):
+                want = R.cloud_io.format_xyz_txt(a[k * per:(k + 1) * per], z_raw=None if z_raw is None else z_raw[k * per:(k + 1) * per])
+                assert open(p, "rb").read() == want, (dtype, k)
+    R.cloud_io.write_xyz_txt_batch([], np.zeros((0, 3)))
+    with pytest.raises(ValueError):
+        R.cloud_io.write_xyz_txt_batch([str(tmp_path / "x.txt")] * 2, np.zeros((3, 3)))
+    with pytest.raises(R.R3DError) as e:
+        R.cloud_io.write_xyz_txt_batch([str(tmp_path / "no_such_dir" / ("x%d.txt" % k)) for k in range(40)], np.zeros((40, 3)))
+    assert "cannot open" in str(e.value)
+
+
+def test_pow10_table_of_the_shortest_digits_algorithm_matches_its_definition():
+    """csrc/r3d_pow10_table.h (generated by tools/gen_pow10_table.py) entry by entry: g(k) = ceil(10^k / 2^r) with
+    r = floor(log2 10^k) - 127, recomputed here with exact integers -- a wrong last bit would misprint one double in 2^64,
+    which no random test finds."""
+    import re
+    from fractions import Fraction
+    text = open(os.path.join(ROOT, PKG, "csrc", "r3d_pow10_table.h")).read()
+    rows = re.findall(r"\{0x([0-9A-F]{16})ull, 0x([0-9A-F]{16})ull\},\s*// (-?\d+)", text)
+    assert [int(k) for _, _, k in rows] == list(range(-292, 325))
+    for hi, lo, k in rows:
+        k = int(k)
+        g = (int(hi, 16) << 64) | int(lo, 16)
+        assert 1 << 127 <= g < 1 << 128
+        # (g - 1) 2^r < 10^k <= g 2^r with r = floor(log2 10^k) - 127, in integers
+        x = Fraction(10) ** k
+        r = x.numerator.bit_length() - x.denominator.bit_length()
+        if Fraction(2) ** r > x:
+            r -= 1
+        r -= 127
+        assert Fraction(g - 1) * Fraction(2) ** r < x <= Fraction(g) * Fraction(2) ** r, k
+
+
+def _repr_lines(R, values):
+    xyz = np.zeros((len(values), 3), np.float64)
+    xyz[:, 0] = values
+    return [ln.split(b",")[0].decode() for ln in R.cloud_io.format_xyz_txt(xyz).split(b"\n")[:-1]]
+
+
+def test_native_repr_is_pythons_for_every_exponent_and_at_every_kind_of_boundary(R):
+    """The txt formatter's shortest-digits routine against repr(): every binary exponent (powers of two -- the doubles whose
+    lower neighbour is closer --, their neighbours on both sides, the largest and a middle significand in each binade),
+    subnormals down to 5e-324, the largest double, integers around 2^53, powers of ten and their neighbours (where the digit
+    count changes), the switch points of repr's notation (1e16, 1e-4) and values with many trailing zeros."""
+    vals = []
+    for e in range(-1074, 1024):
+        p = float(2.0 ** e) if e >= -1022 else float(np.ldexp(1.0, e))
+        vals += [p, np.nextafter(p, np.inf), np.nextafter(p, 0.0)]
+        if -1022 <= e < 1023:
+            vals += [float(np.ldexp(1.5, e)), float(np.ldexp(1.0 + 2.0 ** -52 * 0x5555555555555, e)), float(np.ldexp(2.0 - 2.0 ** -52, e))]
+    for k in range(-323, 309):
+        t = float("1e%d" % k)
+        vals += [t, np.nextafter(t, np.inf), np.nextafter(t, 0.0), float("9.5e%d" % k), float("1.2345678901234567e%d" % k), float("5e%d" % k)]
+    vals += [5e-324, 1.7976931348623157e308, 2.2250738585072014e-308, 2.225073858507201e-308, 9007199254740991.0, 9007199254740992.0,
+             9007199254740994.0, 1e16, 9999999999999998.0, 1e-4, 0.0001, 0.00009999999999999999, 123456789012345680.0, 1e22, 1e23,
+             100.0, 1000000.0, 120000.0, 0.1, 0.2, 0.30000000000000004, 1 / 3, 2 / 3, 1e15, 123.0, 0.5, 4.35, 4.350000000000001]
+    vals = np.array(vals, np.float64)
+    vals = np.concatenate([vals, -vals[::7]])
+    got = _repr_lines(R, vals)
+    for v, g in zip(vals.tolist(), got):
+        assert g == repr(v), (v.hex(), g, repr(v))
+
+
+def test_native_repr_is_pythons_on_random_bit_patterns(R):
+    """2 M doubles drawn as random 64-bit patterns (every exponent equally likely) and 1 M of the camera txt's kind
+    (((i - cx) / fx) * Z) against repr()."""
+    rng = np.random.default_rng(20261004)
+    bits = rng.integers(0, 1 << 64, 2_000_000, dtype=np.uint64)
+    vals = bits.view(np.float64)
+    vals = vals[np.isfinite(vals)]
+    fx, fy, cx, cy = R.REF_INTRINSICS
+    cam = ((rng.integers(0, 1280, 1_000_000) - cx) / fx) * rng.integers(0, 256, 1_000_000).astype(np.float64)
+    for block in (vals, cam):
+        got = _repr_lines(R, block)
+        want = [repr(v) for v in block.tolist()]
+        if got != want:
+            bad = next(k for k in range(len(want)) if got[k] != want[k])
+            raise AssertionError((float(block[bad]).hex(), got[bad], want[bad]))
+
+
+def test_native_percent_4f_is_pythons_on_ties_and_random_values(R):
+    """"%.4f" rounds the EXACT binary value half-to-even.  The formatter's quick way (a double product, trusted only away from
+    the .5 boundary) must hand every doubtful case to its exact integer way: real ties (odd multiples of 1/32 scaled by
+    powers of two -- the only doubles whose fifth decimal is an exact 5), values one ulp either side of them, values whose
+    product with 10^4 lands within an ulp of .5, large values without fraction bits, tiny ones, and 2 M random ones."""
+    rng = np.random.default_rng(7)
+    ties = (2 * rng.integers(0, 1 << 20, 200_000) + 1) / 32.0 * rng.choice([1.0, 0.5, 0.25, 0.125, 2.0, 1024.0], 200_000)
+    ties = np.concatenate([ties, np.arange(1, 20001, 2) / 32.0 / 625.0 * 625.0])
+    near = np.concatenate([np.nextafter(ties, np.inf), np.nextafter(ties, -np.inf)])
+    k = rng.integers(0, 10 ** 9, 400_000)
+    almost = (k + 0.5) / 1e4                                   # decimal ties: not representable, the double decides
+    big = rng.uniform(2.0 ** 30, 2.0 ** 40, 100_000)
+    big = np.concatenate([big, np.floor(big) + 0.5, [2.0 ** 40 - 2.0 ** -13, 2.0 ** 40, 2.0 ** 41 + 0.5, 1e15, 123456789012345680.0]])
+    tiny = np.concatenate([rng.uniform(0, 1e-3, 100_000), [5e-5, 4.9999999999999996e-5, 5.000000000000001e-5, 1.5e-4, 2.5e-4, 5e-324, 0.0, -0.0]])
+    rand = rng.normal(0, 1, 2_000_000) * 10.0 ** rng.integers(-6, 9, 2_000_000)
+    vals = np.concatenate([ties, near, almost, big, tiny, rand])
+    vals = np.concatenate([vals, -vals[::5]])
+    vals = vals[: len(vals) // 3 * 3].reshape(-1, 3)
+    body = R.cloud_io.format_ply(vals).split(b"end_header\n    ", 1)[1]
+    got = body.decode().split()
+    want = ["%.4f" % v for v in vals.reshape(-1).tolist()]
+    assert len(got) == len(want)
+    if got != want:
+        bad = next(i for i in range(len(want)) if got[i] != want[i])
+        raise AssertionError((float(vals.reshape(-1)[bad]).hex(), got[bad], want[bad]))
