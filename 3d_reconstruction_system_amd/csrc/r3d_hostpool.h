@@ -22,10 +22,12 @@ void r3d_set_error(const char* fmt, ...);
 namespace r3d_host {
 
 // How many threads a pool may usefully run: the CPUs this process is ALLOWED, not the ones the machine has --
-// hardware_concurrency() capped by the affinity mask and by the cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us).  The MI355X
-// box shows 256 CPUs and grants 16: pools sized by the first number started 128 formatter threads per slab (and 15 per txt
-// file, four files at a time) for the work 16 can do -- measured the same speed within noise either way (PLY 306-315 ms with 16
-// threads, 314-327 with 128), so the smaller number is the one to create.  R3D_HOST_THREADS overrides.  Read once.
+// hardware_concurrency() capped by the affinity mask and by TWICE the cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us).
+// The MI355X box shows 256 CPUs and grants a quota of 16.  Pools sized by the first number started 128 formatter threads per
+// slab (and 15 per txt file, four files at a time) for no gain; pools of exactly 16 lose to pools of 32 -- the quota is CPU
+// time per 100 ms period, and a pool that lives for 10-200 ms may burst above its average: 100 PNGs decode in 14.5 ms with 16
+// threads, 9.0 with 32 (9.2 with 64); 100 camera txt files take 162-173 ms with 16, 92-142 with 32, no better beyond
+// (tools/bench_host_io.py under R3D_HOST_THREADS).  Hence twice the quota.  R3D_HOST_THREADS overrides.  Read once.
 inline unsigned cpu_budget() {
   static const unsigned budget = [] {
     unsigned n = std::thread::hardware_concurrency();
@@ -46,7 +48,7 @@ inline unsigned cpu_budget() {
         fclose(h);
       }
     }
-    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, 2 * ((quota + period - 1) / period)));
     if (const char* e = getenv("R3D_HOST_THREADS")) {
       const int v = atoi(e);
       if (v > 0) n = (unsigned)std::min(v, 1024);
