@@ -40,6 +40,18 @@ def _is_jpeg(path):
         return f.read(3) == b"\xff\xd8\xff"
 
 
+def _kind(path):
+    """'png' / 'jpeg' / 'other' by the file's first bytes ('missing' when it cannot be opened)."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(8)
+    except OSError:
+        return "missing"
+    if head == b"\x89PNG\r\n\x1a\n":
+        return "png"
+    return "jpeg" if head[:3] == b"\xff\xd8\xff" else "other"
+
+
 def rgb_to_gray(rgb, rule="cvtcolor"):
     """[...,3|4] uint8 R,G,B(,A) -> [...] uint8 grey by one of OpenCV's two integer rules (include/r3d.h, R3D_GRAY_*):
     "opencv_png" = what cv.imread(<png>, IMREAD_GRAYSCALE) does (libpng's rgb_to_gray), "cvtcolor" = cv.cvtColor(BGR2GRAY)."""
@@ -135,11 +147,14 @@ def read_depth_batch(paths, out=None, rule=None):
     h, w = C.c_int(), C.c_int()
     if not os.path.exists(paths[0]):
         raise FileNotFoundError("cannot read depth image %r" % paths[0])
-    jpeg = not _is_png(paths[0]) and _is_jpeg(paths[0])
+    kinds = {_kind(p) for p in paths}
+    jpeg = kinds == {"jpeg"}
     if jpeg:
         rc = lib.r3d_jpeg_gray_info(os.fsencode(paths[0]), C.byref(h), C.byref(w))
+    elif kinds == {"png"}:
+        rc = lib.r3d_png_gray8_info(os.fsencode(paths[0]), C.byref(h), C.byref(w))
     else:
-        rc = lib.r3d_png_gray8_info(os.fsencode(paths[0]), C.byref(h), C.byref(w)) if _is_png(paths[0]) else L.ERR_UNSUPPORTED
+        rc = L.ERR_UNSUPPORTED                                     # other or mixed formats (or a missing file): file by file below
     if rc == L.OK:
         shape = (len(paths), h.value, w.value)
         if out is None:
@@ -178,9 +193,13 @@ def read_rgb_batch(paths, out=None):
         return np.empty((0, 0, 0, 3), np.uint8)
     lib = L.load()
     h, w, ch = C.c_int(), C.c_int(), C.c_int()
-    jpeg = os.path.exists(paths[0]) and not _is_png(paths[0]) and _is_jpeg(paths[0])
+    kinds = {_kind(p) for p in paths}
+    for p in paths:
+        if not os.path.exists(p):
+            raise FileNotFoundError("cannot read image %r" % p)
+    jpeg = kinds == {"jpeg"}
     info = lib.r3d_jpeg_rgb_info if jpeg else lib.r3d_png_rgb_info
-    rc = info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch))
+    rc = info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch)) if len(kinds) == 1 else L.ERR_UNSUPPORTED   # mixed: PIL below
     if rc == L.OK:
         shape = (len(paths), h.value, w.value, 3)
         if out is None:

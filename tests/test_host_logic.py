@@ -810,3 +810,30 @@ def test_native_percent_4f_is_pythons_on_ties_and_random_values(R):
     if got != want:
         bad = next(i for i in range(len(want)) if got[i] != want[i])
         raise AssertionError((float(vals.reshape(-1)[bad]).hex(), got[bad], want[bad]))
+
+
+def test_batches_of_mixed_formats_are_read_file_by_file(R, tmp_path):
+    """A pose file may name PNG and JPEG frames side by side: the native batch decoders take one format per call, a mixed
+    list goes file by file with the same per-format rules; a missing file is named."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 256, (24, 40), dtype=np.uint8)
+    c = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    Image.fromarray(g, "L").save(tmp_path / "a.png")
+    Image.fromarray(c, "RGB").save(tmp_path / "b.jpg", quality=90)
+    Image.fromarray(c, "RGB").save(tmp_path / "c.png")
+    paths = [str(tmp_path / n) for n in ("a.png", "b.jpg", "c.png")]
+    got = R.cloud_io.read_depth_batch(paths)
+    for k, p in enumerate(paths):
+        np.testing.assert_array_equal(got[k], R.cloud_io.read_depth_gray(p))
+    np.testing.assert_array_equal(got[0], g)
+    np.testing.assert_array_equal(got[1], _pil_luma(paths[1]))
+    rgb = R.cloud_io.read_rgb_batch(paths)
+    for k, p in enumerate(paths):
+        np.testing.assert_array_equal(rgb[k], np.asarray(Image.open(p).convert("RGB")))
+    with pytest.raises(FileNotFoundError) as e:
+        R.cloud_io.read_depth_batch(paths + [str(tmp_path / "gone.png")])
+    assert "gone.png" in str(e.value)
+    with pytest.raises(FileNotFoundError) as e:
+        R.cloud_io.read_rgb_batch(paths + [str(tmp_path / "gone.jpg")])
+    assert "gone.jpg" in str(e.value)
