@@ -9,6 +9,7 @@
 // expansion, as CPython and glibc both produce.  Fast path: |x| < 2^40 is scaled exactly with
 // 128-bit integer arithmetic (x = m*2^e, m*10^4 < 2^67); everything else goes through snprintf.
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -355,37 +356,83 @@ void format_rows_rgb(const T* xyz, const unsigned char* rgb, int stride, int64_t
   out->len = p - base;
 }
 
-int format_chunks(const void* h_xyz, int dtype, int64_t n, std::string* header, std::vector<TextBuf>* chunks) {
-  char head[256];
-  snprintf(head, sizeof(head),
-           "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
-           "    property float z\n    end_header\n    ",
-           (long long)n);
-  *header = head;
-  unsigned hw = r3d_host::cpu_budget();
-  if (hw == 0) hw = 1;
-  int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
-  chunks->resize((size_t)n_chunks);   // buffers of earlier slabs are kept and reused
+// rows [lo, lo + cnt) as text, one chunk per pool thread: rows(a, b, TextBuf*) formats rows [a, b).  Buffers the vector
+// already holds are reused.  May throw (no memory, no thread).
+template <typename Rows>
+void format_parallel(int64_t lo, int64_t cnt, int64_t min_rows_per_chunk, const Rows& rows, std::vector<TextBuf>* chunks) {
+  const int64_t n_chunks = std::min<int64_t>(std::max(1u, r3d_host::cpu_budget()), std::max<int64_t>(1, cnt / min_rows_per_chunk));
+  chunks->resize((size_t)n_chunks);
+  if (n_chunks == 1) {
+    rows(lo, lo + cnt, &(*chunks)[0]);
+    return;
+  }
   const r3d_host::Spread spread;
   std::vector<std::thread> pool;
-  for (int64_t c = 0; c < n_chunks; ++c) {
-    const int64_t lo = n * c / n_chunks, hi = n * (c + 1) / n_chunks;
-    auto work = [=]() {
-      if (dtype == R3D_F32)
-        format_rows(static_cast<const float*>(h_xyz), lo, hi, &(*chunks)[(size_t)c]);
-      else
-        format_rows(static_cast<const double*>(h_xyz), lo, hi, &(*chunks)[(size_t)c]);
-    };
-    if (n_chunks == 1)
-      work();
-    else
-      pool.emplace_back([work, c, &spread]() {
+  std::exception_ptr failed;
+  std::atomic<bool> have_failure{false};
+  try {
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      const int64_t a = lo + cnt * c / n_chunks, b = lo + cnt * (c + 1) / n_chunks;
+      pool.emplace_back([&, a, b, c]() {
         spread.place((unsigned)c);   // the creator only waits: chunk 0 may have its CPU
-        work();
+        try {
+          rows(a, b, &(*chunks)[(size_t)c]);
+        } catch (...) {
+          if (!have_failure.exchange(true)) failed = std::current_exception();
+        }
       });
+    }
+  } catch (...) {   // no thread to be had: the ones that started must finish before the buffers go away
+    for (auto& t : pool) t.join();
+    throw;
   }
   for (auto& t : pool) t.join();
-  return R3D_OK;
+  if (have_failure.load()) std::rethrow_exception(failed);
+}
+
+// The body of a text file, slab by slab: slab k goes to the file on a helper thread while slab k + 1 is being formatted
+// (two sets of chunk buffers).  Returns false on a short write; may throw (no memory, no thread) with the helper joined.
+template <typename Rows>
+bool write_slabs(FILE* f, int64_t n_rows, int64_t slab, int64_t min_rows_per_chunk, const Rows& rows) {
+  std::vector<TextBuf> buf[2];
+  std::thread writer;
+  bool wrote_ok = true;
+  struct Join {
+    std::thread& t;
+    ~Join() {
+      if (t.joinable()) t.join();
+    }
+  } join{writer};
+  int cur = 0;
+  for (int64_t lo = 0; lo < n_rows; lo += slab, cur ^= 1) {
+    format_parallel(lo, std::min(slab, n_rows - lo), min_rows_per_chunk, rows, &buf[cur]);
+    if (writer.joinable()) writer.join();   // the other set is free again once its slab is in the file
+    if (!wrote_ok) return false;
+    const std::vector<TextBuf>* src = &buf[cur];
+    writer = std::thread([src, f, &wrote_ok]() {
+      for (const auto& c : *src) wrote_ok = wrote_ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+    });
+  }
+  if (writer.joinable()) writer.join();
+  return wrote_ok;
+}
+
+template <typename F32, typename F64>
+auto by_dtype(int dtype, F32 f32, F64 f64) {
+  return [=](int64_t a, int64_t b, TextBuf* out) {
+    if (dtype == R3D_F32)
+      f32(a, b, out);
+    else
+      f64(a, b, out);
+  };
+}
+
+int ply_header(char* head, size_t cap, int64_t n, bool colour) {
+  return snprintf(head, cap,
+                  "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
+                  "    property float z\n%s    end_header\n    ",
+                  (long long)n,
+                  colour ? "    property uchar red\n    property uchar green\n    property uchar blue\n    property uchar alpha\n" : "");
 }
 
 }  // namespace
@@ -398,11 +445,16 @@ int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, 
     r3d_set_error("r3d_format_ply: bad argument");
     return R3D_ERR_INVALID;
   }
-  std::string header;
+  char head[256];
+  ply_header(head, sizeof(head), n_points, false);
+  const std::string header = head;
   std::vector<TextBuf> chunks;
   try {
-    format_chunks(h_xyz, dtype, n_points, &header, &chunks);
-  } catch (const std::bad_alloc&) {
+    format_parallel(0, n_points, 65536,
+                    by_dtype(dtype, [=](int64_t a, int64_t b, TextBuf* o) { format_rows(static_cast<const float*>(h_xyz), a, b, o); },
+                             [=](int64_t a, int64_t b, TextBuf* o) { format_rows(static_cast<const double*>(h_xyz), a, b, o); }),
+                    &chunks);
+  } catch (const std::exception&) {
     r3d_set_error("r3d_format_ply: out of host memory");
     return R3D_ERR_NOMEM;
   }
@@ -450,43 +502,13 @@ static int write_ply_colour(const char* path, const void* h_xyz, int dtype, cons
   bool ok = true;
   try {
     char head[400];
-    snprintf(head, sizeof(head),
-             "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
-             "    property float z\n    property uchar red\n    property uchar green\n    property uchar blue\n"
-             "    property uchar alpha\n    end_header\n    ",
-             (long long)n_points);
-    ok = fwrite(head, 1, strlen(head), f) == strlen(head);
-    unsigned hw = r3d_host::cpu_budget();
-    if (hw == 0) hw = 1;
-    const int64_t slab = (int64_t)4 << 20;
-    const r3d_host::Spread spread;
-    std::vector<TextBuf> chunks;
-    for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
-      const int64_t cnt = std::min(slab, n_points - s0);
-      const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 65536));
-      chunks.resize((size_t)n_chunks);
-      std::vector<std::thread> pool;
-      for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
-        auto work = [=, &chunks]() {
-          if (dtype == R3D_F32)
-            format_rows_rgb(static_cast<const float*>(h_xyz), h_rgb, stride, lo, hi, &chunks[(size_t)c]);
-          else
-            format_rows_rgb(static_cast<const double*>(h_xyz), h_rgb, stride, lo, hi, &chunks[(size_t)c]);
-        };
-        if (n_chunks == 1)
-          work();
-        else
-          pool.emplace_back([work, c, &spread]() {
-            spread.place((unsigned)c);
-            work();
-          });
-      }
-      for (auto& t : pool) t.join();
-      for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
-    }
+    const int hn = ply_header(head, sizeof(head), n_points, true);
+    ok = fwrite(head, 1, (size_t)hn, f) == (size_t)hn;
+    ok = ok && write_slabs(f, n_points, (int64_t)4 << 20, 65536,
+                           by_dtype(dtype, [=](int64_t a, int64_t b_, TextBuf* o) { format_rows_rgb(static_cast<const float*>(h_xyz), h_rgb, stride, a, b_, o); },
+                                    [=](int64_t a, int64_t b_, TextBuf* o) { format_rows_rgb(static_cast<const double*>(h_xyz), h_rgb, stride, a, b_, o); }));
     ok = ok && fwrite("\n    ", 1, 5, f) == 5;
-  } catch (const std::bad_alloc&) {
+  } catch (const std::exception&) {   // bad_alloc, or no thread to be had
     fclose(f);
     r3d_set_error("r3d_write_ply_rgb: out of host memory");
     return R3D_ERR_NOMEM;
@@ -509,38 +531,17 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
     r3d_set_error("r3d_write_ply: cannot open '%s' for writing", path);
     return R3D_ERR_INVALID;
   }
-  // format and write in slabs of 8 M points so the text never needs more than ~0.5 GB of host memory
-  const int64_t slab = (int64_t)8 << 20;
-  std::string header;
-  std::vector<TextBuf> buf[2];
-  std::thread writer;  // outside the try: it must be joined on every way out
-  bool wrote_ok = true;
+  // formatted and written in slabs of 8 M points so the text never needs more than ~0.5 GB of host memory
   bool ok = true;
   try {
     char head[256];
-    snprintf(head, sizeof(head),
-             "ply\n    format ascii 1.0\n    element vertex %lld\n    property float x\n    property float y\n"
-             "    property float z\n    end_header\n    ",
-             (long long)n_points);
-    ok = fwrite(head, 1, strlen(head), f) == strlen(head);
-    const size_t esz = dtype == R3D_F32 ? 4 : 8;
-    // two text buffers: slab k is written by a helper thread while slab k+1 is being formatted
-    int cur = 0;
-    for (int64_t lo = 0; ok && lo < n_points; lo += slab, cur ^= 1) {
-      const int64_t cnt = std::min(slab, n_points - lo);
-      format_chunks(static_cast<const char*>(h_xyz) + (size_t)lo * 3 * esz, dtype, cnt, &header, &buf[cur]);
-      if (writer.joinable()) writer.join();  // the other buffer is free again once its slab is on disk
-      ok = ok && wrote_ok;
-      const std::vector<TextBuf>* src = &buf[cur];
-      writer = std::thread([src, f, &wrote_ok]() {
-        for (const auto& c : *src) wrote_ok = wrote_ok && fwrite(c.data(), 1, c.size(), f) == c.size();
-      });
-    }
-    if (writer.joinable()) writer.join();
-    ok = ok && wrote_ok;
+    const int hn = ply_header(head, sizeof(head), n_points, false);
+    ok = fwrite(head, 1, (size_t)hn, f) == (size_t)hn;
+    ok = ok && write_slabs(f, n_points, (int64_t)8 << 20, 65536,
+                           by_dtype(dtype, [=](int64_t a, int64_t b_, TextBuf* o) { format_rows(static_cast<const float*>(h_xyz), a, b_, o); },
+                                    [=](int64_t a, int64_t b_, TextBuf* o) { format_rows(static_cast<const double*>(h_xyz), a, b_, o); }));
     ok = ok && fwrite("\n    ", 1, 5, f) == 5;
   } catch (const std::exception&) {  // bad_alloc, or no thread to be had
-    if (writer.joinable()) writer.join();
     fclose(f);
     r3d_set_error("r3d_write_ply: out of host memory");
     return R3D_ERR_NOMEM;
@@ -553,31 +554,9 @@ int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_poin
   return R3D_OK;
 }
 
-static void txt_chunks(const void* h_xyz, int dtype, int64_t s0, int64_t cnt, const void* h_z_raw, int z_raw_dtype,
-                       std::vector<TextBuf>* chunks) {
-  unsigned hw = r3d_host::cpu_budget();
-  if (hw == 0) hw = 1;
-  const int64_t n_chunks = std::min<int64_t>(hw, std::max<int64_t>(1, cnt / 32768));
-  chunks->resize((size_t)n_chunks);   // buffers of earlier slabs are kept and reused
-  const r3d_host::Spread spread;
-  std::vector<std::thread> pool;
-  for (int64_t c = 0; c < n_chunks; ++c) {
-    const int64_t lo = s0 + cnt * c / n_chunks, hi = s0 + cnt * (c + 1) / n_chunks;
-    auto work = [=]() {
-      if (dtype == R3D_F32)
-        txt_rows(static_cast<const float*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &(*chunks)[(size_t)c]);
-      else
-        txt_rows(static_cast<const double*>(h_xyz), h_z_raw, z_raw_dtype, lo, hi, &(*chunks)[(size_t)c]);
-    };
-    if (n_chunks == 1)
-      work();
-    else
-      pool.emplace_back([work, c, &spread]() {
-        spread.place((unsigned)c);   // the creator only waits: chunk 0 may have its CPU
-        work();
-      });
-  }
-  for (auto& t : pool) t.join();
+static auto txt_rows_of(const void* h_xyz, int dtype, const void* h_z_raw, int z_raw_dtype) {
+  return by_dtype(dtype, [=](int64_t a, int64_t b, TextBuf* o) { txt_rows(static_cast<const float*>(h_xyz), h_z_raw, z_raw_dtype, a, b, o); },
+                  [=](int64_t a, int64_t b, TextBuf* o) { txt_rows(static_cast<const double*>(h_xyz), h_z_raw, z_raw_dtype, a, b, o); });
 }
 
 int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const void* h_z_raw, int z_raw_dtype,
@@ -589,8 +568,8 @@ int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const voi
   }
   std::vector<TextBuf> chunks;
   try {
-    txt_chunks(h_xyz, dtype, 0, n_points, h_z_raw, z_raw_dtype, &chunks);
-  } catch (const std::bad_alloc&) {
+    format_parallel(0, n_points, 32768, txt_rows_of(h_xyz, dtype, h_z_raw, z_raw_dtype), &chunks);
+  } catch (const std::exception&) {
     r3d_set_error("r3d_format_xyz_txt: out of host memory");
     return R3D_ERR_NOMEM;
   }
@@ -624,13 +603,8 @@ int r3d_write_xyz_txt(const char* path, const void* h_xyz, int dtype, int64_t n_
   }
   bool ok = true;
   try {
-    const int64_t slab = (int64_t)4 << 20;
-    std::vector<TextBuf> chunks;
-    for (int64_t s0 = 0; ok && s0 < n_points; s0 += slab) {
-      txt_chunks(h_xyz, dtype, s0, std::min(slab, n_points - s0), h_z_raw, z_raw_dtype, &chunks);
-      for (const auto& c : chunks) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
-    }
-  } catch (const std::bad_alloc&) {
+    ok = write_slabs(f, n_points, (int64_t)4 << 20, 32768, txt_rows_of(h_xyz, dtype, h_z_raw, z_raw_dtype));
+  } catch (const std::exception&) {
     fclose(f);
     r3d_set_error("r3d_write_xyz_txt: out of host memory");
     return R3D_ERR_NOMEM;
