@@ -1,4 +1,6 @@
-// Host thread pool shared by the file decoders (r3d_png.cpp, r3d_jpeg.cpp): n files, one task each, first failure wins.
+// What the library's host-side pools share (file decoders r3d_png.cpp / r3d_jpeg.cpp, text formatters r3d_format.cpp, staging
+// copies r3d_hostpipe.hip, the .bt writer r3d_voxel.hip): how many threads to start (cpu_budget), where they start (Spread, opt-in),
+// recycled scratch memory (Scratch), and run_batch -- n files, one task each, first failure wins.
 #pragma once
 
 #include <pthread.h>
