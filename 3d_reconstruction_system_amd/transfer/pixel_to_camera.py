@@ -48,9 +48,9 @@ def _as_xyz(gtxyz):
 def genply_noRGB(gtxyz, imgpath, pc_file):
     """The COLOURED writer (the reference's names are swapped): x y z R G B 0 rows with the
     uchar red/green/blue/alpha header of p2c:55-91."""
-    from PIL import Image
     t1 = time.time()
-    img = np.array(Image.open(imgpath).convert("RGB"))
+    # the bytes PIL's Image.open(imgpath) gives (p2c:58): PNG and JPEG decoded natively, anything else by PIL itself
+    img = r3d.cloud_io.read_rgb_batch([imgpath])[0]
     xyz = _as_xyz(gtxyz)
     if img.shape[0] * img.shape[1] != xyz.shape[0]:
         raise ValueError("colour image has %d pixels, cloud has %d points" % (img.shape[0] * img.shape[1], xyz.shape[0]))

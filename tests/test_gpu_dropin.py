@@ -235,7 +235,8 @@ def test_sharded_dropin_fails_on_every_rank_instead_of_hanging(tmp_path, golden_
     assert not (tmp_path / "ply" / "small_035_p8.ply").exists()
 
 
-def test_pixel_to_camera_script_writes_the_coloured_ply_when_the_image_exists(tmp_path):
+@pytest.mark.parametrize("colour_format", ["png", "jpeg"])
+def test_pixel_to_camera_script_writes_the_coloured_ply_when_the_image_exists(tmp_path, colour_format):
     """p2c:136 calls its writer with (points, ./img/24.png, ply path) -- the coloured writer's signature.  With ./img/24.png
     present the drop-in's main() writes `x y z R G B 0` rows under the uchar header of p2c:71-87; the oracle's formatter
     (pinned by the reference-generated coloured fixture in tests/test_oracle_golden.py) gives the expected bytes."""
@@ -246,7 +247,11 @@ def test_pixel_to_camera_script_writes_the_coloured_ply_when_the_image_exists(tm
     depth = rng.integers(1, 256, (48, 64), dtype=np.uint8)
     rgb = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
     Image.fromarray(np.stack([depth // 2, depth, depth // 3], 2).astype(np.uint8), "RGB").save(tmp_path / "depth" / "24.png")
-    Image.fromarray(rgb, "RGB").save(tmp_path / "img" / "24.png")
+    if colour_format == "png":
+        Image.fromarray(rgb, "RGB").save(tmp_path / "img" / "24.png")
+    else:       # AirSim's scene images are JPG: JPEG bytes under the name the script opens; the colours are what PIL decodes
+        Image.fromarray(rgb, "RGB").save(tmp_path / "img" / "24.png", format="JPEG", quality=90)
+        rgb = np.asarray(Image.open(tmp_path / "img" / "24.png").convert("RGB"))
     out = run_script("transfer/pixel_to_camera.py", str(tmp_path))
     assert "Write into .ply file Done." in out
     assert (tmp_path / "ply" / "24.ply").read_bytes() == O.format_ply_rgb(O.unproject(depth), rgb.reshape(-1, 3)).encode()
