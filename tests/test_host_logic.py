@@ -215,14 +215,16 @@ def test_read_xyz_txt_takes_first_three_fields_and_names_bad_lines(R, tmp_path):
 
 
 def test_colmap_depth_prep_drop_in(tmp_path):
-    """other_tools/data_transfer.py:5-16 (parity unpinned: OpenCV is absent): 640x480 grey uint8 .npy, nearest-neighbour
-    index rule and Q14 grey weights as restated."""
+    """other_tools/data_transfer.py:5-16 (parity unpinned: OpenCV is absent): 640x480 grey uint8 .npy.  The reference's
+    `cv2.resize(img, (640, 480), cv2.INTER_NEAREST)` passes the constant as `dst`, so OpenCV resizes BILINEARLY: that is the
+    default here, in OpenCV's fixed point (checked against a float bilinear to within one grey level, against the exact
+    box-filter case, against the identity); interpolation="nearest" is the index rule its comment intends.  Q14 grey weights."""
     from PIL import Image
     dt = importlib.import_module(PKG + ".other_tools.data_transfer")
     rng = np.random.default_rng(3)
     rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
     Image.fromarray(rgb, "RGB").save(tmp_path / "a.png")
-    out = dt.get_data(str(tmp_path / "a.png"), str(tmp_path / "a.npy"))
+    out = dt.get_data(str(tmp_path / "a.png"), str(tmp_path / "a.npy"), interpolation="nearest")
     saved = np.load(tmp_path / "a.npy")
     assert saved.shape == (480, 640) and saved.dtype == np.uint8
     np.testing.assert_array_equal(out, saved)
@@ -234,6 +236,29 @@ def test_colmap_depth_prep_drop_in(tmp_path):
     assert (dt.bgr_to_gray(grey) == 200).all()                   # the weights sum to 2^14
     big = rng.integers(0, 256, (960, 1280, 3), dtype=np.uint8)    # exact 2x downscale picks every other pixel
     np.testing.assert_array_equal(dt.resize_nearest(big, 640, 480), big[::2, ::2])
+    # the default: what the reference's call does under OpenCV
+    out = dt.get_data(str(tmp_path / "a.png"), str(tmp_path / "b.npy"))
+    np.testing.assert_array_equal(out, dt.bgr_to_gray(dt.resize_linear_u8(rgb[..., ::-1], 640, 480)))
+    assert not np.array_equal(out, saved)
+    for (h, w) in ((37, 53), (1080, 1920), (100, 2000), (479, 641)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = dt.resize_linear_u8(img, 640, 480).astype(np.float64)
+        fx, fy = (np.arange(640) + 0.5) * (w / 640) - 0.5, (np.arange(480) + 0.5) * (h / 480) - 0.5
+        x0, y0 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+        ax, ay = (fx - x0)[None, :, None], (fy - y0)[:, None, None]
+        xa, xb, ya, yb = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1), np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
+        f = img.astype(np.float64)
+        ref = (f[ya][:, xa] * (1 - ax) + f[ya][:, xb] * ax) * (1 - ay) + (f[yb][:, xa] * (1 - ax) + f[yb][:, xb] * ax) * ay
+        assert np.abs(got - ref).max() < 1.0
+    b4 = big.astype(np.int64)
+    np.testing.assert_array_equal(dt.resize_linear_u8(big, 640, 480),
+                                  ((b4[0::2, 0::2] + b4[0::2, 1::2] + b4[1::2, 0::2] + b4[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    same = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(dt.resize_linear_u8(same, 640, 480), same)
+    flat = np.full((33, 71), 137, np.uint8)
+    assert (dt.resize_linear_u8(flat, 640, 480) == 137).all()     # the fixed-point weights of a pixel pair sum to 2048
+    with pytest.raises(ValueError):
+        dt.get_data(str(tmp_path / "a.png"), str(tmp_path / "c.npy"), interpolation="cubic")
 
 
 def test_native_rgb_png_batch_matches_pil(R, tmp_path):
