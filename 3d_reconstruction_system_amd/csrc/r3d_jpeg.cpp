@@ -505,13 +505,17 @@ int decode_gray_impl(const char* path, unsigned char* out, size_t cap_bytes, int
 // libjpeg's default colour decode: every component through the islow IDCT, chroma brought to full resolution by "fancy"
 // (triangle-filter) upsampling (jdsample.c: h2v1 / h2v2; plain replication when a chroma row has fewer than three samples),
 // then YCbCr -> RGB with 16-bit fixed-point tables (jdcolor.c).
-inline unsigned char clamp255(int v) { return (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
-
 // one chroma row pair -> one full-resolution row.  near / far: the chroma rows this output row lies between (the nearer one
 // weighs 3, the other 1; the same row twice when the component is not subsampled vertically); dw real samples per row.
-// (h1v2 -- 4:4:0 -- is refused by the caller.)
-void upsample_row(const unsigned char* near_, const unsigned char* far_, int dw, bool h2, bool v2, bool fancy, unsigned char* out, int out_w,
-                  unsigned char* tmp /* 2 dw bytes */) {
+// (h1v2 -- 4:4:0 -- is refused by the caller.)  jdsample.c walks a row with running sums and special first / last columns;
+// the same numbers come out of ONE formula per output parity over a row padded by a copy of its end samples --
+//   h2v2: s[x] = 3 near[x] + far[x];  out[2x] = (3 s[x] + s[x-1] + 8) >> 4,  out[2x+1] = (3 s[x] + s[x+1] + 7) >> 4
+//         (first column: (4 s[0] + 8) >> 4 = the formula with s[-1] = s[0]; last: (4 s + 7) >> 4 likewise)
+//   h2v1: out[2x] = (3 in[x] + in[x-1] + 1) >> 2,  out[2x+1] = (3 in[x] + in[x+1] + 2) >> 2   (ends: (4 in + 1 or 2) >> 2 = in)
+// -- loops without a carried dependency, which the compiler turns into 16-bit vector arithmetic.
+// sums: dw + 2 shorts of scratch; out: room for 2 dw bytes (one more than out_w when the width is odd).
+void upsample_row(const unsigned char* __restrict near_, const unsigned char* __restrict far_, int dw, bool h2, bool v2, bool fancy,
+                  unsigned char* __restrict out, int out_w, int16_t* __restrict sums) {
   if (!h2 && !v2) {
     memcpy(out, near_, (size_t)out_w);
     return;
@@ -520,53 +524,26 @@ void upsample_row(const unsigned char* near_, const unsigned char* far_, int dw,
     for (int x = 0; x < out_w; ++x) out[x] = near_[h2 ? x >> 1 : x];
     return;
   }
-  if (h2 && !v2) {   // h2v1_fancy_upsample
-    int o = 0;
-    int invalue = near_[0];
-    tmp[o++] = (unsigned char)invalue;
-    tmp[o++] = (unsigned char)((invalue * 3 + near_[1] + 2) >> 2);
-    for (int x = 1; x < dw - 1; ++x) {
-      invalue = near_[x] * 3;
-      tmp[o++] = (unsigned char)((invalue + near_[x - 1] + 1) >> 2);
-      tmp[o++] = (unsigned char)((invalue + near_[x + 1] + 2) >> 2);
+  int16_t* s = sums + 1;
+  if (v2) {
+    for (int x = 0; x < dw; ++x) s[x] = (int16_t)(3 * near_[x] + far_[x]);
+  } else {
+    for (int x = 0; x < dw; ++x) s[x] = near_[x];
+  }
+  s[-1] = s[0];
+  s[dw] = s[dw - 1];
+  if (v2) {
+    for (int x = 0; x < dw; ++x) {
+      out[2 * x] = (unsigned char)((3 * s[x] + s[x - 1] + 8) >> 4);
+      out[2 * x + 1] = (unsigned char)((3 * s[x] + s[x + 1] + 7) >> 4);
     }
-    invalue = near_[dw - 1];
-    tmp[o++] = (unsigned char)((invalue * 3 + near_[dw - 2] + 1) >> 2);
-    tmp[o++] = (unsigned char)invalue;
-    memcpy(out, tmp, (size_t)out_w);
-    return;
+  } else {
+    for (int x = 0; x < dw; ++x) {
+      out[2 * x] = (unsigned char)((3 * s[x] + s[x - 1] + 1) >> 2);
+      out[2 * x + 1] = (unsigned char)((3 * s[x] + s[x + 1] + 2) >> 2);
+    }
   }
-  // h2v2_fancy_upsample
-  int o = 0;
-  int thiscolsum = near_[0] * 3 + far_[0], nextcolsum = near_[1] * 3 + far_[1], lastcolsum;
-  tmp[o++] = (unsigned char)((thiscolsum * 4 + 8) >> 4);
-  tmp[o++] = (unsigned char)((thiscolsum * 3 + nextcolsum + 7) >> 4);
-  lastcolsum = thiscolsum;
-  thiscolsum = nextcolsum;
-  for (int x = 1; x < dw - 1; ++x) {
-    nextcolsum = near_[x + 1] * 3 + far_[x + 1];
-    tmp[o++] = (unsigned char)((thiscolsum * 3 + lastcolsum + 8) >> 4);
-    tmp[o++] = (unsigned char)((thiscolsum * 3 + nextcolsum + 7) >> 4);
-    lastcolsum = thiscolsum;
-    thiscolsum = nextcolsum;
-  }
-  tmp[o++] = (unsigned char)((thiscolsum * 3 + lastcolsum + 8) >> 4);
-  tmp[o++] = (unsigned char)((thiscolsum * 4 + 7) >> 4);
-  memcpy(out, tmp, (size_t)out_w);
 }
-
-int g_cr_r[256], g_cb_b[256], g_cr_g[256], g_cb_g[256];   // jdcolor.c build_ycc_rgb_table
-struct YccInit {
-  YccInit() {
-    for (int i = 0; i < 256; ++i) {
-      const int x = i - 128;
-      g_cr_r[i] = (int)((91881LL * x + 32768) >> 16);     // FIX(1.40200)
-      g_cb_b[i] = (int)((116130LL * x + 32768) >> 16);    // FIX(1.77200)
-      g_cr_g[i] = (int)(-46802LL * x);                    // FIX(0.71414)
-      g_cb_g[i] = (int)(-22554LL * x + 32768);            // FIX(0.34414), + ONE_HALF
-    }
-  }
-} g_ycc_init;
 
 // out == NULL: header query.  R,G,B bytes, [H][W][3].
 int decode_rgb_impl(const char* path, unsigned char* out, size_t cap_bytes, int* h_out, int* w_out, int* comps_out, std::string* msg) {
@@ -596,7 +573,8 @@ int decode_rgb_impl(const char* path, unsigned char* out, size_t cap_bytes, int*
   const bool h2 = P.hmax == 2 * P.h[1], v2 = P.vmax == 2 * P.v[1];
   const int dw = h2 ? (P.width + 1) / 2 : P.width, dh = v2 ? (P.height + 1) / 2 : P.height;   // real chroma samples
   const bool fancy = dw > 2;   // jinit_upsampler: fancy upsampling needs more than two samples in a row
-  std::vector<unsigned char> cb(W + 2), cr(W + 2), tmp((size_t)2 * dw + 2);
+  std::vector<unsigned char> cb(W + 2), cr(W + 2), red(W), green(W), blue(W);
+  std::vector<int16_t> sums((size_t)dw + 2);
   for (size_t y = 0; y < H; ++y) {
     // chroma rows this output row lies between: row y/2 and its neighbour above (even y) or below (odd y), edges replicated
     const int cy = v2 ? (int)(y >> 1) : (int)y;
@@ -609,15 +587,34 @@ int decode_rgb_impl(const char* path, unsigned char* out, size_t cap_bytes, int*
     for (int c = 1; c <= 2; ++c) {
       const unsigned char* near_ = P.data[c] + (size_t)cy * P.stride[c];
       const unsigned char* far_ = P.data[c] + (size_t)other * P.stride[c];
-      upsample_row(near_, far_, dw, h2, v2, fancy, c == 1 ? cb.data() : cr.data(), (int)W, tmp.data());
+      upsample_row(near_, far_, dw, h2, v2, fancy, c == 1 ? cb.data() : cr.data(), (int)W, sums.data());
     }
     const unsigned char* yrow = P.data[0] + y * P.stride[0];
     unsigned char* o = out + y * W * 3;
-    for (size_t x = 0; x < W; ++x) {
-      const int yy = yrow[x], b_ = cb[x], r_ = cr[x];
-      o[3 * x] = clamp255(yy + g_cr_r[r_]);
-      o[3 * x + 1] = clamp255(yy + ((g_cb_g[b_] + g_cr_g[r_]) >> 16));
-      o[3 * x + 2] = clamp255(yy + g_cb_b[b_]);
+    // jdcolor.c's tables written out -- R = Y + ((91881 Cr' + 32768) >> 16), B = Y + ((116130 Cb' + 32768) >> 16),
+    // G = Y + ((-22554 Cb' - 46802 Cr' + 32768) >> 16), Cb' = Cb - 128 -- as arithmetic into three planes (vector code), then
+    // the planes interleaved
+    {
+      const unsigned char* __restrict yp = yrow;
+      const unsigned char* __restrict bp = cb.data();
+      const unsigned char* __restrict rp = cr.data();
+      unsigned char* __restrict R_ = red.data();
+      unsigned char* __restrict G_ = green.data();
+      unsigned char* __restrict B_ = blue.data();
+      for (size_t x = 0; x < W; ++x) {
+        const int yy = yp[x], cbv = bp[x] - 128, crv = rp[x] - 128;
+        const int r = yy + ((91881 * crv + 32768) >> 16);
+        const int g = yy + ((-22554 * cbv - 46802 * crv + 32768) >> 16);
+        const int bl = yy + ((116130 * cbv + 32768) >> 16);
+        R_[x] = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+        G_[x] = (unsigned char)(g < 0 ? 0 : g > 255 ? 255 : g);
+        B_[x] = (unsigned char)(bl < 0 ? 0 : bl > 255 ? 255 : bl);
+      }
+      for (size_t x = 0; x < W; ++x) {
+        o[3 * x] = R_[x];
+        o[3 * x + 1] = G_[x];
+        o[3 * x + 2] = B_[x];
+      }
     }
   }
   return R3D_OK;
