@@ -198,23 +198,24 @@ int parse_headers(const char* path, const std::vector<unsigned char>& f, Jpeg* j
 struct Bits {
   const unsigned char* p;
   const unsigned char* end;
-  uint64_t buf = 0;
-  int n = 0;          // valid bits in buf (low end)
+  uint64_t buf = 0;   // the coming bits, first bit in bit 63.  Below the n valid ones there may be a PREVIEW of the next byte's
+                      // leading bits (left by the 8-byte refill); the same bits are or-ed over it by the next refill, and the
+                      // byte-wise path clears it first
+  int n = 0;          // valid bits
   int marker = 0;     // a marker met in the data (its second byte); nothing is read past it
   void fill() {
-    if (!marker && end - p >= 8 && n <= 56) {   // eight bytes without an 0xff among them: no stuffing, no marker -- take what fits at once
+    if (!marker && end - p >= 8) {   // eight bytes without an 0xff among them: no stuffing, no marker -- take what fits at once
       uint64_t w;
       memcpy(&w, p, 8);
       const uint64_t x = ~w;
       if (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) == 0) {
-        w = __builtin_bswap64(w);
-        const int take = (64 - n) >> 3;   // 1..8 bytes
-        buf = take == 8 ? w : ((buf << (8 * take)) | (w >> (64 - 8 * take)));
-        p += take;
-        n += 8 * take;
+        buf |= __builtin_bswap64(w) >> n;   // n < 64 here: fill() is called with fewer than 16 bits left
+        p += (63 - n) >> 3;                 // the whole bytes that fitted
+        n |= 56;
         return;
       }
     }
+    buf = n ? (buf & (~0ull << (64 - n))) : 0;
     while (n <= 56) {
       int byte = 0;
       if (!marker && p < end) {
@@ -234,12 +235,15 @@ struct Bits {
           ++p;
         }
       }
-      buf = (buf << 8) | (uint64_t)byte;
+      buf |= (uint64_t)byte << (56 - n);
       n += 8;
     }
   }
-  inline int peek(int k) { return (int)((buf >> (n - k)) & ((1u << k) - 1)); }
-  inline void drop(int k) { n -= k; }
+  inline int peek(int k) { return (int)(buf >> (64 - k)); }   // 1 <= k <= n
+  inline void drop(int k) {
+    buf <<= k;
+    n -= k;
+  }
   inline int get(int k) {
     if (k == 0) return 0;
     if (n < k) fill();
