@@ -466,7 +466,9 @@ int r3d_png_rgb_decode_batch(const char* const* paths, int n_files, unsigned cha
  * default -- every component through the islow IDCT, chroma to full resolution by libjpeg's "fancy" triangle upsampling
  * (jdsample.c h2v1 / h2v2; replication when a chroma row has fewer than three samples), YCbCr -> RGB through jdcolor.c's
  * 16-bit fixed-point tables; a grey JPEG is replicated.  Pinned byte for byte against PIL over sizes, qualities and
- * 4:4:4 / 4:2:2 / 4:2:0.  Same refusals as the grey reader, plus any other chroma layout: R3D_ERR_UNSUPPORTED (the Python
+ * 4:4:4 / 4:2:2 / 4:2:0.  (That is libjpeg-turbo's / libjpeg 6b's decoder, the one in current Pillow wheels and in OpenCV; IJG
+ * libjpeg 7+ upsamples subsampled chroma in the DCT domain and gives slightly different COLOURS for 4:2:x files.)
+ * Same refusals as the grey reader, plus any other chroma layout: R3D_ERR_UNSUPPORTED (the Python
  * host then lets PIL decode, which IS the reference's reader for colour).  *components = 1 or 3. */
 int r3d_jpeg_rgb_info(const char* path, int* height, int* width, int* components);
 int r3d_jpeg_rgb_decode_batch(const char* const* paths, int n_files, unsigned char* h_out, int height, int width);
