@@ -87,6 +87,46 @@ inline int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// One scanline's filter undone (PNG spec 9.2): row = filtered + predictor(left, up, upper left), bytes `bpp` apart; the row above
+// is all zeros for the first line.  One loop per filter type (the type is a property of the line, not of the byte): Up is a
+// plain vector add, Sub / Average / Paeth carry a dependency from `bpp` bytes back.
+inline bool unfilter_row(int filter, const unsigned char* __restrict src, unsigned char* __restrict row,
+                         const unsigned char* __restrict up, size_t stride, size_t bpp) {
+  switch (filter) {
+    case 0:
+      memcpy(row, src, stride);
+      return true;
+    case 1:
+      for (size_t x = 0; x < bpp && x < stride; ++x) row[x] = src[x];
+      for (size_t x = bpp; x < stride; ++x) row[x] = (unsigned char)(src[x] + row[x - bpp]);
+      return true;
+    case 2:
+      if (!up) {
+        memcpy(row, src, stride);
+      } else {
+        for (size_t x = 0; x < stride; ++x) row[x] = (unsigned char)(src[x] + up[x]);
+      }
+      return true;
+    case 3:
+      for (size_t x = 0; x < stride; ++x) {
+        const int a = x >= bpp ? row[x - bpp] : 0, b = up ? up[x] : 0;
+        row[x] = (unsigned char)(src[x] + ((a + b) >> 1));
+      }
+      return true;
+    case 4:
+      if (!up) {   // predictor = left
+        for (size_t x = 0; x < bpp && x < stride; ++x) row[x] = src[x];
+        for (size_t x = bpp; x < stride; ++x) row[x] = (unsigned char)(src[x] + row[x - bpp]);
+      } else {
+        for (size_t x = 0; x < bpp && x < stride; ++x) row[x] = (unsigned char)(src[x] + up[x]);   // paeth(0, b, 0) = b
+        for (size_t x = bpp; x < stride; ++x) row[x] = (unsigned char)(src[x] + paeth(row[x - bpp], up[x], up[x - bpp]));
+      }
+      return true;
+    default:
+      return false;
+  }
+}
+
 // Inflate + unfilter one non-interlaced PNG: `pixels` receives height rows of `stride` bytes (no filter bytes).
 // channels_out = samples per pixel in the file (1 grey, 2 grey+alpha, 3 RGB, 4 RGBA).  Palette / interlace / sub-byte
 // depths -> R3D_ERR_UNSUPPORTED.  header_only: stop after IHDR checks.
@@ -127,24 +167,10 @@ int decode_png(const char* path, bool header_only, PngInfo* info, int* channels_
   unsigned char* dst = pixels->data();
   for (uint32_t y = 0; y < info->height; ++y) {
     const unsigned char* src = &raw[(stride + 1) * y];
-    const int filter = src[0];
     unsigned char* row = dst + stride * y;
-    const unsigned char* up = y ? row - stride : nullptr;
-    ++src;
-    for (size_t x = 0; x < stride; ++x) {
-      const int a = x >= bpp ? row[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
-      int v = src[x];
-      switch (filter) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += b; break;
-        case 3: v += (a + b) >> 1; break;
-        case 4: v += paeth(a, b, c); break;
-        default:
-          *msg = std::string("'") + path + "': bad PNG filter type";
-          return R3D_ERR_INVALID;
-      }
-      row[x] = (unsigned char)v;
+    if (!unfilter_row(src[0], src + 1, row, y ? row - stride : nullptr, stride, bpp)) {
+      *msg = std::string("'") + path + "': bad PNG filter type";
+      return R3D_ERR_INVALID;
     }
   }
   return R3D_OK;
