@@ -862,3 +862,76 @@ def test_batches_of_mixed_formats_are_read_file_by_file(R, tmp_path):
     with pytest.raises(FileNotFoundError) as e:
         R.cloud_io.read_rgb_batch(paths + [str(tmp_path / "gone.jpg")])
     assert "gone.jpg" in str(e.value)
+
+
+def _png_with_filter(path, img, bit_depth, filter_type):
+    """A PNG whose every scanline uses ONE filter type (encoders choose per line; this pins each of the five)."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    colour_type = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    rows = img.astype(">u2" if bit_depth == 16 else np.uint8).reshape(h, -1).view(np.uint8).astype(np.int64)   # bytes of each line
+    bpp = ch * bit_depth // 8
+    out = bytearray()
+    prev = np.zeros(rows.shape[1], np.int64)
+    for y in range(h):
+        cur = rows[y]
+        left = np.concatenate([np.zeros(bpp, np.int64), cur[:-bpp]])
+        upleft = np.concatenate([np.zeros(bpp, np.int64), prev[:-bpp]])
+        if filter_type == 0:
+            pred = np.zeros_like(cur)
+        elif filter_type == 1:
+            pred = left
+        elif filter_type == 2:
+            pred = prev
+        elif filter_type == 3:
+            pred = (left + prev) >> 1
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        out.append(filter_type)
+        out += ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, colour_type, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(bytes(out), 6)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("filter_type", [0, 1, 2, 3, 4])
+def test_png_unfilter_every_type_and_pixel_size(R, tmp_path, filter_type):
+    """The five PNG line filters x bytes per pixel 1 (grey 8), 2 (grey 16 / grey+alpha), 3 (RGB), 4 (RGBA), 6 (RGB 16),
+    8 (RGBA 16): files written with one filter type on every line, read back through the native decoders and through PIL."""
+    from PIL import Image
+    rng = np.random.default_rng(filter_type)
+    yy, xx = np.mgrid[0:23, 0:37]
+    smooth = ((np.sin(xx / 5.0) + np.cos(yy / 3.0) + 2) * 60).astype(np.int64)
+    cases = [(smooth.astype(np.uint8), 8), ((smooth * 250 + rng.integers(0, 9, smooth.shape)).astype(np.uint16), 16),
+             (np.stack([smooth, 255 - smooth], 2).astype(np.uint8), 8),
+             (np.stack([smooth, smooth // 2, rng.integers(0, 256, smooth.shape)], 2).astype(np.uint8), 8),
+             (rng.integers(0, 256, smooth.shape + (4,), dtype=np.uint8), 8),
+             (rng.integers(0, 65536, smooth.shape + (3,)).astype(np.uint16), 16),
+             (rng.integers(0, 65536, smooth.shape + (4,)).astype(np.uint16), 16)]
+    for k, (img, depth) in enumerate(cases):
+        p = str(tmp_path / ("f%d_%d.png" % (filter_type, k)))
+        _png_with_filter(p, img, depth, filter_type)
+        pil = np.asarray(Image.open(p))
+        assert pil.shape[:2] == img.shape[:2]
+        got = R.cloud_io.read_depth_gray(p)                          # IMREAD_GRAYSCALE semantics through the native decoder
+        if img.ndim == 2 and depth == 8:
+            np.testing.assert_array_equal(got, img)
+        elif img.ndim == 2:
+            np.testing.assert_array_equal(got, (img >> 8).astype(np.uint8))
+        elif depth == 8 and img.shape[2] in (3, 4):
+            np.testing.assert_array_equal(R.cloud_io.read_rgb_batch([p])[0], img[..., :3])
+            np.testing.assert_array_equal(got, R.cloud_io.rgb_to_gray(img[..., :3], "opencv_png"))
+        elif depth == 8:                                             # grey + alpha: alpha dropped
+            np.testing.assert_array_equal(got, img[..., 0])
+        else:                                                        # 16-bit colour: libpng's 16-bit rule (rounds), then the high byte
+            r, g, b = (img[..., c].astype(np.int64) for c in range(3))
+            g16 = np.where((r == g) & (g == b), r, (9797 * r + 19234 * g + 3737 * b + 16384) >> 15)
+            np.testing.assert_array_equal(got, (g16 >> 8).astype(np.uint8))
