@@ -10,6 +10,7 @@
 // so PCIe runs at its pinned rate and the pageable copies are spread over host threads.  Buffers that are
 // already pinned (r3d_host_alloc, or hipHostRegister'ed by the caller) skip the staging copies.
 #include <algorithm>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -18,25 +19,41 @@
 
 namespace {
 
-void parallel_memcpy(void* dst, const void* src, size_t bytes, unsigned n_threads) {
-  if (bytes < ((size_t)4 << 20) || n_threads <= 1) {
-    memcpy(dst, src, bytes);
-    return;
-  }
-  const r3d_host::Spread spread;
-  std::vector<std::thread> pool;
-  const size_t per = ((bytes / n_threads) + 4095) & ~(size_t)4095;
-  for (unsigned t = 0; t < n_threads; ++t) {
-    const size_t lo = (size_t)t * per;
-    if (lo >= bytes) break;
-    const size_t n = std::min(per, bytes - lo);
-    pool.emplace_back([=, &spread]() {
-      spread.place(t);   // the creator only waits
-      memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, n);
+// How many threads share a chunk's pageable <-> pinned copy.  A 32 MiB chunk is ~1 ms of copying for ONE thread pair of
+// streams; what the copy competes with is not bandwidth but the hand-over (wake the crew, wait for the last member): on the
+// box C2's pageable round trip took 11.8-13.7 ms with 6-8 members, 13.7-14.5 with 16, 13.9 with 32, 16.9 with 2 (pinned
+// buffers, no copies: 11.3).
+constexpr unsigned kCopyCrew = 8;
+
+// The call's crew, started when the first pageable copy needs it (pinned buffers never do).
+struct LazyCrew {
+  unsigned n_threads;
+  std::unique_ptr<r3d_host::Crew> crew;
+  // false: no thread to be had
+  bool copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < ((size_t)4 << 20) || n_threads <= 1) {
+      memcpy(dst, src, bytes);
+      return true;
+    }
+    if (!crew) {
+      try {
+        crew.reset(new r3d_host::Crew(n_threads));
+      } catch (const std::exception&) {
+        return false;
+      }
+    }
+    const unsigned n = crew->size();
+    // a member's share: ceil(bytes / n) rounded up to a page.  (Until round 4 this was floor(bytes / n) rounded up, which
+    // leaves up to n - 1 bytes at the end uncopied whenever bytes / n is itself a whole number of pages and bytes is not
+    // a multiple of n: e.g. 65536 k + 12 bytes over 16 threads.  tests/test_gpu_fusion.py pins such sizes now.)
+    const size_t per = (((bytes + n - 1) / n) + 4095) & ~(size_t)4095;
+    crew->run([=](unsigned t) {
+      const size_t lo = (size_t)t * per;
+      if (lo < bytes) memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, std::min(per, bytes - lo));
     });
+    return true;
   }
-  for (auto& th : pool) th.join();
-}
+};
 
 bool is_pinned(const void* p) {
   hipPointerAttribute_t attr;
@@ -71,8 +88,7 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
   R3D_REQUIRE(n_in >= 1 && n_in <= r3d_ctx::kPipeBufs && n_out >= 1 && n_out <= r3d_ctx::kPipeBufs,
               "host pipeline takes 1..%d arrays per direction", r3d_ctx::kPipeBufs);
   int rc;
-  unsigned n_threads = r3d_host::cpu_budget();
-  n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
+  LazyCrew crew{std::min(std::max(1u, r3d_host::cpu_budget()), kCopyCrew), nullptr};
   bool in_pinned[r3d_ctx::kPipeBufs], out_pinned[r3d_ctx::kPipeBufs];
   size_t big = 0;
   for (int k = 0; k < n_in; ++k) {
@@ -119,7 +135,7 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
       const size_t ib = ins[k].item_bytes;
       const char* src = static_cast<const char*>(ins[k].h) + (size_t)lo * ib;
       if (!in_pinned[k]) {
-        parallel_memcpy(pin_in[k][b], src, (size_t)n * ib, n_threads);
+        R3D_REQUIRE(crew.copy(pin_in[k][b], src, (size_t)n * ib), "no host thread for the staging copies");
         src = static_cast<const char*>(pin_in[k][b]);
       }
       r3d_wrote(ctx, static_cast<char*>(ins[k].d) + (size_t)lo * ib, (size_t)n * ib);   // fresh from the host
@@ -145,8 +161,8 @@ int r3d_host_pipeline_multi(r3d_ctx* ctx, int64_t n_items, const r3d_pipe_buf* i
     R3D_HIP(hipEventSynchronize(ev_done[b]));
     for (int k = 0; k < n_out; ++k)
       if (!out_pinned[k])
-        parallel_memcpy(static_cast<char*>(outs[k].h) + (size_t)lo * outs[k].item_bytes, pin_out[k][b],
-                        (size_t)n * outs[k].item_bytes, n_threads);
+        R3D_REQUIRE(crew.copy(static_cast<char*>(outs[k].h) + (size_t)lo * outs[k].item_bytes, pin_out[k][b], (size_t)n * outs[k].item_bytes),
+                    "no host thread for the staging copies");
     return R3D_OK;
   };
   // On ANY failure copies may still be in flight into the caller's buffers or the staging ring: quiesce both streams
@@ -176,8 +192,7 @@ int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t b
     return R3D_OK;
   }
   int rc;
-  unsigned n_threads = r3d_host::cpu_budget();
-  n_threads = n_threads == 0 ? 1 : std::min(n_threads, 16u);
+  LazyCrew crew{std::min(std::max(1u, r3d_host::cpu_budget()), kCopyCrew), nullptr};
   const size_t chunk = (size_t)32 << 20;
   void* pin[2] = {};
   for (int b = 0; b < 2; ++b)
@@ -194,7 +209,11 @@ int r3d_download_pageable(r3d_ctx* ctx, void* h_dst, const void* d_src, size_t b
       (void)hipStreamSynchronize(ctx->stream);
       return r3d_fail_hip(e, "download", __FILE__, __LINE__);
     }
-    parallel_memcpy(static_cast<char*>(h_dst) + lo, pin[c & 1], n, n_threads);
+    if (!crew.copy(static_cast<char*>(h_dst) + lo, pin[c & 1], n)) {
+      (void)hipStreamSynchronize(ctx->stream);
+      r3d_set_error("no host thread for the staging copies");
+      return R3D_ERR_NOMEM;
+    }
     return R3D_OK;
   };
   for (size_t c = 0; c < n_chunks; ++c) {

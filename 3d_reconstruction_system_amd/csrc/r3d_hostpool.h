@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,6 +94,83 @@ struct Spread {
     CPU_SET(cpus[(home + t) % (unsigned)n], &one);
     if (pthread_setaffinity_np(pthread_self(), sizeof(one), &one) == 0) pthread_setaffinity_np(pthread_self(), sizeof(allowed), &allowed);
   }
+};
+
+// Threads that live for ONE library call and take its many small jobs -- the 32 MiB chunks of a host pipeline, each copied
+// between pageable and pinned memory by all of them: starting sixteen threads per chunk cost more than the chunk's copy
+// (19 chunks of C2: 15.0 -> see DESIGN 5 for the figure).  run(work) calls work(t) for t in [0, size()) -- t = 0 on the
+// calling thread -- and returns when all are done.  Jobs must not throw.
+class Crew {
+ public:
+  explicit Crew(unsigned n) : n_(std::max(1u, n)) {
+    const Spread spread;
+    try {
+      for (unsigned t = 1; t < n_; ++t)
+        helpers_.emplace_back([this, t, spread]() {
+          spread.place(t);
+          loop(t);
+        });
+    } catch (...) {
+      stop();
+      throw;
+    }
+  }
+  ~Crew() { stop(); }
+  Crew(const Crew&) = delete;
+  Crew& operator=(const Crew&) = delete;
+  unsigned size() const { return n_; }
+  void run(const std::function<void(unsigned)>& work) {
+    if (helpers_.empty()) {
+      work(0);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      job_ = &work;
+      pending_ = (unsigned)helpers_.size();
+      ++generation_;
+    }
+    wake_.notify_all();
+    work(0);
+    std::unique_lock<std::mutex> lock(m_);
+    done_.wait(lock, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void loop(unsigned t) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)>* job;
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stopping_) return;
+        job = job_;
+      }
+      (*job)(t);
+      std::lock_guard<std::mutex> lock(m_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      stopping_ = true;
+      ++generation_;
+    }
+    wake_.notify_all();
+    for (auto& t : helpers_) t.join();
+    helpers_.clear();
+  }
+  const unsigned n_;
+  std::vector<std::thread> helpers_;
+  std::mutex m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(unsigned)>* job_ = nullptr;
+  uint64_t generation_ = 0;
+  unsigned pending_ = 0;
+  bool stopping_ = false;
 };
 
 // Scratch memory of the decoders (file bytes, inflated rows, component planes), recycled across frames AND batches.  A frame

@@ -282,6 +282,33 @@ def test_pinned_and_preallocated_outputs(R, ctx):
     del pin, pin_in, got
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbytes", [65536 * 192 + 12, 65536 * 128 + 1, 65536 * 130 + 15, (32 << 20) + 65536 * 64 + 7, 4 * 65536 * 16 + 3])
+def test_staging_copies_reach_the_last_byte(R, ctx, nbytes):
+    """The pageable <-> pinned copies of the host pipeline are split over host threads in page-rounded shares.  Sizes whose
+    per-thread share is a whole number of pages while the size is not a multiple of the thread count used to lose their last
+    few bytes (floor before rounding: found in round 4 by a race-detector test of the new crew).  Download into pageable
+    memory and the *_host fused path on a ragged single-row raster, byte for byte."""
+    rng = np.random.default_rng(nbytes)
+    src = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    buf = ctx.alloc(nbytes).upload(src)
+    try:
+        for _ in range(2):
+            np.testing.assert_array_equal(buf.download(np.uint8, nbytes), src)
+    finally:
+        buf.free()
+    if nbytes < 16 << 20:
+        depth = src.reshape(1, 1, nbytes)                                   # one frame, one row: the chunk IS the raster
+        q, t = np.array([[0.1, 0.2, 0.3, 0.9]]), np.array([[1.0, 2.0, 3.0]])
+        pin_in = ctx.pinned_empty(depth.shape, np.uint8)                    # pinned both ways: no staging copies at all
+        pin_in[...] = depth
+        pin_out = ctx.pinned_empty((nbytes, 3), np.float32)
+        R.fuse_frames(pin_in, q, t, out_dtype=np.float32, ctx=ctx, out=pin_out)
+        got = R.fuse_frames(depth, q, t, out_dtype=np.float32, ctx=ctx)      # pageable both ways
+        np.testing.assert_array_equal(got, pin_out)
+        del pin_in, pin_out
+
+
 def test_nonfinite_and_negative_f32_depth_propagate_like_numpy(R, ctx):
     """f32 rasters may carry NaN / inf / negative / zero: no masking in the reference, none here; IEEE semantics match."""
     rng = np.random.default_rng(13)
