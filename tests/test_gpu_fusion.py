@@ -487,11 +487,16 @@ def test_fuse_rgb_host_pipeline_many_chunks(R, ctx, odtype):
 def test_seeded_random_shape_sweep_every_kernel(R, ctx):
     """120 seeded random (F, H, W) -- frame sizes around the 1024-pixel tile (1023, 1024, 1025, multiples, primes), 1..7
     frames -- through every shipped kernel (3 depth types x f32/f64 xyz x pose / no pose x plain / colour) against the oracle.
-    Random shapes find what hand-picked ones do not: tile tails, frames that are not a multiple of the tile, 1-wide rasters."""
-    rng = np.random.default_rng(20260)
+    Random shapes find what hand-picked ones do not: tile tails, frames that are not a multiple of the tile, 1-wide rasters.
+    (tools/stress_random.py runs the same sweep under other seeds for as long as it is given.)"""
+    random_shape_sweep(R, ctx, 20260, 120)
+
+
+def random_shape_sweep(R, ctx, seed, cases):
+    rng = np.random.default_rng(seed)
     specials = [1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1021, 1023, 1024, 1025, 2047, 2048, 2049, 3071,
                 3072, 3073, 4095, 4096, 4097, 5003]
-    for case in range(120):
+    for case in range(cases):
         if case % 3 == 0:                                  # a frame of exactly / nearly k tiles, factored at random
             px = int(rng.choice(specials))
             divs = [d for d in range(1, px + 1) if px % d == 0]
