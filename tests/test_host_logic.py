@@ -935,3 +935,54 @@ def test_png_unfilter_every_type_and_pixel_size(R, tmp_path, filter_type):
             r, g, b = (img[..., c].astype(np.int64) for c in range(3))
             g16 = np.where((r == g) & (g == b), r, (9797 * r + 19234 * g + 3737 * b + 16384) >> 15)
             np.testing.assert_array_equal(got, (g16 >> 8).astype(np.uint8))
+
+
+def test_file_writers_across_slab_boundaries(R, tmp_path):
+    """The file writers format slab k + 1 while a helper thread writes slab k (8 M points per slab for the PLY, 4 M for the
+    coloured PLY and the txt): clouds a little over one and over two slabs must give the bytes of the in-memory formatters,
+    whose output is pinned to the reference's by the golden tests."""
+    rng = np.random.default_rng(9)
+    n = (8 << 20) + 12_345
+    xyz = (rng.normal(0, 30, (n, 3))).astype(np.float32)
+    p = tmp_path / "big.ply"
+    R.cloud_io.write_ply(str(p), xyz)
+    head = ("ply\n    format ascii 1.0\n    element vertex %d\n    property float x\n    property float y\n"
+            "    property float z\n    end_header\n    " % n).encode()
+    data = p.read_bytes()
+    assert data.startswith(head) and data.endswith(b"\n    ")
+    body = data[len(head):-5]
+    pos = 0
+    for lo in range(0, n, 1_000_003):                       # compare block by block: a block's text does not depend on its neighbours
+        want = R.cloud_io.format_ply(xyz[lo:lo + 1_000_003]).split(b"end_header\n    ", 1)[1][:-5]
+        assert body[pos:pos + len(want)] == want, lo
+        pos += len(want)
+    assert pos == len(body)
+    p.unlink()
+    m = 2 * (4 << 20) + 777                                  # two full slabs and a bit
+    t = tmp_path / "big.txt"
+    R.cloud_io.write_xyz_txt(str(t), xyz[:m])
+    data = t.read_bytes()
+    pos = 0
+    for lo in range(0, m, 1_000_003):
+        want = R.cloud_io.format_xyz_txt(xyz[lo:min(m, lo + 1_000_003)])
+        assert data[pos:pos + len(want)] == want, lo
+        pos += len(want)
+    assert pos == len(data)
+    t.unlink()
+    k = (4 << 20) + 4_321
+    rgb = rng.integers(0, 256, (k, 3), dtype=np.uint8)
+    c = tmp_path / "big_rgb.ply"
+    R.cloud_io.write_ply_rgb(str(c), xyz[:k], rgb)
+    lines = c.read_bytes().split(b"end_header\n    ", 1)[1]
+    # rows: the plain PLY's "x y z " followed by "R G B 0"
+    plain = R.cloud_io.format_ply(xyz[:k]).split(b"end_header\n    ", 1)[1][:-5].split(b" \n")
+    got_rows = lines[:-5].split(b"\n")
+    assert len(got_rows) == k + 0 or got_rows[-1] == b""
+    for i in (0, 1, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, k - 1):
+        assert got_rows[i] == plain[i] + b" %d %d %d 0" % tuple(int(v) for v in rgb[i]), i
+    import hashlib
+    want = hashlib.sha256()
+    for i0 in range(0, k, 500_000):
+        blk = b"".join(plain[i] + b" %d %d %d 0\n" % (rgb[i, 0], rgb[i, 1], rgb[i, 2]) for i in range(i0, min(k, i0 + 500_000)))
+        want.update(blk)
+    assert hashlib.sha256(lines[:-5]).hexdigest() == want.hexdigest()
