@@ -45,7 +45,10 @@ def quat_to_rinv(q_xyzw):
     normalised (SciPy does), rotation matrix, then a GENERAL matrix inverse (not a
     transpose).  Returns float64 [3,3]."""
     q = np.asarray(q_xyzw, dtype=np.float64)
-    n = np.sqrt(np.dot(q, q))
+    # SciPy normalises with scipy.linalg.norm(quat, axis=1) = sqrt(add.reduce(q * q)): the four squares added one after
+    # the other.  (np.dot(q, q) -- BLAS ddot -- sums them in another order and is an ulp off for one quaternion in eight:
+    # found in round 4 by tools/stress_dropin.py; tests/test_oracle_golden.py pins this function against SciPy itself now.)
+    n = np.sqrt(np.add.reduce(q * q))
     if n == 0.0:
         raise ValueError("zero-norm quaternion")
     x, y, z, w = q / n

@@ -146,3 +146,20 @@ def test_c1_192x640_digest(golden_dir, tmp_path):
     assert _sha(str(tmp_path / "cam_0.txt")) == g["sha256_cam_txt"]
     assert _sha(str(tmp_path / "world.txt")) == g["sha256_world_txt"]
     np.testing.assert_allclose(got, fused, rtol=0, atol=1e-12)
+
+
+def test_quat_to_rinv_is_scipys_on_quaternions_of_every_scale():
+    """c2w:53-55 through SciPy itself (importable here and on the GPU box): `np.matrix(R.from_quat(q).as_matrix()).I` for 20,000
+    random quaternions scaled over four decades (SciPy normalises; the order in which the four squares are added shows in
+    the last bit) against the oracle's restatement AND the product's (poses.scipy_transfer), bit for bit.  The golden
+    poses.json holds three quaternions: not enough to notice that an np.dot-based norm is an ulp off for one in eight."""
+    Rotation = pytest.importorskip("scipy.spatial.transform").Rotation
+    import importlib
+    from helpers import PKG
+    poses = importlib.import_module(PKG + ".poses")
+    rng = np.random.default_rng(31337)
+    for _ in range(20000):
+        q = rng.normal(size=4) * 10 ** rng.uniform(-2, 2)
+        want = np.asarray(np.matrix(Rotation.from_quat(q).as_matrix()).I)
+        assert np.array_equal(O.quat_to_rinv(q), want), q
+        assert np.array_equal(np.asarray(poses.scipy_transfer(q)), want), q
