@@ -1,6 +1,7 @@
 """The camera_to_world drop-in against the oracle's LOOPS (the reference's per-point Python, oracle/fusion_ref.py) on random
 small scenes: 1..4 frames of 1..48 x 1..64 pixels, 8-bit grey / 16-bit grey / colour PNG depth files, poses with unnormalised
-quaternions and translations of every magnitude.  Every file byte for byte: per-frame camera txt, world txt, fused PLY.
+quaternions and translations of every magnitude.  Per-frame camera txt and fused PLY byte for byte, the world txt to 1e-12 (its fp64 digits depend on the summation order of
+the reference's BLAS).
 usage: python tools/stress_dropin.py [seconds] [seed]"""
 import importlib
 import io
@@ -65,7 +66,12 @@ while time.time() - t0 < budget:
             O.gentxtcord_loop(cam, rasters[k])
             O.get_pointdata_loop(cam, quats[k], ts[k], xs, ys, zs, "./ref/world.txt")
             assert open("./point/%03d.txt" % k, "rb").read() == open(cam, "rb").read(), (seed, n, "camera txt", k, F, H, W, kind)
-        assert open("./point_world/small_worldpoint_5_23_5.txt", "rb").read() == open("./ref/world.txt", "rb").read(), (seed, n, "world txt", F, H, W, kind)
+        # world txt: fp64 values equal up to the summation order of the three-term dot product (the reference's is whatever
+        # its BLAS does in np.dot; the kernel's is fma(r2 dz, fma(r1 dy, r0 dx))) -- the tolerance of tests/test_gpu_dropin.py
+        got = O.read_xyz_txt("./point_world/small_worldpoint_5_23_5.txt")
+        want = O.read_xyz_txt("./ref/world.txt")
+        assert got.shape == want.shape and (np.abs(got - want) / (1 + np.linalg.norm(want, axis=1, keepdims=True))).max() <= 1e-12, \
+            (seed, n, "world txt", F, H, W, kind)
         O.genply_loop([xs, ys, zs], "./ref/fused.ply")
         assert open("./ply/small_035_p8.ply", "rb").read() == open("./ref/fused.ply", "rb").read(), (seed, n, "PLY", F, H, W, kind)
     finally:
