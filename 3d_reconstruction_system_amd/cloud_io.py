@@ -135,10 +135,50 @@ def read_depth_gray(path, rule=None, allow_pil_jpeg=None):
     return rgb_to_gray(np.array(pil.convert("RGB")), "cvtcolor")
 
 
-def read_depth_batch(paths, out=None, rule=None):
+def _jpeg_backend(backend):
+    """'native' (csrc/r3d_jpeg.cpp on the library's host threads) unless the caller asks for 'pil' (libjpeg-turbo through PIL on
+    a Python thread pool: the same bytes, tests/test_host_logic.py).  Measured round 5: per thread libjpeg-turbo is
+    ~2x faster, but PIL's grey (draft) decode does not scale over threads at all and its colour decode scales to the native
+    pool's rate at best (8 threads, 1080p: grey 9.1 vs 2.2 ms/file, colour 3.7 + copy vs 3.9), so native stays the default."""
+    backend = backend or "native"
+    if backend not in ("pil", "native"):
+        raise ValueError("JPEG backend must be 'native' or 'pil'")
+    return backend
+
+
+def _pil_jpeg_batch(paths, out, colour):
+    """A batch of baseline JPEGs through PIL's libjpeg-turbo on a thread pool (the decoder releases the GIL): grey = libjpeg
+    asked for greyscale output (draft 'L': the luma plane through the integer IDCT, OpenCV's IMREAD_GRAYSCALE request), colour
+    = Image.open(...).convert('RGB') (p2c:58-60).  Returns False when a file is not what the batch expects (size, flavour):
+    the caller then takes the native / file-by-file way, which also owns the error messages."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    want = out.shape[1:3]
+
+    def one(k):
+        with Image.open(paths[k]) as im:
+            if im.format != "JPEG" or im.size != (want[1], want[0]) or im.mode not in ("L", "RGB") or \
+                    (not colour and im.info.get("progressive")):     # grey from a progressive file: read_depth_gray's rule decides
+                return False
+            if not colour:
+                im.draft("L", im.size)
+            im = im.convert("RGB" if colour else "L")
+            if im.size != (want[1], want[0]):
+                return False
+            out[k] = np.asarray(im)
+        return True
+    workers = max(1, min(len(paths), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1, 64))
+    if workers == 1:
+        return all(one(k) for k in range(len(paths)))
+    with ThreadPoolExecutor(workers) as pool:
+        return all(pool.map(one, range(len(paths))))
+
+
+def read_depth_batch(paths, out=None, rule=None, jpeg_backend=None):
     """[F,H,W] raster batch for a list of depth files with IMREAD_GRAYSCALE meaning (c2w:160).  PNGs of any supported
-    flavour -- 8/16-bit, grey or colour (read_depth_gray has the rules) -- and sequential JPEGs are decoded by the library's
-    host threads straight into one contiguous (optionally pinned) buffer; other formats go file by file."""
+    flavour -- 8/16-bit, grey or colour (read_depth_gray has the rules) -- are decoded by the library's host threads straight
+    into one contiguous (optionally pinned) buffer; sequential JPEGs by the library's own decoder
+    (jpeg_backend='pil': libjpeg-turbo through PIL on a thread pool, same bytes); other formats go file by file."""
     paths = [os.fspath(p) for p in paths]
     if not paths:
         return np.empty((0, 0, 0), np.uint8)
@@ -149,6 +189,7 @@ def read_depth_batch(paths, out=None, rule=None):
         raise FileNotFoundError("cannot read depth image %r" % paths[0])
     kinds = {_kind(p) for p in paths}
     jpeg = kinds == {"jpeg"}
+    use_pil = jpeg and _jpeg_backend(jpeg_backend) == "pil"
     if jpeg:
         rc = lib.r3d_jpeg_gray_info(os.fsencode(paths[0]), C.byref(h), C.byref(w))
     elif kinds == {"png"}:
@@ -161,6 +202,8 @@ def read_depth_batch(paths, out=None, rule=None):
             out = np.empty(shape, np.uint8)
         elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
+        if use_pil and _pil_jpeg_batch(paths, out, colour=False):
+            return out
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
         if jpeg:
             rc = lib.r3d_jpeg_gray_decode_batch(arr, len(paths), out.ctypes.data, h.value, w.value)
@@ -183,11 +226,12 @@ def read_depth_batch(paths, out=None, rule=None):
     return np.stack(rasters)
 
 
-def read_rgb_batch(paths, out=None):
+def read_rgb_batch(paths, out=None, jpeg_backend=None):
     """[F,H,W,3] uint8 (R,G,B) for a list of colour images -- the colour planes of the RGBD path (fuse_frames_rgb).
-    8-bit RGB / RGBA / grey PNGs and sequential YCbCr / grey JPEGs (4:4:4, 4:2:2, 4:2:0 -- the bytes PIL's Image.open gives,
-    which is what the reference reads colour with, p2c:58-60) are decoded by the library's host threads into one contiguous
-    (optionally pinned) buffer; anything else goes through PIL file by file."""
+    8-bit RGB / RGBA / grey PNGs are decoded by the library's host threads into one contiguous (optionally pinned) buffer;
+    sequential YCbCr / grey JPEGs (4:4:4, 4:2:2, 4:2:0) give the bytes PIL's Image.open gives, which is what the reference
+    reads colour with (p2c:58-60) -- through the library's decoder, or PIL itself on a thread pool (jpeg_backend='pil', same
+    bytes); anything else (BMP, TIFF, mixed lists, ...) goes through PIL file by file."""
     paths = [os.fspath(p) for p in paths]
     if not paths:
         return np.empty((0, 0, 0, 3), np.uint8)
@@ -198,14 +242,21 @@ def read_rgb_batch(paths, out=None):
         if not os.path.exists(p):
             raise FileNotFoundError("cannot read image %r" % p)
     jpeg = kinds == {"jpeg"}
-    info = lib.r3d_jpeg_rgb_info if jpeg else lib.r3d_png_rgb_info
-    rc = info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch)) if len(kinds) == 1 else L.ERR_UNSUPPORTED   # mixed: PIL below
+    if jpeg:
+        rc = lib.r3d_jpeg_rgb_info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch))
+    elif kinds == {"png"}:
+        rc = lib.r3d_png_rgb_info(os.fsencode(paths[0]), C.byref(h), C.byref(w), C.byref(ch))
+    else:
+        rc = L.ERR_UNSUPPORTED                                     # other or mixed formats: PIL below, as the reference does
+    use_pil = jpeg and _jpeg_backend(jpeg_backend) == "pil"
     if rc == L.OK:
         shape = (len(paths), h.value, w.value, 3)
         if out is None:
             out = np.empty(shape, np.uint8)
         elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
+        if use_pil and _pil_jpeg_batch(paths, out, colour=True):
+            return out
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
         decode = lib.r3d_jpeg_rgb_decode_batch if jpeg else lib.r3d_png_rgb_decode_batch
         rc = decode(arr, len(paths), out.ctypes.data, h.value, w.value)

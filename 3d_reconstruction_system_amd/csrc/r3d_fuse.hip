@@ -831,6 +831,13 @@ int r3d_fuse_frames_voxel(r3d_ctx* ctx, const r3d_camera* cam, const void* d_dep
   R3D_REQUIRE(vs != nullptr, "voxel set is NULL");
   R3D_REQUIRE((d_rgb == nullptr) == (d_rgba_out == nullptr), "colour needs both the rgb plane and the rgba output");
   R3D_REQUIRE(ctx != nullptr && cam != nullptr, "NULL argument");
+  {  // the set's stream must be this ctx's: the probe below samples and inserts on it right behind the fuse
+    r3d_ctx* vctx = nullptr;
+    VoxelView view;
+    int rc = r3d_voxelset_device_view(vs, &vctx, &view.factor, &view.table, &view.log2cap, &view.counters);
+    if (rc) return rc;
+    R3D_REQUIRE(vctx == ctx, "voxel set belongs to a different ctx");
+  }
   const bool with_pose = d_pose != nullptr;
   // Which form is faster depends on the CLOUD: where neighbouring pixels share voxels (scans) the one-launch kernel saves
   // reading the cloud back; where nearly every point has a voxel of its own, its per-point CAS into the table is the whole cost

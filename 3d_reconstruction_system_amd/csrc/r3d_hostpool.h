@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -177,7 +178,7 @@ class Crew {
 // needs a few buffers of 0.5 ... 6 MB; as fresh std::vectors each is an mmap, a run of first-touch page faults and a munmap
 // -- per frame and thread, all of them through the process's one address-space lock.  With recycled buffers a worker touches
 // fresh pages once per process, not once per frame.  Vectors keep their capacity; users clear() / resize() them as if they
-// were new.  At most kKeep scratches of at most kKeepBytes each are held.
+// were new.  At most kKeep scratches of at most kKeepBytes each, and at most kKeepTotal bytes over all of them, are held.
 struct Scratch {
   std::vector<unsigned char> buf[6];
   size_t capacity() const {
@@ -186,9 +187,10 @@ struct Scratch {
     return c;
   }
 };
-constexpr size_t kKeep = 64, kKeepBytes = (size_t)256 << 20;
+constexpr size_t kKeep = 64, kKeepBytes = (size_t)256 << 20, kKeepTotal = (size_t)1 << 30;
 inline std::mutex g_scratch_mutex;
 inline std::vector<std::unique_ptr<Scratch>> g_scratch_free;
+inline size_t g_scratch_held = 0;   // capacity of everything on the free list (under g_scratch_mutex)
 inline thread_local Scratch* t_scratch = nullptr;
 
 // The calling thread holds a scratch for the lifetime of the outermost ScratchScope on its stack.
@@ -201,6 +203,7 @@ struct ScratchScope {
       if (!g_scratch_free.empty()) {
         t_scratch = g_scratch_free.back().release();
         g_scratch_free.pop_back();
+        g_scratch_held -= std::min(g_scratch_held, t_scratch->capacity());
       }
     }
     if (!t_scratch) t_scratch = new Scratch;
@@ -210,9 +213,13 @@ struct ScratchScope {
     if (!own) return;
     std::unique_ptr<Scratch> s(t_scratch);
     t_scratch = nullptr;
-    if (s->capacity() > kKeepBytes) return;
+    const size_t cap = s->capacity();
+    if (cap > kKeepBytes) return;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (g_scratch_free.size() < kKeep) g_scratch_free.push_back(std::move(s));
+    if (g_scratch_free.size() < kKeep && g_scratch_held + cap <= kKeepTotal) {
+      g_scratch_held += cap;
+      g_scratch_free.push_back(std::move(s));
+    }
   }
   ScratchScope(const ScratchScope&) = delete;
   ScratchScope& operator=(const ScratchScope&) = delete;
@@ -251,7 +258,14 @@ inline int run_batch(int n_files, const char* what, F&& decode_one) {
     }
   };
   std::vector<std::thread> pool;
-  for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+  pool.reserve(n_threads);
+  for (unsigned t = 1; t < n_threads; ++t) {
+    try {
+      pool.emplace_back(worker, t);
+    } catch (const std::system_error&) {   // EAGAIN under a pids limit: the batch goes on with the workers it has
+      break;
+    }
+  }
   worker(0);
   for (auto& t : pool) t.join();
   if (first_rc.load() != R3D_OK) {

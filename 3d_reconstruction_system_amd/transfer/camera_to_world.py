@@ -50,19 +50,31 @@ def point_camera(p1, r_inverse, t):
     return np.array(p_world.T)
 
 
-def read_pfm(path):
-    """Portable Float Map -> float32 array (what cv.imread returns for a .pfm): 'Pf'/'PF' header, width height,
-    scale (negative = little endian), rows stored bottom-up."""
+def read_pfm(path, unchanged=False):
+    """Portable Float Map as `cv.imread(path)` returns it with DEFAULT flags (c2w:35): uint8 H x W x 3, BGR -- the float
+    samples divided by |scale|, rows flipped to top-down, grey replicated to three channels, then saturate_cast<uchar>
+    (round half to even, clamp to 0..255).  Restated from OpenCV's PFM reader (modules/imgcodecs/src/grfmt_pfm.cpp) and
+    imread's "no IMREAD_ANYDEPTH => 8 bit" rule; cv2 is not in this image, so it is pinned by formula only.
+    unchanged=True gives the float32 samples instead (IMREAD_UNCHANGED: H x W, or H x W x 3 in BGR order)."""
     with open(path, 'rb') as f:
         kind = f.readline().strip()
         if kind not in (b'Pf', b'PF'):
             raise ValueError("%s is not a PFM file" % path)
         w, h = [int(v) for v in f.readline().split()]
         scale = float(f.readline().strip())
+        if scale == 0.0:
+            raise ValueError("%s: PFM scale factor 0" % path)
         ch = 3 if kind == b'PF' else 1
         data = np.frombuffer(f.read(w * h * ch * 4), dtype='<f4' if scale < 0 else '>f4').astype(np.float32)
-    img = data.reshape(h, w, ch)[::-1]
-    return np.ascontiguousarray(img[:, :, ::-1] if ch == 3 else img[:, :, 0])      # colour: BGR like OpenCV
+    img = data.reshape(h, w, ch)[::-1] * np.float32(1.0 / abs(scale))
+    img = img[:, :, ::-1] if ch == 3 else img[:, :, 0]                              # colour: BGR like OpenCV
+    if unchanged:
+        return np.ascontiguousarray(img, dtype=np.float32)
+    if ch == 1:
+        img = np.repeat(img[:, :, None], 3, axis=2)
+    with np.errstate(invalid='ignore'):
+        u8 = np.clip(np.rint(np.nan_to_num(img, nan=0.0)), 0, 255).astype(np.uint8)  # np.rint rounds half to even, as cvRound
+    return np.ascontiguousarray(u8)
 
 
 def sfm2npy(transfer_name):
@@ -147,8 +159,10 @@ def _get_file_name_sharded(qt_path):
     names, lo, hi, depths, world = D.fuse_pose_file_sharded(qt_path, './depth/', _common.intrinsics(), np.float64, ctx, comm,
                                                             pose_scale=_common.pose_scale())
     n_frames = len(names)
-    ply_done = _ply_in_background(world, './ply/small_035_p8.ply') if comm.rank == 0 else None
+    ply_done = None
     try:        # a rank that fails while writing its files must still meet the others at the barrier, then raise
+        if comm.rank == 0:
+            ply_done = _ply_in_background(world, './ply/small_035_p8.ply')
         if n_frames and not _common.skip_intermediate():
             if hi > lo:
                 per = depths.shape[1] * depths.shape[2]
@@ -164,10 +178,22 @@ def _get_file_name_sharded(qt_path):
     finally:
         try:
             if ply_done is not None:
-                ply_done()
+                _finish_ply(ply_done)
         finally:
             comm.barrier()                         # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
             comm.close()
+
+
+def _finish_ply(ply_done):
+    """Wait for the background PLY from a `finally`: its error is raised only when nothing else is already propagating (the
+    first failure is the one the caller should see)."""
+    import sys
+    if sys.exc_info()[0] is None:
+        return ply_done()
+    try:
+        ply_done()
+    except Exception:
+        pass
 
 
 def _ply_in_background(world, pc_file):
@@ -210,7 +236,7 @@ def get_file_name(qt_path):
         print('##################')
         print("%d frames cost ." % n_frames, t2 - t1)
     finally:
-        ply_done()
+        _finish_ply(ply_done)
         _common.stamp("rest of the PLY")
 
 

@@ -179,17 +179,33 @@ def test_coloured_ply_matches_reference_bytes(R, golden_dir, tmp_path):
 
 
 def test_sfm2npy_helper(tmp_path, monkeypatch):
-    """c2w:32-38 surface completeness: PFM (bottom-up float rows) -> npy."""
+    """c2w:32-38 surface completeness: PFM (bottom-up float rows) -> npy of what cv.imread(path) gives with DEFAULT flags:
+    uint8 H x W x 3 (no IMREAD_ANYDEPTH => saturate_cast<uchar>, round half to even; grey replicated; colour in BGR order;
+    samples divided by |scale|).  The float samples stay reachable through read_pfm(..., unchanged=True)."""
     c2w = importlib.import_module(PKG + ".transfer.camera_to_world")
     monkeypatch.chdir(tmp_path)
     os.makedirs("pfm")
     os.makedirs("npy")
-    img = np.arange(12, dtype=np.float32).reshape(3, 4) / 7
+    img = np.array([[0.5, 1.5, 2.5, 3.49], [-3.0, 254.5, 255.5, 300.0], [7.0, 8.25, 9.75, 100.0]], np.float32)
     with open("pfm/a.pfm", "wb") as f:
         f.write(b"Pf\n4 3\n-1.0\n")
         f.write(img[::-1].astype("<f4").tobytes())
     assert c2w.sfm2npy("a") == "./npy/a.npy"
-    np.testing.assert_array_equal(np.load("npy/a.npy"), img)
+    got = np.load("npy/a.npy")
+    want = np.array([[0, 2, 2, 3], [0, 254, 255, 255], [7, 8, 10, 100]], np.uint8)
+    assert got.dtype == np.uint8 and got.shape == (3, 4, 3)
+    for c in range(3):
+        np.testing.assert_array_equal(got[:, :, c], want)
+    np.testing.assert_array_equal(c2w.read_pfm("pfm/a.pfm", unchanged=True), img)
+    # big-endian colour file with a scale factor: samples / |scale|, channels reversed to BGR
+    rgb = np.stack([img, img + 10, img + 20], 2)
+    with open("pfm/c.pfm", "wb") as f:
+        f.write(b"PF\n4 3\n2.0\n")
+        f.write((rgb[::-1] * 2).astype(">f4").tobytes())
+    np.testing.assert_array_equal(c2w.read_pfm("pfm/c.pfm", unchanged=True), rgb[:, :, ::-1])
+    got = c2w.read_pfm("pfm/c.pfm")
+    np.testing.assert_array_equal(got[:, :, 2], want)                  # R is the last channel
+    np.testing.assert_array_equal(got[:, :, 0], np.clip(np.rint(img + 20), 0, 255).astype(np.uint8))
 
 
 def test_read_xyz_txt_takes_first_three_fields_and_names_bad_lines(R, tmp_path):
@@ -610,10 +626,11 @@ def test_native_jpeg_grey_equals_libjpeg_byte_for_byte(R, tmp_path, hw):
     assert len(paths) >= 9
     for p in paths:
         np.testing.assert_array_equal(R.cloud_io.read_depth_gray(p), _pil_luma(p), err_msg=p)
-    got = R.cloud_io.read_depth_batch(paths)
-    assert got.shape == (len(paths), H, W)
-    for k, p in enumerate(paths):
-        np.testing.assert_array_equal(got[k], _pil_luma(p))
+    for backend in ("native", "pil", None):          # the library's decoder, libjpeg-turbo on a thread pool, the default choice
+        got = R.cloud_io.read_depth_batch(paths, jpeg_backend=backend)
+        assert got.shape == (len(paths), H, W)
+        for k, p in enumerate(paths):
+            np.testing.assert_array_equal(got[k], _pil_luma(p), err_msg="%s %s" % (backend, p))
 
 
 def test_native_jpeg_refuses_what_it_does_not_restate(R, tmp_path):
@@ -674,10 +691,11 @@ def test_native_jpeg_colour_equals_pil_byte_for_byte(R, tmp_path, hw):
     Image.fromarray(img[..., 0], "L").save(p, quality=80)
     paths.append(p)
     assert len(paths) >= 4
-    got = R.cloud_io.read_rgb_batch(paths)
-    assert got.shape == (len(paths), H, W, 3) and got.dtype == np.uint8
-    for k, p in enumerate(paths):
-        np.testing.assert_array_equal(got[k], np.asarray(Image.open(p).convert("RGB")), err_msg=p)
+    for backend in ("native", "pil", None):
+        got = R.cloud_io.read_rgb_batch(paths, jpeg_backend=backend)
+        assert got.shape == (len(paths), H, W, 3) and got.dtype == np.uint8
+        for k, p in enumerate(paths):
+            np.testing.assert_array_equal(got[k], np.asarray(Image.open(p).convert("RGB")), err_msg="%s %s" % (backend, p))
 
 
 def test_native_jpeg_colour_refusals_fall_back_to_pil(R, tmp_path):
@@ -700,6 +718,15 @@ def test_native_jpeg_colour_refusals_fall_back_to_pil(R, tmp_path):
     got = R.cloud_io.read_rgb_batch([str(tmp_path / "s.jpg"), str(tmp_path / "p.jpg")])
     for k, n in enumerate(("s.jpg", "p.jpg")):
         np.testing.assert_array_equal(got[k], np.asarray(Image.open(tmp_path / n).convert("RGB")))
+    # formats that are neither PNG nor JPEG go to PIL, alone or mixed with others (the reference opens any colour image with
+    # Image.open, p2c:58-60)
+    Image.fromarray(img, "RGB").save(tmp_path / "c.bmp")
+    Image.fromarray(img, "RGB").save(tmp_path / "c.tiff")
+    Image.fromarray(img, "RGB").save(tmp_path / "c.png")
+    for names in (["c.bmp"], ["c.tiff"], ["c.bmp", "c.tiff"], ["c.png", "c.bmp"]):
+        got = R.cloud_io.read_rgb_batch([str(tmp_path / n) for n in names])
+        for k in range(len(names)):
+            np.testing.assert_array_equal(got[k], img)
     (tmp_path / "t.jpg").write_bytes(b"\xff\xd8\xff\xe0\x00\x10JFIF")
     assert lib.r3d_jpeg_rgb_info(os.fsencode(str(tmp_path / "t.jpg")), C.byref(h), C.byref(w), C.byref(c)) == L.ERR_INVALID
     with pytest.raises(R.R3DError):
