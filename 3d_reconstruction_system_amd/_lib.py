@@ -108,6 +108,7 @@ SIGNATURES = {
     "r3d_comm_create": (_i, [_vp, _vp, _i, _i, _pvp]),
     "r3d_comm_destroy": (_i, [_vp]),
     "r3d_comm_info": (_i, [_vp, _pi, _pi, C.POINTER(C.c_char_p)]),
+    "r3d_comm_rccl_report": (_i, [_vp, _pi, _pi, _pi, _pi]),
     "r3d_comm_allgather": (_i, [_vp, _vp, _vp, _vp, _i]),
     "r3d_allgather_xyz": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
     "r3d_allgather_inputs": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),

@@ -183,6 +183,14 @@ class Comm:
         L.check(self.ctx.lib.r3d_comm_info(self.handle, None, None, C.byref(s)))
         return (s.value or b"").decode()
 
+    def rccl_report(self):
+        """What the communicator says about itself -- ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion
+        (-1 where the bound library lacks the call) -- beside what the caller passed in."""
+        v = [C.c_int(-1) for _ in range(4)]
+        L.check(self.ctx.lib.r3d_comm_rccl_report(self.handle, *[C.byref(x) for x in v]))
+        return {"world": v[0].value, "rank": v[1].value, "device": v[2].value, "version": v[3].value,
+                "world_passed_in": self.world, "origin": self.rccl_origin()}
+
     @staticmethod
     def _counts(counts, world):
         a = np.ascontiguousarray(counts, dtype=np.int64)

@@ -46,6 +46,11 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (r3d_comm_rccl_report): what the communicator says about itself
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
 RcclApi g_api;
@@ -100,6 +105,10 @@ void load_rccl() {
   R3D_SYM(GroupEnd, "ncclGroupEnd")
   R3D_SYM(GetErrorString, "ncclGetErrorString")
 #undef R3D_SYM
+  *(void**)(&a.CommCount) = dlsym(h, "ncclCommCount");
+  *(void**)(&a.CommUserRank) = dlsym(h, "ncclCommUserRank");
+  *(void**)(&a.CommCuDevice) = dlsym(h, "ncclCommCuDevice");
+  *(void**)(&a.GetVersion) = dlsym(h, "ncclGetVersion");
   g_api = a;
 }
 
@@ -193,6 +202,18 @@ int r3d_comm_info(const r3d_comm* comm, int* rank_out, int* world_out, const cha
   if (rank_out) *rank_out = comm->rank;
   if (world_out) *world_out = comm->world;
   if (rccl_origin_out) *rccl_origin_out = g_api.origin;
+  return R3D_OK;
+}
+
+int r3d_comm_rccl_report(const r3d_comm* comm, int* count_out, int* user_rank_out, int* device_out, int* version_out) {
+  R3D_REQUIRE(comm != nullptr && comm->comm != nullptr, "comm is NULL");
+  const RcclApi* api = rccl();
+  if (!api) return R3D_ERR_UNSUPPORTED;
+  int v = -1;
+  if (count_out) *count_out = (api->CommCount && api->CommCount(comm->comm, &v) == ncclSuccess) ? v : -1;
+  if (user_rank_out) *user_rank_out = (api->CommUserRank && api->CommUserRank(comm->comm, &v) == ncclSuccess) ? v : -1;
+  if (device_out) *device_out = (api->CommCuDevice && api->CommCuDevice(comm->comm, &v) == ncclSuccess) ? v : -1;
+  if (version_out) *version_out = (api->GetVersion && api->GetVersion(&v) == ncclSuccess) ? v : -1;
   return R3D_OK;
 }
 

@@ -373,6 +373,9 @@ int r3d_comm_create(r3d_ctx* ctx, const void* id, int rank, int world, r3d_comm*
 int r3d_comm_destroy(r3d_comm* comm);
 /* any out pointer may be NULL; *rccl_origin_out says which librccl was bound */
 int r3d_comm_info(const r3d_comm* comm, int* rank_out, int* world_out, const char** rccl_origin_out);
+/* What the communicator says about ITSELF: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion (-1 where the
+ * bound library lacks the call); any out pointer may be NULL. */
+int r3d_comm_rccl_report(const r3d_comm* comm, int* count_out, int* user_rank_out, int* device_out, int* version_out);
 /* All-gather of byte shards of possibly UNEQUAL length: rank r's h_counts[r] bytes land at offset sum(h_counts[0..r))
  * of d_recv on every rank (rank order = pose-file order).  d_send may already be this rank's slot of d_recv (in place).
  * algo: R3D_GATHER_AUTO (ncclAllGather when the shards are equal, else direct), R3D_GATHER_NCCL (equal shards only),

@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE, not product code: a stand-in for librccl that moves bytes between PROCESSES THAT SHARE ONE GPU
 // through files in /dev/shm, so that the N > 1 logic of csrc/r3d_comm.hip (shard offsets, ragged shards, in-place slots,
 // the direct send/recv schedule, the all-reduce) runs for real on the one-GPU test box, where RCCL itself refuses two
-// ranks on one device.  Loaded through R3D_RCCL_PATH; implements exactly the ten symbols r3d_comm.hip binds.
+// ranks on one device.  Loaded through R3D_RCCL_PATH; implements the ten symbols r3d_comm.hip needs and two of
+// the four optional ones (ncclCommCount, ncclCommUserRank; ncclCommCuDevice / ncclGetVersion are left out on purpose: -1).
 // Semantics kept from NCCL: rank order, in-place all-gather when sendbuff == recvbuff + rank*count, grouped p2p without
 // deadlock.  Not kept: asynchrony (every call synchronises the stream), speed.
 #include <hip/hip_runtime.h>
@@ -131,6 +132,16 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   delete comm;
+  return ncclSuccess;
+}
+
+// the communicator's own account of itself (r3d_comm_rccl_report binds these when the library has them)
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+  *count = comm->world;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+  *rank = comm->rank;
   return ncclSuccess;
 }
 

@@ -95,6 +95,10 @@ def test_bench_four_ranks_as_the_driver_launches_it(mock_rccl):
     assert d["n_gpus"] == 4 and "R3D_RCCL_PATH" in d["transport"] and "watchdog" not in d
     for m in ("none", "outputs", "inputs", "outputs_direct", "inputs_direct", "inputs_overlap"):
         assert "ms_per_step" in d["assemble"][m], (m, d["assemble"][m])
+        assert d["assemble"][m]["same_bits_as_single_launch"] is True, (m, d["assemble"][m])      # EVERY strategy, bit for bit
+    # first-contact instrumentation: the communicator's own world / rank, the transport, RCCL's log object
+    assert d["comm"]["launcher_world"] == 4 and d["comm"]["rccl"]["world"] == 4 and d["comm"]["rccl"]["rank"] == 0
+    assert "R3D_RCCL_PATH" in d["comm"]["rccl"]["origin"] and "rccl_log" in d["comm"]
     assert d["config"]["points_per_step"] == 4 * 16 * 384 * 1280 and d["config"]["assemble"] != "none"
     assert d["assemble"]["outputs"]["fabric_bytes_in_per_gpu"] == 3 * 16 * 384 * 1280 * 12
     assert d["assemble"]["inputs"]["fabric_bytes_in_per_gpu"] == 3 * 16 * (384 * 1280 + 96)

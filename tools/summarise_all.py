@@ -85,33 +85,94 @@ def pmc(dirname, counter):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r04")
+    ap.add_argument("--round", default="r05")
+    ap.add_argument("--unprofiled", default=None, help="a file holding the bench line of an UNPROFILED run on the same box")
     a = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", "prof_" + a.round)
     dst = os.path.join(ROOT, "profiles")
-    # ---- headline kernel under the driver's command
+    # ---- headline step under the driver's command: the library's staging sweep + the fused kernel, fresh rasters every step
     stats = most_calls(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), "fuse_lane_kernel")
     shutil.copy(stats, os.path.join(dst, "%s_fuse_kernel_stats.csv" % a.round))
     all_rows = list(csv.DictReader(open(stats)))
     row = [r for r in all_rows if "fuse_lane_kernel" in r["Name"]][0]
     touch = [r for r in all_rows if "cache_touch_kernel" in r["Name"]]
     trace_file = stats.replace("_kernel_stats.csv", "_kernel_trace.csv")
-    tr = [r for r in csv.DictReader(open(trace_file)) if "fuse_lane_kernel" in r["Kernel_Name"]]
+    trace_rows = sorted(csv.DictReader(open(trace_file)), key=lambda r: int(r["Start_Timestamp"]))
+    tr = [r for r in trace_rows if "fuse_lane_kernel" in r["Kernel_Name"]]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
+    bench_line = None
+    for line in open(os.path.join(src, "trace.log")):
+        if line.startswith("{"):
+            bench_line = json.loads(line)
+    steps = bench_line["steps"] if bench_line else 20
+    # a STEP as the trace sees it: a sweep immediately followed by a fused launch -> from the sweep's start to the kernel's end
+    # (the inter-kernel gap included); launches without a sweep in front (the cached-input leg of the bench) are kept apart
+    step_ns, fused_after_sweep, fused_alone = [], [], []
+    for prev, cur in zip(trace_rows, trace_rows[1:]):
+        if "fuse_lane_kernel" in cur["Kernel_Name"]:
+            dur = int(cur["End_Timestamp"]) - int(cur["Start_Timestamp"])
+            if "cache_touch_kernel" in prev["Kernel_Name"]:
+                step_ns.append(int(cur["End_Timestamp"]) - int(prev["Start_Timestamp"]))
+                fused_after_sweep.append(dur)
+            else:
+                fused_alone.append(dur)
+    alg = N_C2 * 13
+
+    def frac(ns):
+        return round(alg / ns / 1e3 / 8.0, 4)
+
     summary = {"round": a.round, "command": "python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-regimes --no-end-to-end",
                "rocprof_kernel_stats": {"name": row["Name"], "calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]),
                                         "min_ns": int(row["MinNs"]), "max_ns": int(row["MaxNs"])},
                "rocprof_kernel_trace": {"n": len(d), "median_ns": statistics.median(d), "last_half_mean_ns": statistics.mean(d[len(d) // 2:]),
                                         "first_30_ns": d[:30], "grid": tr[0]["Grid_Size_X"], "workgroup": tr[0]["Workgroup_Size_X"],
-                                        "vgpr": tr[0]["VGPR_Count"], "sgpr": tr[0]["SGPR_Count"], "lds": tr[0]["LDS_Block_Size"],
-                                        "note": "an idle GPU boosts for ~20 launches (~93 us), dips for ~20 ms (up to ~140 us), then settles"}}
+                                        "vgpr": tr[0]["VGPR_Count"], "sgpr": tr[0]["SGPR_Count"], "lds": tr[0]["LDS_Block_Size"]}}
     if touch:
         t = touch[0]
         summary["input_staging_sweep"] = {"name": t["Name"], "calls": int(t["Calls"]), "average_ns": float(t["AverageNs"]),
-                                          "note": "round 4: staging by provenance -- the sweep runs in front of the launches whose "
-                                                  "raster is not presumed cached (here: the first one), not in front of every launch"}
-    summary["algorithmic_TBps_at_kernel_average"] = N_C2 * 13 / float(row["AverageNs"]) / 1e3
+                                          "note": "fresh rasters: the sweep runs in front of every launch whose raster is not presumed cached"}
+    summary["algorithmic_TBps_at_kernel_average"] = alg / float(row["AverageNs"]) / 1e3
     summary["sweeps_per_fused_launch"] = (int(touch[0]["Calls"]) if touch else 0) / int(row["Calls"])
+    summary["bench_line_under_rocprof"] = bench_line
+    # the reconciliation VERDICT r4 asked for: the line's figures (HIP events, same process) beside the trace's
+    rf = (bench_line or {}).get("roofline", {})
+    touch_avg = float(touch[0]["AverageNs"]) if touch else 0.0
+    reconcile = {
+        "round": a.round, "what": "bench.py's roofline figures against the rocprofv3 kernel trace OF THE SAME PROCESS (so profiler overhead, "
+                                  "if any, is in both); fractions of 8 TB/s at 13 B/point x 49,152,000 points",
+        "trace": {
+            "fused_kernel": {"calls": len(d), "mean_ns": statistics.mean(d), "median_ns": statistics.median(d),
+                             "mean_of_last_%d_launches_ns" % steps: statistics.mean(d[-steps:]),
+                             "frac_at_mean": frac(statistics.mean(d)), "frac_at_median": frac(statistics.median(d)),
+                             "frac_at_mean_of_last_%d" % steps: frac(statistics.mean(d[-steps:]))},
+            "fused_kernel_right_after_a_sweep": {"n": len(fused_after_sweep), "mean_ns": statistics.mean(fused_after_sweep) if fused_after_sweep else None,
+                                                 "median_ns": statistics.median(fused_after_sweep) if fused_after_sweep else None},
+            "fused_kernel_without_a_sweep_in_front": {"n": len(fused_alone), "median_ns": statistics.median(fused_alone) if fused_alone else None,
+                                                      "note": "the cached-input leg (one raster re-read) and the first launches"},
+            "sweep": {"calls": int(touch[0]["Calls"]) if touch else 0, "mean_ns": touch_avg},
+            "step_sweep_start_to_kernel_end": {"n": len(step_ns), "mean_ns": statistics.mean(step_ns) if step_ns else None,
+                                               "median_ns": statistics.median(step_ns) if step_ns else None,
+                                               "mean_of_last_%d_ns" % steps: statistics.mean(step_ns[-steps:]) if step_ns else None,
+                                               "frac_at_mean": frac(statistics.mean(step_ns)) if step_ns else None,
+                                               "frac_at_median": frac(statistics.median(step_ns)) if step_ns else None,
+                                               "frac_at_mean_of_last_%d" % steps: frac(statistics.mean(step_ns[-steps:])) if step_ns else None},
+            "stats_csv_average_sum_ns": float(row["AverageNs"]) + touch_avg,
+            "frac_at_stats_csv_average_sum": frac(float(row["AverageNs"]) + touch_avg)},
+        "line_same_process": {k: rf.get(k) for k in ("frac", "frac_mean", "kernel_ms", "kernel_mean_ms", "launches", "frac_timed_region",
+                                                     "kernel_ms_timed_region", "frac_kernel_only", "kernel_only_ms", "frac_cached_inputs",
+                                                     "cached_inputs_ms")}}
+    if step_ns and rf.get("kernel_ms"):
+        reconcile["agreement"] = {
+            "line_frac_over_trace_step_median": round(rf["frac"] / frac(statistics.median(step_ns)), 4),
+            "line_frac_over_stats_csv_average_sum": round(rf["frac"] / frac(float(row["AverageNs"]) + touch_avg), 4),
+            "line_kernel_only_over_trace_fused_median": round(rf["frac_kernel_only"] / frac(statistics.median(fused_after_sweep)), 4),
+            "line_timed_region_over_trace_last_steps": round(rf["frac_timed_region"] / frac(statistics.mean(step_ns[-steps:])), 4)}
+    if a.unprofiled and os.path.exists(a.unprofiled):
+        for line in open(a.unprofiled):
+            if line.startswith("{"):
+                u = json.loads(line).get("roofline", {})
+                reconcile["line_unprofiled_run_same_box"] = {k: u.get(k) for k in reconcile["line_same_process"]}
+    json.dump(reconcile, open(os.path.join(dst, "%s_fuse_reconcile.json" % a.round), "w"), indent=1)
     # the other regimes of the launch (same kernel symbols), profiled as their own command: kept apart on purpose
     child = fresh(glob.glob(os.path.join(src, "trace_regimes", "**", "*_kernel_stats.csv"), recursive=True))
     if child:
@@ -119,26 +180,26 @@ def main():
         for line in open(os.path.join(src, "trace_regimes.log")):
             if line.startswith("{"):
                 summary["regimes_line_under_rocprof"] = json.loads(line)
-    for line in open(os.path.join(src, "trace.log")):
-        if line.startswith("{"):
-            summary["bench_line_under_rocprof"] = json.loads(line)
     fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     kf = [k for k in fetch if "fuse_lane_kernel" in k][0]
     rd, wr = fetch[kf] * 1024 * 2, write[kf] * 1024
-    # (the staging sweep runs once per ~4100 launches now: its bytes are not part of a step)
-    rd_t, wr_t = 0.0, 0.0
+    kt = [k for k in fetch if "cache_touch_kernel" in k]
+    rd_t, wr_t = (fetch[kt[0]] * 1024 * 2, write.get(kt[0], 0.0) * 1024) if kt else (0.0, 0.0)
     summary.update({"pmc_raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf]}, "hbm_read_bytes_per_launch_corrected_x2": rd,
                     "hbm_write_bytes_per_launch": wr, "staging_sweep_hbm_read_bytes_x2": rd_t, "staging_sweep_hbm_write_bytes": wr_t,
-                    "hbm_bytes_per_launch": rd + wr + rd_t + wr_t, "algorithmic_bytes_per_launch": N_C2 * 13,
-                    "traffic_over_algorithmic": (rd + wr + rd_t + wr_t) / (N_C2 * 13),
-                    "traffic_note": "per step = the fused kernel (its raster is presumed cached from the previous launch: no sweep); "
-                                    "the PMC passes ran bench.py --no-regimes --no-end-to-end (a profiled process must not start "
-                                    "another program)"})
+                    "hbm_bytes_per_launch": rd + wr + rd_t + wr_t, "algorithmic_bytes_per_launch": alg,
+                    "traffic_over_algorithmic": (rd + wr + rd_t + wr_t) / alg,
+                    "traffic_note": "per step = the staging sweep (reads the raster from HBM into the Infinity Cache) + the fused kernel "
+                                    "(FETCH_SIZE counts its reads at the L2/fabric boundary: they are served by the Infinity Cache, so the "
+                                    "raster is counted twice here and crosses HBM once); medians over the launches of the PMC passes, which "
+                                    "ran bench.py --no-regimes --no-end-to-end (a profiled process must not start another program)"})
     rd, wr = rd + rd_t, wr + wr_t
     json.dump(summary, open(os.path.join(dst, "%s_fuse_summary.json" % a.round), "w"), indent=1)
-    json.dump({"round": a.round, "config": {"frames": 100, "out_dtype": "float32", "depth": "u8"}, "hbm_bytes_per_launch": rd + wr,
-               "read_bytes_x2_corrected": rd, "write_bytes": wr, "raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf]},
-               "collected": "round %s, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes" % a.round,
+    json.dump({"round": a.round, "config": {"frames": 100, "out_dtype": "float32", "depth": "u8", "inputs": "fresh"},
+               "hbm_bytes_per_launch": rd + wr, "read_bytes_x2_corrected": rd, "write_bytes": wr,
+               "of_which_staging_sweep_read_bytes": rd_t,
+               "raw_KiB": {"FETCH_SIZE": fetch[kf], "WRITE_SIZE": write[kf], "sweep_FETCH_SIZE": fetch[kt[0]] if kt else None},
+               "collected": "round %s, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; per step = sweep + fused kernel" % a.round,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --gpus 1 --steps 20 --warmup 5`"},
               open(os.path.join(dst, "pmc_fuse_latest.json"), "w"), indent=1)
     # ---- every kernel
