@@ -19,6 +19,6 @@ from .fusion import (REF_INTRINSICS, unproject, fuse_frames, fuse_frames_rgb, se
                      apply_T_device)
 from .poses import (scipy_transfer, get_r, pose_table, pose_to_T, read_pose_file, get_T, write_T,  # noqa: F401
                     str_tofloat)
-from . import cloud_io  # noqa: F401
+from . import cloud_io, device_text  # noqa: F401
 
 __version__ = "0.2.0"

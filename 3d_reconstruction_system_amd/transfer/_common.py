@@ -10,6 +10,8 @@ Environment (all optional; the defaults are the reference's hard-coded values):
                                 `transfer_T_icp.py --estimate-rigid --colmap ...` writes): every pose translation is multiplied
                                 by it -- COLMAP's unit brought to the depth maps' unit (readme.md:25).  Default 1 = the reference.
   WORLD_SIZE RANK LOCAL_RANK    set by a one-process-per-GPU launcher (torch.distributed.run ...): frames are sharded
+  R3D_HOST_TEXT=1               camera_to_world.py: format the txt / PLY text on the host (csrc/r3d_format.cpp) instead of on the GPU
+                                (csrc/r3d_textfmt.hip); same bytes, for A/B timing
   R3D_TIMING=1                  stage times on stderr (stamp() below)
 """
 import importlib

@@ -6,8 +6,8 @@ Same entry point (`python camera_to_world.py` from a directory holding ./camera_
 ./point, ./point_world, ./ply), same functions, same files written.  What changed is where the
 per-point arithmetic runs: all frames of the pose file are unprojected and moved to the world
 frame by ONE fused HIP launch (fp64 registers, reference evaluation order) instead of two Python
-loops per frame with a text file between them.  The text/PLY files are produced from the GPU's
-fp64 result by the library's native formatter, byte-compatible with Python's repr()/"%.4f".
+loops per frame with a text file between them.  The txt/PLY text is produced ON THE GPU from its
+fp64 result (csrc/r3d_textfmt.hip), byte-compatible with Python's repr()/"%.4f"; the host copies it into files.
 
 Several GPUs: start it under a one-process-per-GPU launcher, e.g.
     python -m torch.distributed.run --nproc-per-node 8 camera_to_world.py
@@ -215,9 +215,63 @@ def _ply_in_background(world, pc_file):
 
 
 def get_file_name(qt_path):
+    """The frame loop (c2w:138-174) with every frame in flight at once: the rasters go up (1 B/point), ONE fused launch
+    makes the world cloud and one more the camera clouds, both fp64 and both STAYING in HBM; the GPU then formats the
+    reference's text from them (csrc/r3d_textfmt.hip: repr() lines for ./point/<stem>.txt and the world txt, "%.4f" rows for
+    the PLY) and host threads copy that text into the files -- the PLY beside the per-frame txts.  Same bytes as the host
+    formatter (R3D_HOST_TEXT=1 takes that way: clouds to host memory, csrc/r3d_format.cpp)."""
     if _common.world_size() > 1:
         return _get_file_name_sharded(qt_path)
+    if os.environ.get("R3D_HOST_TEXT", "0") not in ("", "0"):
+        return _get_file_name_host_text(qt_path)
     print('data start transfer')
+    t1 = time.time()
+    _common.stamp(None)
+    names, quats, ts = r3d.read_pose_file(qt_path)
+    n_frames = len(names)
+    if not n_frames:
+        return _get_file_name_host_text(qt_path, announce=False)     # a header-only PLY: nothing for the GPU to do
+    depths = r3d.cloud_io.read_depth_batch([os.path.join('./depth/', n) for n in names])
+    _common.stamp("pose file + %d depth files decoded" % n_frames)
+    ctx = _common.context()
+    _common.stamp("GPU context")
+    per = depths.shape[1] * depths.shape[2]
+    n = n_frames * per
+    cam = ctx.camera(depths.shape[1], depths.shape[2], *_common.intrinsics())
+    table = r3d.pose_table(quats, ts * _common.pose_scale())       # 1 unless R3D_POSE_SCALE says otherwise
+    bufs = []
+    try:
+        d_depth, d_pose, d_world = ctx.alloc(depths.nbytes).upload(depths), ctx.alloc(table.nbytes).upload(table), ctx.alloc(n * 24)
+        bufs += [d_depth, d_pose, d_world]
+        r3d.fuse_frames_device(ctx, cam, d_depth.ptr, depths.dtype, n_frames, d_pose.ptr, d_world.ptr, np.float64)
+        text = r3d.device_text.TextWriter(ctx)
+        text.add_ply('./ply/small_035_p8.ply', d_world.ptr, np.float64, n)     # the same bytes genply(world, ...) writes
+        if not _common.skip_intermediate():
+            d_cam = ctx.alloc(n * 24)
+            bufs.append(d_cam)
+            r3d.unproject_device(ctx, cam, d_depth.ptr, depths.dtype, n_frames, d_cam.ptr, np.float64)
+            integral = depths.dtype in (np.uint8, np.uint16)
+            # the per-frame camera txt the reference leaves in ./point/ (third column: the raster's own integers)
+            text.add_xyz_txt(['./point/' + nm[0:-4] + '.txt' for nm in names], d_cam.ptr, np.float64, n,
+                             d_z_raw=d_depth.ptr if integral else None, z_dtype=depths.dtype if integral else None)
+            # the reference reopens this file with 'w' for every frame: it ends up holding the last one
+            text.add_xyz_txt(['./point_world/small_worldpoint_5_23_5.txt'], d_world.ptr + (n_frames - 1) * per * 24, np.float64, per)
+        _common.stamp("fused launches + text sizes (device)")
+        written = text.write()
+        _common.stamp("%d bytes of text formatted on the GPU and written" % written)
+    finally:
+        for b in bufs:
+            b.free()
+    t2 = time.time()
+    print('##################')
+    print("%d frames cost ." % n_frames, t2 - t1)
+    print("Write into .ply file Done.")
+
+
+def _get_file_name_host_text(qt_path, announce=True):
+    """The same files through the HOST formatter (rounds 1-4's way; R3D_HOST_TEXT=1): both fp64 clouds come to host memory."""
+    if announce:
+        print('data start transfer')
     t1 = time.time()
     names, depths, world = fuse_pose_file(qt_path)
     n_frames = len(names)

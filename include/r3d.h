@@ -429,6 +429,36 @@ int r3d_format_xyz_txt(const void* h_xyz, int dtype, int64_t n_points, const voi
 int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double* h_xyz_out, int64_t cap_points,
                        int64_t* n_points_out, int64_t* bad_line_out);
 
+/* ---- f1 on the device: the same text formatted by the GPU (csrc/r3d_textfmt.hip), so that the TEXT leaves the device
+ * (41 B/point of camera txt) instead of fp64 clouds into pageable memory, and the host only copies it into files.
+ * kind R3D_TEXT_XYZ_TXT: the lines of r3d_write_xyz_txt (d_aux = the integer third column, u8 / u16 per aux_dtype, or NULL);
+ * R3D_TEXT_PLY_ROWS: the vertex rows of r3d_write_ply ("%.4f %.4f %.4f \n", no header / trailer); R3D_TEXT_PLY_ROWS_RGB: the
+ * rows of r3d_write_ply_rgb / _rgba (d_aux = colours, aux_dtype = 3 or 4 bytes apart).  Byte-identical to the host formatter.
+ * d_xyz is a device [n][3] cloud; rows appear in point order in d_text (device, text_cap bytes).  Two-call protocol:
+ * d_text == NULL only computes *n_bytes_out and the segment offsets.  segment_points > 0: h_segment_offsets_out
+ * [ceil(n / segment_points) + 1] receives the byte offset of the first row of every block of segment_points points (a frame's
+ * camera txt) and, last, the total.  Synchronises the ctx's stream once (the sizes come to the host); the rows themselves are
+ * enqueued.  R3D_ERR_UNSUPPORTED when a "%.4f" coordinate has magnitude >= 2^40 (more digits than a device row holds): format
+ * that cloud on the host. */
+#define R3D_TEXT_XYZ_TXT 0
+#define R3D_TEXT_PLY_ROWS 1
+#define R3D_TEXT_PLY_ROWS_RGB 2
+int r3d_format_text_device(r3d_ctx* ctx, int kind, const void* d_xyz, int dtype, int64_t n_points, const void* d_aux, int aux_dtype,
+                           int64_t segment_points, char* d_text, size_t text_cap, int64_t* h_segment_offsets_out,
+                           int64_t* n_bytes_out);
+/* Device text -> files: file k = head (host bytes), then text_bytes of d_text from text_offset, then tail (host bytes).
+ * Host threads take the files largest first, each through its own pinned 1 MiB pieces and stream (PCIe and write() overlap);
+ * one file is one sequential write stream, different files are written side by side.  Waits for the ctx's stream first. */
+typedef struct r3d_text_file {
+  const char* path;
+  const char* head;
+  size_t head_bytes;
+  size_t text_offset, text_bytes;
+  const char* tail;
+  size_t tail_bytes;
+} r3d_text_file;
+int r3d_write_device_text_files(r3d_ctx* ctx, const char* d_text, const r3d_text_file* files, int n_files);
+
 /* ---- f3 ingestion: the depth rasters of camera_to_world.py:160 (`cv.imread(path, IMREAD_GRAYSCALE)`) decoded by host
  * threads.  Native path: non-interlaced greyscale PNG, 8 bits (-> uint8, same bytes as OpenCV) or 16 bits (-> uint16);
  * any other PNG flavour returns R3D_ERR_UNSUPPORTED (the Python host then falls back to cv2 / PIL).

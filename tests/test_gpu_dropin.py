@@ -48,6 +48,37 @@ def test_camera_to_world_script_reproduces_reference_files(tmp_path, golden_dir)
     assert (np.abs(got - want) / (1 + np.linalg.norm(want, axis=1, keepdims=True))).max() <= 1e-12
 
 
+def test_camera_to_world_device_text_equals_host_text(tmp_path):
+    """The script's default way (text formatted on the GPU, csrc/r3d_textfmt.hip) and the host formatter's way
+    (R3D_HOST_TEXT=1, rounds 1-4) write the same bytes into every file: 7 frames of 120 x 200, 16-bit depth PNGs too."""
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    F, H, W = 7, 120, 200
+    for sub, bits in (("a8", 8), ("b8", 8), ("a16", 16), ("b16", 16)):
+        for d in ("depth", "point", "point_world", "ply", "camera_pose"):
+            os.makedirs(tmp_path / sub / d)
+    for bits in (8, 16):
+        rs = np.random.default_rng(bits)
+        with open(tmp_path / ("a%d" % bits) / "camera_pose" / "image_colmap_simi_2.txt", "w") as f:
+            f.write("id,tx,ty,tz,qx,qy,qz,qw,name,extra\n")
+            for k in range(F):
+                if bits == 8:
+                    Image.fromarray(rs.integers(0, 256, (H, W), dtype=np.uint8)).save(tmp_path / "a8" / "depth" / ("%03d.png" % k))
+                else:
+                    Image.fromarray(rs.integers(0, 65536, (H, W), dtype=np.uint16)).save(tmp_path / "a16" / "depth" / ("%03d.png" % k))
+                q, t = rs.normal(size=4), rs.normal(size=3) * 10
+                f.write(",".join([str(k)] + [repr(float(x)) for x in t] + [repr(float(x)) for x in q] + ["%03d.png" % k, "x"]) + "\n")
+        a, b = tmp_path / ("a%d" % bits), tmp_path / ("b%d" % bits)
+        shutil.copytree(a / "depth", b / "depth", dirs_exist_ok=True)
+        shutil.copy(a / "camera_pose" / "image_colmap_simi_2.txt", b / "camera_pose")
+        out_a = run_script("transfer/camera_to_world.py", str(a))
+        out_b = run_script("transfer/camera_to_world.py", str(b), env={"R3D_HOST_TEXT": "1"})
+        assert out_a.count("Write into .ply file Done.") == out_b.count("Write into .ply file Done.") == 1
+        for rel in ["ply/small_035_p8.ply", "point_world/small_worldpoint_5_23_5.txt"] + ["point/%03d.txt" % k for k in range(F)]:
+            assert (a / rel).read_bytes() == (b / rel).read_bytes(), (bits, rel)
+        assert os.path.getsize(a / "ply" / "small_035_p8.ply") > F * H * W * 20
+
+
 def test_camera_to_world_functions_keep_reference_semantics(tmp_path, golden_dir, monkeypatch):
     import importlib
     c2w = importlib.import_module(PKG + ".transfer.camera_to_world")
