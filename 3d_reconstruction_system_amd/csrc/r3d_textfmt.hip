@@ -586,8 +586,15 @@ int r3d_write_device_text_files(r3d_ctx* ctx, const char* d_text, const r3d_text
   std::vector<int> order((size_t)n_files);
   for (int k = 0; k < n_files; ++k) order[k] = k;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return files[a].text_bytes > files[b].text_bytes; });
-  unsigned want_workers = std::min(r3d_host::cpu_budget(), 32u);
-  if (const char* e = getenv("R3D_TEXT_WRITERS")) want_workers = (unsigned)std::max(1, atoi(e));
+  // How many writers: the largest file is one stream (~6 GB/s into tmpfs, measured on the MI355X box's host; several streams on
+  // ONE inode are slower, an mmap half as fast: tools/tmpfs_write_probe.cpp) and sets the finishing time; the other files need
+  // about (rest / largest) streams to be done by then, plus one to spare.  More than that only competes with the critical
+  // stream for the process's CPU quota: C2's 3.29 GB took 298 / 269 / 242 / 227 ms with 32 / 16 / 8 / 4 writers.
+  size_t all_bytes = 0;
+  for (int k = 0; k < n_files; ++k) all_bytes += files[k].text_bytes;
+  const size_t big_bytes = std::max<size_t>(files[order[0]].text_bytes, 1);
+  const unsigned want_workers = (unsigned)std::min<size_t>(2 + (all_bytes - files[order[0]].text_bytes + big_bytes - 1) / big_bytes,
+                                                            std::max(1u, r3d_host::cpu_budget() / 2));
   const unsigned n_workers = std::max(1u, std::min<unsigned>(want_workers, (unsigned)n_files));
   constexpr size_t kPiece = (size_t)1 << 20;
   char* pinned = nullptr;
