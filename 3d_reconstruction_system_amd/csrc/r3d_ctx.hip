@@ -256,7 +256,6 @@ static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "voxel_dedupe")) return &ctx->voxel_dedupe;
   if (!strcmp(key, "voxel_path")) return &ctx->voxel_path;
   if (!strcmp(key, "voxel_last_path")) return &ctx->voxel_last_path;
-  if (!strcmp(key, "voxel_merge_phases")) return &ctx->voxel_merge_phases;
   if (!strcmp(key, "voxel_merge_blocks")) return &ctx->voxel_merge_blocks;
   return nullptr;
 }

@@ -48,7 +48,6 @@ struct r3d_ctx {
   int apply_blocks = 0;
   int voxel_path = 0;     // big inserts: 0 auto (a sample of the cloud decides), 1 LDS-set + CAS kernel, 2 sort-merge (r3d_voxel.hip)
   int voxel_merge_blocks = 0; // sort-merge insert: workgroups of a merge launch (0 auto)
-  int voxel_merge_phases = 0; // sort-merge insert: phases of the merge (0 auto: ~96 MB of keys each; 1 = unphased, A/B)
   int voxel_last_path = 0; // read-only: the path the last r3d_voxelset_insert took (1 / 2)
   int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set; 3: on, with the
                           // flush barrier inside its `if` (A/B against DESIGN 4.5b's finding only)
@@ -149,6 +148,8 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
 constexpr int kSortTile = 4096;   // keys per workgroup of every sort kernel
 int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* n_blocks_out);
 static inline int r3d_sort_stride(int n_blocks) { return (n_blocks + 3) & ~3; }   // counters per histogram row (16-byte aligned rows)
+// hist[bin][tile] (256 rows of `stride` counters) -> exclusive prefixes over the tiles, in place; totals[bin] = the bin's count
+void r3d_sort_launch_scan(r3d_ctx* ctx, uint32_t* hist, int n_blocks, int stride, uint32_t* totals);
 
 // r3d_nnindex.hip: the index's own copy of the target cloud (original order), its size and its context
 int r3d_nn_index_target(r3d_nn_index* index, const float** d_tgt, int64_t* n_tgt, r3d_ctx** ctx);

@@ -12,13 +12,16 @@
 //                           bin order in LDS and written out by consecutive lanes; destination = bin base + workgroup
 //                           prefix + place inside the tile's bin.  Order of equal digits is preserved (stable).
 #include "r3d_internal.h"
+#include "r3d_sort_dev.h"
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kRounds = 16;
-constexpr int kTile = kThreads * kRounds;  // keys per workgroup
-constexpr int kBins = 256;
+using r3d_sort::kBins;
+using r3d_sort::kRounds;
+using r3d_sort::kThreads;
+using r3d_sort::kTile;
+using r3d_sort::wave_inclusive_scan;
+using r3d_sort::xcd_contiguous;
 
 __global__ __launch_bounds__(kThreads) void digit_histogram_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                                                                    uint32_t* __restrict__ hist, int stride) {
@@ -40,15 +43,6 @@ __global__ __launch_bounds__(kThreads) void digit_histogram_kernel(const uint64_
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   hist[(int64_t)threadIdx.x * stride + blockIdx.x] = bins[threadIdx.x];
-}
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
-  return v;
 }
 
 // grid = kBins workgroups of 256 threads: bin b's counts over the workgroups become exclusive prefixes in place.  The row
@@ -95,13 +89,6 @@ __global__ __launch_bounds__(kThreads) void digit_scan_kernel(uint32_t* __restri
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// workgroup b of a grid of g -> item x * (g / 8) + min(x, g % 8) + b / 8 with x = b % 8: the workgroups of one XCD walk a
-// contiguous eighth of the items, in order
-__device__ __forceinline__ int xcd_contiguous(unsigned b, unsigned g) {
-  const unsigned x = b & 7u, j = b >> 3, q = g >> 3, r = g & 7u;
-  return (int)(x * q + (x < r ? x : r) + j);
-}
-
 // The tile's 4096 keys leave in BIN ORDER: ranked without a workgroup barrier per round, staged in LDS, written out by
 // consecutive lanes.  (Until round 4 every round of 256 keys took four barriers and every lane stored its key where its
 // rank said -- a wave instruction of 64 eight-byte stores to ~56 different places: 490 us per pass on 49 M keys = 1.6 TB/s.)
@@ -120,32 +107,17 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
                                                                  const uint32_t* __restrict__ hist, int stride,
                                                                  const uint32_t* __restrict__ totals,
                                                                  uint64_t* __restrict__ out) {
-  constexpr int kWaves = kThreads / 64, kPerWave = kTile / kWaves;
+  using r3d_sort::kPerWave;
+  using r3d_sort::kWaves;
   __shared__ uint64_t sorted[kTile];
-  __shared__ uint32_t wave_cnt[kWaves][kBins];   // running counts while ranking, then the waves' offsets inside each bin
-  __shared__ uint32_t bin_start[kBins];
+  __shared__ r3d_sort::RankShared rk;
   __shared__ uint64_t g_base[kBins];
   __shared__ uint64_t wave_total[kWaves];
-  __shared__ uint32_t wave_sum[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // bin bases = exclusive prefix of the 256 bin totals, computed here by every workgroup (a launch of its own for one wave's
   // work cost more in launch latency than all workgroups repeating it: sorts of 0.3 - 0.5 M keys are launch-bound)
-  uint64_t bin_base;
-  {
-    const uint64_t mine = totals[threadIdx.x];
-    uint64_t inc = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint64_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) wave_total[wave] = inc;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) wave_cnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    bin_base = inc - mine;
-    for (int w = 0; w < wave; ++w) bin_base += wave_total[w];
-  }
+  r3d_sort::rank_reset(rk);
+  const uint64_t bin_base = r3d_sort::block_exclusive_scan_256(totals[threadIdx.x], wave_total);   // (its barrier covers rank_reset)
   // Which tile: workgroups are dealt to the chip's 8 XCDs round-robin (workgroup b -> XCD b % 8), each XCD behind an L2 of its
   // own.  Tiles t and t + 1 write ADJACENT runs in every bin, and a run begins and ends inside a 128-byte line: dealt round-robin
   // the two halves of such a line are written through two different L2s and reach HBM as two partial (read-modify-write)
@@ -154,88 +126,30 @@ __global__ __launch_bounds__(kThreads) void digit_scatter_kernel(const uint64_t*
   const int64_t base = (int64_t)tile * kTile;
   const int64_t first = base + (int64_t)wave * kPerWave + lane;
   uint64_t key[kRounds];
-  uint32_t place[kRounds];   // rank inside the wave's quarter among the keys of the same digit
+  uint32_t digit[kRounds], place[kRounds], live_mask = 0;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int64_t i = first + r * 64;
     key[r] = i < n ? keys[i] : 0;
+    digit[r] = (uint32_t)(key[r] >> shift) & 0xff;
+    live_mask |= (i < n ? 1u : 0u) << r;
   }
-  // Four rounds at a time, in three sweeps, so that a round does not wait for the LDS round trips of the one before it:
-  // (1) who shares my digit -- pure ALU; (2) the four counter bumps back to back (the LDS serves one wave's operations in
-  // order: the returned values ARE the running counts); (3) the four hand-overs from the lowest peer.  (All sixteen rounds in
-  // one group of sweeps kept 128 ballot masks alive: 399 VGPRs of spilled scalars.  One round per group -- the first form --
-  // spent its time in sixteen dependent pairs of LDS round trips per wave.)
-  constexpr int kGroup = 4;
-#pragma unroll
-  for (int g = 0; g < kRounds; g += kGroup) {
-    uint32_t info[kGroup];   // rank among the peers | their number << 8 | the lowest peer's lane << 16 | live << 24
-#pragma unroll
-    for (int q = 0; q < kGroup; ++q) {
-      const int r = g + q;
-      const bool live = first + r * 64 < n;
-      const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xff;
-      unsigned long long peers = __ballot(live);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const unsigned long long m = __ballot((digit >> b) & 1);
-        peers &= ((digit >> b) & 1) ? m : ~m;
-      }
-      const uint32_t rank = __popcll(peers & ((1ull << lane) - 1));
-      info[q] = rank | ((uint32_t)__popcll(peers) << 8) | ((peers ? (uint32_t)__ffsll((long long)peers) - 1u : 0u) << 16) | ((uint32_t)live << 24);
-    }
-#pragma unroll
-    for (int q = 0; q < kGroup; ++q) {
-      const int r = g + q;
-      place[r] = 0;
-      if ((info[q] >> 24) && (info[q] & 0xff) == 0)   // live, and the lowest of its peers
-        place[r] = atomicAdd(&wave_cnt[wave][(uint32_t)(key[r] >> shift) & 0xff], (info[q] >> 8) & 0xff);
-    }
-#pragma unroll
-    for (int q = 0; q < kGroup; ++q) {
-      const int r = g + q;
-      place[r] = (uint32_t)__shfl((int)place[r], (int)((info[q] >> 16) & 0xff), 64) + (info[q] & 0xff);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep the groups apart: merged, their ballot masks do not fit the scalar registers
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  r3d_sort::rank_rounds(digit, live_mask, place, rk);
   __syncthreads();
-  {
-    // thread b: bin b over the four waves
-    uint32_t c[kWaves], tot = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      c[w] = wave_cnt[w][threadIdx.x];
-      tot += c[w];
-    }
-    const uint32_t inc = wave_inclusive_scan(tot, lane);
-    if (lane == 63) wave_sum[wave] = inc;
-    __syncthreads();   // everybody has read the running counts; the wave sums are there
-    uint32_t start = inc - tot;
-    for (int w = 0; w < wave; ++w) start += wave_sum[w];
-    bin_start[threadIdx.x] = start;
-    uint32_t off = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      wave_cnt[w][threadIdx.x] = off;
-      off += c[w];
-    }
-    g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
-  }
+  r3d_sort::rank_place_bins(rk);
+  g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
-    if (first + r * 64 < n) {
-      const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xff;
-      sorted[bin_start[digit] + wave_cnt[wave][digit] + place[r]] = key[r];
-    }
+    if ((live_mask >> r) & 1u) sorted[rk.bin_start[digit[r]] + rk.wave_cnt[wave][digit[r]] + place[r]] = key[r];
   }
   __syncthreads();
   const int n_tile = (int)(n - base < (int64_t)kTile ? n - base : (int64_t)kTile);
 #pragma unroll 4
   for (int j = threadIdx.x; j < n_tile; j += kThreads) {
     const uint64_t k = sorted[j];
-    const uint32_t digit = (uint32_t)(k >> shift) & 0xff;
-    out[g_base[digit] + (uint32_t)(j - (int)bin_start[digit])] = k;   // (plain stores: nontemporal ones -- partial lines past the L2 -- took 431 us instead of 239)
+    const uint32_t d = (uint32_t)(k >> shift) & 0xff;
+    out[g_base[d] + (uint32_t)(j - (int)rk.bin_start[d])] = k;   // (plain stores: nontemporal ones -- partial lines past the L2 -- took 431 us instead of 239)
   }
 }
 
@@ -259,6 +173,11 @@ int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* 
   *hist_out = static_cast<uint32_t*>(ws);
   *n_blocks_out = (int)n_blocks64;
   return R3D_OK;
+}
+
+// hist[bin][tile] -> exclusive prefixes over the tiles in place + the 256 bin totals (for radix passes built outside this file)
+void r3d_sort_launch_scan(r3d_ctx* ctx, uint32_t* hist, int n_blocks, int stride, uint32_t* totals) {
+  hipLaunchKernelGGL(digit_scan_kernel, dim3(kBins), dim3(kThreads), 0, ctx->stream, hist, n_blocks, stride, totals);
 }
 
 int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t n, int bits, int first_bit, uint64_t** d_result,

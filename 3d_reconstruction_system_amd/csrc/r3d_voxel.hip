@@ -24,6 +24,7 @@
 
 #include "r3d_hostpool.h"
 #include "r3d_internal.h"
+#include "r3d_sort_dev.h"
 #include "r3d_voxel_dev.h"
 
 struct r3d_voxelset {
@@ -197,32 +198,39 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
 // The LDS-set kernel above wins when neighbouring pixels share voxels (scans: tens of points per voxel).  On a cloud without
 // surfaces (BASELINE C2's random depth: 49.2 M points -> 48.4 M voxels) nothing dedupes and every point ends as a 64-bit CAS
 // at a random place of a 1 GB table: 3.3 ms, ~80 B written per 8-byte key (profiles/r03_all_kernels.json) -- every CAS drags
-// a whole line through HBM and back.  Random access is the cost, so this path has none:
-//   voxel_keys_kernel     12 B/point in, 8 B out: word = REGION << 48 | packed key, where REGION = the top bits of the key's
-//                         home slot in the table (the packed key has 48 bits: the region rides in the 16 above them);
-//   r3d_radix_sort_u64    on the region bits only (two 8-bit passes for a 65536-region table): the words of one region
-//                         become one contiguous run;
-//   voxel_bounds_kernel   where each region's run starts;
-//   voxel_merge_kernel    persistent workgroups walk the regions that received keys: a region's 2048..8192 table slots come into
-//                         LDS with 16-byte loads (or are just initialised when the table is known to be empty), the run's keys
-//                         are inserted THERE (LDS compare-and-swap, linear probing from the home
-//                         slot -- the same placement rule as table_insert, so later lookups and CAS inserts see a table they
-//                         understand), the region goes back with 16-byte stores.  A probe that runs off the region's end is
-//                         deferred to a spill list, inserted by voxel_spill_kernel with the ordinary CAS afterwards (~0.1 % of
-//                         the keys at load 0.4).
-// HBM sees streams only.  Per point: 20 B (keys) + 48 B (two sort passes) + 8 B (bounds) + 8 B + 16 B x capacity / n (merge).
-constexpr int kRegionMinLog2 = 11;   // slots per region: 2048 (16 KB of LDS) ... 8192 (64 KB)
+// a whole line through HBM and back.  Random access is the cost, so this path has none.
+//
+// Round 5 form.  A key's place in the table is the top bits of h48 = key * G mod 2^48, a BIJECTION of the 48-bit keys
+// (r3d_voxel_dev.h).  The top 16 bits of h48 name one of 65536 PIECES of the table; within a piece a key is the low 32 bits of
+// h48.  So the sort moves 4-byte remainders (+ one digit byte while it is still needed), not 8-byte words:
+//   voxel_keys_kernel      12 B/point in; out: rem = h48 & 0xffffffff (4 B), the piece's two digit bytes hi | lo (2 B), and the
+//                          tile's histogram of `lo` (the first pass's);
+//   piece_scatter_kernel<1>  by `lo`: 6 B in, rem + hi out (5 B), stable, tile staged in LDS in bin order (r3d_sort_dev.h);
+//   byte_histogram_kernel  of the permuted `hi` bytes: 1 B/point (rounds 2-4 re-read the 8-byte words: 8 B/point);
+//   piece_scatter_kernel<2>  by `hi`: 5 B in, rem out (4 B) -- and the RUN STARTS of all 65536 pieces: the pass's input is in
+//                          `lo` order, so a tile knows from the first pass's bin totals which `lo` boundaries fall inside it,
+//                          and thread `hi` counts how many of its bin's elements lie in front of each (a binary search over the
+//                          original positions, kept beside the staged tile).  Rounds 2-4 spent a pass over the sorted words on this;
+//   voxel_merge_kernel     persistent workgroups walk the table's 2048..8192-slot regions: the region comes into LDS (or is just
+//                          initialised when the table is known to be empty), the remainders of its piece(s) are turned back into
+//                          keys (key = (piece << 32 | rem) * G^-1 mod 2^48) and inserted THERE (LDS compare-and-swap, linear
+//                          probing from the home slot: the same placement rule as table_insert), the region goes back with 16-byte
+//                          stores.  A probe that runs off the region's end is deferred to a spill list (voxel_spill_kernel,
+//                          ordinary CAS, ~0.1 % of the keys at load 0.4).
+// HBM sees streams only.  Per point: 18 (keys) + 11 + 1 + 9 (sort) + 4 + 16 x capacity / n (merge) = 43 + 8 x slots per point
+// bytes; rounds 2-4: 76 + 8 x slots per point.  C2 (2.73 slots per point): 64.8 instead of 97.8 B/point.
+constexpr int kRegionMinLog2 = 11;   // slots per LDS region: 2048 (16 KB of LDS) ... 8192 (64 KB)
 constexpr int kRegionMaxLog2 = 13;
-constexpr int kMaxRegionBits = 16;   // what fits above a 48-bit key
-constexpr uint64_t kKeyMask48 = ((uint64_t)1 << 48) - 1;
-constexpr uint64_t kSkip = ~0ull;    // a word that carries no key (ignored point, duplicate of the previous lane)
+constexpr int kPieceBits = 16;       // the table is sorted into 2^16 pieces (the top 16 bits of h48)
+constexpr uint32_t kPieces = 1u << kPieceBits;
+using r3d_vox::hash48;
+using r3d_vox::kMask48;
+using r3d_vox::unhash48;
 
-__device__ __forceinline__ uint64_t home_slot(uint64_t key, int log2cap) { return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap); }
-
-// One workgroup per SORT TILE (4096 points -> 4096 words): besides the words it leaves the tile's histogram of the first sort
-// digit (bits 48..55) where the sort's first pass would have had to compute it from the words again (hist[bin][tile]).
-__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor, int log2cap,
-                                                              int region_log2, uint64_t* __restrict__ words,
+// One workgroup per SORT TILE (4096 points): rem / hl for every point of the tile (live or not) and the tile's histogram of the
+// low piece byte, hist[bin][tile] (what the first pass would otherwise have to count from the elements again).
+__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor,
+                                                              uint32_t* __restrict__ rem, uint16_t* __restrict__ hl,
                                                               uint32_t* __restrict__ hist, int hist_stride,
                                                               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
                                                               unsigned long long spill_cap, unsigned long long* __restrict__ counters) {
@@ -252,17 +260,18 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
       }
       const uint64_t prev = prev_lane_u64(key);
       if (live && lane > 0 && prev == key) live = false;
-      uint64_t word = kSkip;
+      uint64_t h = kMask48;   // no key
       if (live) {
-        word = ((home_slot(key, log2cap) >> region_log2) << 48) | key;
-        if (word == kSkip) {   // voxel (65535, 65535, 65535) in region 65535 would read as "no key": it takes the deferred way in
+        h = hash48(key);
+        if (h == kMask48) {   // the one key whose h48 reads as "no key": it takes the deferred way in
           const unsigned long long at = atomicAdd(spill_count, 1ull);   // (the list holds one entry per point: always room)
           if (at < spill_cap) spill[at] = key;
         }
       }
       if (i < n) {
-        words[i] = word;
-        atomicAdd(&bins[(uint32_t)(word >> 48) & 0xff], 1u);
+        rem[i] = (uint32_t)h;
+        hl[i] = (uint16_t)(h >> 32);
+        atomicAdd(&bins[(uint32_t)(h >> 32) & 0xff], 1u);
       }
     }
   }
@@ -274,48 +283,176 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
   hist[(int64_t)threadIdx.x * hist_stride + blockIdx.x] = bins[threadIdx.x];
 }
 
-// starts[b] = index of the first word whose region is >= b, for b in [0, n_regions + 1]; words that carry no key sort behind
-// every region when there are fewer than 65536 of them (pseudo-region n_regions) and are skipped by value in any case.
-// Eight words per thread (four 16-byte loads in flight) + the one in front of them.
-__global__ __launch_bounds__(kThreads) void voxel_bounds_kernel(const uint64_t* __restrict__ words, int64_t n, uint32_t n_regions,
-                                                                uint32_t* __restrict__ starts) {
-  const int64_t groups = (n + 8) / 8 + 1;   // covers index n (the end marker) too
-  for (int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kThreads) {
-    const int64_t i0 = g * 8;
-    if (i0 > n) break;
-    uint64_t w[8];
-    if (i0 + 8 <= n) {
+// hist[bin][tile] of a byte array, 4096 bytes per tile.  A workgroup takes FOUR tiles, one per wave (12 000 one-tile workgroups
+// of a single 16-byte load per thread were bound by their own launch: 34 us for 49 MB): four 16-byte loads per lane in flight,
+// 64 LDS adds into the wave's own 256 bins.
+__global__ __launch_bounds__(kThreads) void byte_histogram_kernel(const uint8_t* __restrict__ bytes, int64_t n, int n_tiles,
+                                                                  uint32_t* __restrict__ hist, int stride) {
+  __shared__ uint32_t bins[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const ulonglong2 v = reinterpret_cast<const ulonglong2*>(words + i0)[k];
-        w[2 * k] = v.x;
-        w[2 * k + 1] = v.y;
-      }
-    } else {
+  for (int w = 0; w < 4; ++w) bins[w][threadIdx.x] = 0;
+  __syncthreads();
+  const int tile = blockIdx.x * 4 + wave;
+  const int64_t t0 = (int64_t)tile * kSortTile;
+  if (tile < n_tiles) {
+    uint4 v[4];
+    bool whole[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = i0 + k < n ? words[i0 + k] : 0;
+    for (int k = 0; k < 4; ++k) {
+      const int64_t at = t0 + (int64_t)(k * 64 + lane) * 16;
+      whole[k] = at + 16 <= n;
+      v[k] = whole[k] ? *reinterpret_cast<const uint4*>(bytes + at) : uint4{0, 0, 0, 0};
     }
-    int64_t prev = i0 > 0 ? (int64_t)min((uint32_t)(words[i0 - 1] >> 48), n_regions) : -1;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int64_t i = i0 + k;
-      if (i > n) break;
-      const int64_t cur = i < n ? (int64_t)min((uint32_t)(w[k] >> 48), n_regions) : (int64_t)n_regions + 1;
-      for (int64_t b = prev + 1; b <= cur; ++b) starts[b] = (uint32_t)i;
-      prev = cur;
+    for (int k = 0; k < 4; ++k) {
+      if (whole[k]) {
+        const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          atomicAdd(&bins[wave][w4[c] & 0xff], 1u);
+          atomicAdd(&bins[wave][(w4[c] >> 8) & 0xff], 1u);
+          atomicAdd(&bins[wave][(w4[c] >> 16) & 0xff], 1u);
+          atomicAdd(&bins[wave][w4[c] >> 24], 1u);
+        }
+      } else {
+        const int64_t at = t0 + (int64_t)(k * 64 + lane) * 16;
+        for (int c = 0; c < 16 && at + c < n; ++c) atomicAdd(&bins[wave][bytes[at + c]], 1u);
+      }
+    }
+  }
+  r3d_vox::lds_settle();
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (blockIdx.x * 4 + w < n_tiles) hist[(int64_t)threadIdx.x * stride + blockIdx.x * 4 + w] = bins[w][threadIdx.x];
+}
+
+// One radix pass over the elements of the sort-merge insert.  PASS 1: digit = lo (of hl), carries rem + hi; any order inside a
+// bin (nothing has been sorted yet).  PASS 2: digit = hi, carries rem alone and leaves starts[piece] for all 65536 pieces (+ two
+// end markers).  Its input is in lo order and a tile of 4096 elements almost always lies inside ONE lo run (~190 K elements on
+// C2): such a tile may also be ranked in any order; only a tile with a lo boundary in its interior (1 in ~47) takes the stable
+// ranking, which keeps the smaller lo in front inside every hi bin.  totals_lo: the first pass's bin totals.
+template <int PASS>
+__global__ __launch_bounds__(kThreads) void piece_scatter_kernel(const uint32_t* __restrict__ rem_in, const uint16_t* __restrict__ hl_in,
+                                                                 const uint8_t* __restrict__ hi_in, int64_t n,
+                                                                 const uint32_t* __restrict__ hist, int stride,
+                                                                 const uint32_t* __restrict__ totals, const uint32_t* __restrict__ totals_lo,
+                                                                 uint32_t* __restrict__ rem_out, uint8_t* __restrict__ hi_out,
+                                                                 uint32_t* __restrict__ starts) {
+  using namespace r3d_sort;
+  __shared__ uint32_t s_rem[kTile];
+  __shared__ uint8_t s_dig[kTile];                       // the digit of the element staged at each place
+  __shared__ uint8_t s_hi[PASS == 1 ? kTile : 4];        // pass 1: the byte that travels on
+  __shared__ uint16_t s_orig[PASS == 2 ? kTile : 2];     // pass 2, stable tiles: where in the tile the element came from
+  __shared__ uint32_t s_owned[PASS == 2 ? kBins : 1];    // pass 2: the lo boundaries this tile owns: lo | tile-local position << 8
+  __shared__ uint32_t n_owned;
+  __shared__ RankShared rk;
+  __shared__ uint64_t g_base[kBins];
+  __shared__ uint64_t wave_total[kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int64_t base = (int64_t)tile * kTile;
+  const int n_tile = (int)(n - base < (int64_t)kTile ? n - base : (int64_t)kTile);
+  rank_reset(rk);
+  if (threadIdx.x == 0) n_owned = 0;
+  const uint64_t bin_base = block_exclusive_scan_256(totals[threadIdx.x], wave_total);
+  bool stable = false;
+  if (PASS == 2) {
+    // The input is in lo order: position P[lo] = sum of the first pass's totals below lo is where lo's run starts.  The tile that
+    // holds that position (the last tile when it is the end of the input) OWNS lo: it will say where the pieces (hi, lo) start.
+    __syncthreads();   // wave_total is reused
+    const int64_t q = (int64_t)block_exclusive_scan_256(totals_lo[threadIdx.x], wave_total) - base;   // thread = lo
+    const bool last = base + kTile >= n;
+    const bool own = q >= 0 && (q < kTile || (last && q <= (int64_t)n_tile));
+    if (own) s_owned[atomicAdd(&n_owned, 1u)] = threadIdx.x | ((uint32_t)q << 8);
+    stable = __syncthreads_or(own && q > 0 && q < (int64_t)n_tile) != 0;   // a boundary INSIDE the tile: order matters
+  }
+  const int64_t first = base + (int64_t)wave * kPerWave + lane;
+  uint32_t rem[kRounds], digit[kRounds], carry[kRounds], place[kRounds], live_mask = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = first + r * 64;
+    const bool live = i < n;
+    rem[r] = live ? rem_in[i] : 0;
+    if (PASS == 1) {
+      const uint32_t v = live ? hl_in[i] : 0;
+      digit[r] = v & 0xff;
+      carry[r] = v >> 8;
+    } else {
+      digit[r] = live ? hi_in[i] : 0;
+      carry[r] = 0;
+    }
+    live_mask |= (live ? 1u : 0u) << r;
+  }
+  if (stable) {
+    rank_rounds(digit, live_mask, place, rk);
+    __syncthreads();
+    rank_place_bins(rk);
+  } else {
+    rank_any_rounds(digit, live_mask, place, rk);
+    __syncthreads();
+    rank_any_place_bins(rk);
+  }
+  g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    if ((live_mask >> r) & 1u) {
+      const uint32_t at = rk.bin_start[digit[r]] + rk.wave_cnt[wave][digit[r]] + place[r];   // (the wave offsets are zero in any-order tiles)
+      s_rem[at] = rem[r];
+      s_dig[at] = (uint8_t)digit[r];
+      if (PASS == 1) s_hi[at] = (uint8_t)carry[r];
+      if (PASS == 2) s_orig[at] = (uint16_t)(wave * kPerWave + r * 64 + lane);
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int j = threadIdx.x; j < n_tile; j += kThreads) {
+    const uint32_t d = s_dig[j];
+    const uint64_t to = g_base[d] + (uint32_t)(j - (int)rk.bin_start[d]);
+    rem_out[to] = s_rem[j];
+    if (PASS == 1) hi_out[to] = s_hi[j];
+  }
+  if (PASS == 2) {
+    // starts[hi * 256 + lo] = index (in the pass's OUTPUT) of the first element whose piece is >= hi * 256 + lo = this tile's
+    // place in bin hi + the number of its bin-hi elements in front of tile-local position q (the ones with a smaller lo).  In
+    // a stable tile those come first inside the bin: found by their original positions.  Thread = hi.
+    const uint32_t b0 = rk.bin_start[threadIdx.x], cnt = rk.bin_count[threadIdx.x];
+    const uint64_t gb = g_base[threadIdx.x];
+    const uint32_t n_own = n_owned;
+    for (uint32_t k = 0; k < n_own; ++k) {   // (uniform over the workgroup; nearly every tile owns no boundary or one)
+      const uint32_t lo = s_owned[k] & 0xff, q = s_owned[k] >> 8;
+      uint32_t a = 0, b = cnt;                 // first place in the bin whose original position is >= q
+      if (q == 0) {
+        b = 0;
+      } else if (q >= (uint32_t)n_tile) {
+        a = cnt;
+      } else {
+        while (a < b) {
+          const uint32_t mid = (a + b) >> 1;
+          if ((uint32_t)s_orig[b0 + mid] < q) a = mid + 1; else b = mid;
+        }
+      }
+      starts[threadIdx.x * kBins + lo] = (uint32_t)(gb + a);
+    }
+    if (tile == 0 && threadIdx.x == 0) {
+      starts[kPieces] = (uint32_t)n;
+      starts[kPieces + 1] = (uint32_t)n;
     }
   }
 }
 
+// REGION_LOG2: slots per LDS region.  sub_log2: log2 of the pieces per region (0 when a piece IS a region: tables of 2^27 slots
+// and more; smaller tables have pieces of fewer than 2048 slots, a region then takes 2^sub_log2 consecutive ones).
 template <int REGION_LOG2>
-__global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* __restrict__ words, const uint32_t* __restrict__ starts,
-                                                               uint32_t n_regions, uint64_t* __restrict__ table, int log2cap,
-                                                               unsigned long long* __restrict__ counters,
+__global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
+                                                               uint32_t n_regions, int sub_log2, uint64_t* __restrict__ table, int log2cap,
                                                                uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                               unsigned long long spill_cap, int pristine, uint32_t r_begin,
+                                                               unsigned long long spill_cap, int pristine,
                                                                unsigned long long* __restrict__ partials) {
   constexpr int kSlots = 1 << REGION_LOG2;
-  constexpr int kAhead = 4;   // keys per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
+  constexpr int kAhead = 4;   // elements per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
   __shared__ unsigned wg_count[2];
   if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;   // (ordered before its first use by the barrier in front of the adds at the end)
   __shared__ __attribute__((aligned(16))) unsigned long long region[kSlots];
@@ -323,11 +460,22 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
   const int lane = threadIdx.x & 63;
   unsigned n_new = 0, n_over = 0;
   bool mine_changed = false;
-  auto insert = [&](uint64_t word) {
-    if (word == kSkip) return;
-    const uint64_t key = word & kKeyMask48;
+  // element i of region r: which piece it belongs to (its position says so), hence its h48, its key and its home slot
+  auto insert = [&](uint32_t r, uint32_t i, uint32_t rem) {
+    uint32_t piece = r << sub_log2;
+    if (sub_log2) {   // the last piece of the region whose run starts at or before i
+      uint32_t a = 0, b = (1u << sub_log2) - 1;
+      while (a < b) {
+        const uint32_t mid = (a + b + 1) >> 1;
+        if (starts[piece + mid] <= i) a = mid; else b = mid - 1;
+      }
+      piece += a;
+    }
+    const uint64_t h = ((uint64_t)piece << 32) | rem;
+    if (h == kMask48) return;   // an element that carries no key
+    const uint64_t key = unhash48(h);
     bool done = false;
-    for (uint32_t s = (uint32_t)home_slot(key, log2cap) & (kSlots - 1); s < (uint32_t)kSlots && !done; ++s) {
+    for (uint32_t s = (uint32_t)(h >> (48 - log2cap)) & (kSlots - 1); s < (uint32_t)kSlots && !done; ++s) {
       const unsigned long long old = atomicCAS(&region[s], (unsigned long long)kEmpty, (unsigned long long)key);
       if (old == kEmpty) {
         ++n_new;
@@ -342,31 +490,31 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
       if (at < spill_cap) spill[at] = key; else ++n_over;
     }
   };
-  auto fetch = [&](uint32_t lo_, uint32_t hi_, uint64_t (&dst)[kAhead]) {
+  auto fetch = [&](uint32_t lo_, uint32_t hi_, uint32_t (&dst)[kAhead]) {
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
       const uint32_t i = lo_ + (uint32_t)k * kThreads + threadIdx.x;
-      dst[k] = i < hi_ ? words[i] : kSkip;
+      dst[k] = i < hi_ ? rems[i] : 0;
     }
   };
-  // The loop is a pipeline: a region's first keys are fetched while the region before it is being worked on (its bounds one
-  // step earlier still) -- per region the workgroup otherwise sat out three dependent memory round trips (bounds, keys, and
-  // with a table that is not fresh its slots) between barriers: 582 us for 65536 regions, 3 TB/s of streams that can do 6.
-  uint32_t r = r_begin + blockIdx.x, lo = 0, hi = 0;   // regions [r_begin, n_regions): one phase of the merge
+  // The loop is a pipeline: a region's first elements are fetched while the region before it is being worked on (its bounds one
+  // step earlier still) -- per region the workgroup otherwise sat out three dependent memory round trips (bounds, elements, and
+  // with a table that is not fresh its slots) between barriers.
+  uint32_t r = blockIdx.x, lo = 0, hi = 0;
   if (r < n_regions) {
-    lo = starts[r];
-    hi = starts[r + 1];
+    lo = starts[r << sub_log2];
+    hi = starts[(r + 1) << sub_log2];
   }
-  uint64_t cur[kAhead];
+  uint32_t cur[kAhead];
   fetch(lo, hi, cur);
   while (r < n_regions) {   // workgroup-uniform trip count
     const uint32_t rn = r + gridDim.x;
     uint32_t lon = 0, hin = 0;
     if (rn < n_regions) {
-      lon = starts[rn];
-      hin = starts[rn + 1];
+      lon = starts[rn << sub_log2];
+      hin = starts[(rn + 1) << sub_log2];
     }
-    uint64_t nxt[kAhead];
+    uint32_t nxt[kAhead];
     if (lo != hi) {   // (a region that received nothing is not even read)
       ulonglong2* g = reinterpret_cast<ulonglong2*>(table + ((uint64_t)r << REGION_LOG2));
       r3d_vox::lds_barrier();   // the previous region's write-back has read the LDS copy (its stores may still be in flight)
@@ -382,8 +530,11 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
       fetch(lon, hin, nxt);   // in flight while this region's keys go in (and across the barriers: they order LDS only)
       mine_changed = false;
 #pragma unroll
-      for (int k = 0; k < kAhead; ++k) insert(cur[k]);
-      for (uint32_t i = lo + kAhead * kThreads + threadIdx.x; i < hi; i += kThreads) insert(words[i]);   // a longer run than usual
+      for (int k = 0; k < kAhead; ++k) {
+        const uint32_t i = lo + (uint32_t)k * kThreads + threadIdx.x;
+        if (i < hi) insert(r, i, cur[k]);
+      }
+      for (uint32_t i = lo + kAhead * kThreads + threadIdx.x; i < hi; i += kThreads) insert(r, i, rems[i]);   // a longer run than usual
       if (mine_changed) changed = 1;   // (benign race: everybody writes the same value)
       r3d_vox::lds_barrier();
       if (changed) {   // (nontemporal stores change nothing here: measured)
@@ -414,31 +565,6 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint64_t* _
   }
   r3d_vox::lds_barrier();
   if (threadIdx.x < 2) partials[2 * (uint64_t)blockIdx.x + threadIdx.x] = wg_count[threadIdx.x];
-}
-
-// Read-only sweep of the words of regions [r0, r1) (their bounds are on the device only): leaves them in the Infinity Cache for
-// the merge launch that follows.  Same reason as the fused kernels' input staging (r3d_fuse.hip): the merge writes three bytes
-// for every one it reads, and reads sprinkled among writes halve what the DRAM delivers -- 455 us for 1.46 GB.  Phased (sweep
-// ~96 MB of keys, then merge their regions from the cache while HBM sees a pure write stream) the same work takes under 300.
-__global__ __launch_bounds__(kThreads) void voxel_touch_kernel(const uint64_t* __restrict__ words, const uint32_t* __restrict__ starts,
-                                                               uint32_t r0, uint32_t r1, uint32_t* __restrict__ sink) {
-  const uint64_t lo = ((uint64_t)starts[r0] + 1) & ~(uint64_t)1, hi = (uint64_t)starts[r1] & ~(uint64_t)1;   // whole 16-byte pieces
-  if (hi <= lo) return;
-  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(words + lo);
-  const uint64_t n16 = (hi - lo) / 2;
-  uint64_t acc = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * (kThreads * 4);
-  for (uint64_t base = (uint64_t)blockIdx.x * (kThreads * 4) + threadIdx.x; base < n16; base += stride) {
-    ulonglong2 q[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint64_t i = base + (uint64_t)k * kThreads;
-      q[k] = src[i < n16 ? i : n16 - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc ^= q[k].x ^ q[k].y;
-  }
-  if (acc == 0x9e3779b97f4a7c15ull && n16 == ~(uint64_t)0) *sink = 1;   // never true: keeps the loads, writes nothing
 }
 
 // the deferred keys, by the ordinary CAS (their count is known on the device only: fixed grid, device-side bound)
@@ -523,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_codes_kernel(const uint
     if (live && lane > 0 && prev == code) live = false;  // sorted inputs repeat a code in neighbouring lanes
     if (live) {
       code = r3d_vox::key_of_morton(code);  // the table holds packed keys (r3d_voxel_dev.h)
-      uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+      uint64_t slot = r3d_vox::home_slot(code, log2cap);
       bool done = false;
       for (uint64_t probe = 0; probe <= mask && !done; ++probe) {
         const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
@@ -860,7 +986,7 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
 // `forced`, worth considering for this many points (its fixed costs -- a dozen launches, the table streamed once -- want a
 // big insert and a table that is not vastly larger than it)?
 bool r3d_voxelset_sort_feasible(const r3d_voxelset* vs, int64_t n_points, bool forced) {
-  if (vs->log2cap < 16 || vs->log2cap > kMaxRegionBits + kRegionMaxLog2) return false;
+  if (vs->log2cap < kPieceBits || vs->log2cap > kPieceBits + kRegionMaxLog2) return false;
   if (forced) return n_points >= 1;
   return n_points >= ((int64_t)1 << 22) && vs->capacity <= (uint64_t)n_points * 16;
 }
@@ -889,69 +1015,66 @@ int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, 
 
 static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) {
   r3d_ctx* ctx = vs->ctx;
-  const int region_bits = std::min(kMaxRegionBits, vs->log2cap - kRegionMinLog2);
-  const int region_log2 = vs->log2cap - region_bits;
-  const uint32_t n_regions = (uint32_t)1 << region_bits;
-  const int64_t chunk = (int64_t)1 << 27;   // points per round: 1 GB of words + 1 GB of sort scratch
+  const int region_log2 = std::max(kRegionMinLog2, vs->log2cap - kPieceBits);   // slots per LDS region
+  const int sub_log2 = kPieceBits - (vs->log2cap - region_log2);                // pieces per region (log2)
+  const uint32_t n_regions = (uint32_t)1 << (vs->log2cap - region_log2);
+  const int64_t chunk = (int64_t)1 << 27;   // points per round: 0.8 GB of elements + 0.7 GB of sort scratch
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   int rc;
   for (int64_t off = 0; off < n_points; off += chunk) {
     const int64_t m = std::min(chunk, n_points - off);
     const float* src = d_xyz + off * 3;
     const uint64_t spill_cap = (uint64_t)m;   // every key may be deferred (a nearly full table): the list can take them all
-    void *words_v = nullptr, *tmp_v = nullptr, *ws = nullptr;
-    if ((rc = r3d_scratch(ctx, 1, (size_t)m * 8, &words_v))) return rc;
-    if ((rc = r3d_scratch(ctx, 2, (size_t)m * 8, &tmp_v))) return rc;
-    const size_t starts_bytes = (((size_t)n_regions + 2) * sizeof(uint32_t) + 63) & ~(size_t)63;
-    constexpr int kMaxPhases = 64;
+    const int64_t n_tiles64 = (m + kSortTile - 1) / kSortTile;
+    const int n_tiles = (int)n_tiles64, stride = r3d_sort_stride(n_tiles);
+    void *a_v = nullptr, *b_v = nullptr, *ws = nullptr;
+    if ((rc = r3d_scratch(ctx, 1, up((size_t)m * 4) + up((size_t)m * 2), &a_v))) return rc;   // rem | hl, later the sorted rem
+    if ((rc = r3d_scratch(ctx, 2, up((size_t)m * 4) + up((size_t)m), &b_v))) return rc;       // rem | hi after the first pass
+    uint32_t* rem_a = static_cast<uint32_t*>(a_v);
+    uint16_t* hl_a = reinterpret_cast<uint16_t*>(static_cast<char*>(a_v) + up((size_t)m * 4));
+    uint32_t* rem_b = static_cast<uint32_t*>(b_v);
+    uint8_t* hi_b = reinterpret_cast<uint8_t*>(static_cast<char*>(b_v) + up((size_t)m * 4));
     const unsigned merge_grid = ctx->voxel_merge_blocks > 0 ? (unsigned)std::min(ctx->voxel_merge_blocks, 1 << 16) : (unsigned)ctx->num_cus * 8;
-    const size_t partial_bytes = (size_t)kMaxPhases * merge_grid * 2 * sizeof(unsigned long long);
-    if ((rc = r3d_scratch(ctx, 5, 64 + partial_bytes + starts_bytes + spill_cap * 8, &ws))) return rc;
-    unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 32);
-    unsigned long long* d_partials = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 64);
-    uint32_t* d_starts = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + 64 + partial_bytes);
-    uint64_t* d_spill = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + 64 + partial_bytes + starts_bytes);
-    uint64_t* words = static_cast<uint64_t*>(words_v);
+    const size_t partial_bytes = up((size_t)merge_grid * 2 * sizeof(unsigned long long));
+    const size_t starts_bytes = up(((size_t)kPieces + 2) * sizeof(uint32_t));
+    const size_t hist_bytes = up((size_t)256 * stride * sizeof(uint32_t));
+    if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + spill_cap * 8, &ws))) return rc;
+    char* w = static_cast<char*>(ws);
+    unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(w + 32);
+    unsigned long long* d_partials = reinterpret_cast<unsigned long long*>(w + 256);
+    uint32_t* d_starts = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes);
+    uint32_t* hist_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes);
+    uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes);
+    uint32_t* totals_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes);
+    uint32_t* totals_hi = totals_lo + 256;
+    uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
     R3D_HIP(hipMemsetAsync(d_spill_count, 0, 8, ctx->stream));
-    uint32_t* hist = nullptr;
-    int n_tiles = 0;
-    if ((rc = r3d_radix_sort_workspace(ctx, m, &hist, &n_tiles))) return rc;
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, vs->log2cap, region_log2,
-                       words, hist, r3d_sort_stride(n_tiles), d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
-    R3D_HIP(hipGetLastError());
-    uint64_t* sorted = nullptr;
-    // both region digits, always: the words that carry no key (all ones) must end up behind every region.  The first
-    // digit's histogram is the key kernel's.
-    if ((rc = r3d_radix_sort_u64(ctx, words, static_cast<uint64_t*>(tmp_v), m, 64, 48, &sorted, true))) return rc;
-    const unsigned bound_blocks = (unsigned)std::min<int64_t>((m / 8 + 2 + kThreads) / kThreads, (int64_t)ctx->num_cus * 32);
-    hipLaunchKernelGGL(voxel_bounds_kernel, dim3(bound_blocks), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted, m, n_regions, d_starts);
-    // The merge, as ONE launch.  ("voxel_merge_phases" > 1 = A/B only: sweep ~1/k of the words into the Infinity Cache, merge
-    // their regions, next -- the phasing that rescues the fused kernels' inputs.  Measured: 1.36 ms unphased, 1.37 / 1.40 / 1.44
-    // with 2 / 4 / 8 phases; the merge's reads are a quarter of its traffic and stream well enough.)
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, rem_a, hl_a, hist_lo,
+                       stride, d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
+    r3d_sort_launch_scan(ctx, hist_lo, n_tiles, stride, totals_lo);
+    hipLaunchKernelGGL(piece_scatter_kernel<1>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
+                       (const uint16_t*)hl_a, (const uint8_t*)nullptr, m, (const uint32_t*)hist_lo, stride, (const uint32_t*)totals_lo,
+                       (const uint32_t*)nullptr, rem_b, hi_b, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(byte_histogram_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b, m, n_tiles,
+                       hist_hi, stride);
+    r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
+    hipLaunchKernelGGL(piece_scatter_kernel<2>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
+                       (const uint16_t*)nullptr, (const uint8_t*)hi_b, m, (const uint32_t*)hist_hi, stride, (const uint32_t*)totals_hi,
+                       (const uint32_t*)totals_lo, rem_a, (uint8_t*)nullptr, d_starts);
     const int pristine = vs->pristine ? 1 : 0;
     vs->pristine = false;
-    const uint32_t n_phases = std::min<uint32_t>(std::min<uint32_t>(n_regions, kMaxPhases),
-                                                 ctx->voxel_merge_phases > 0 ? (uint32_t)ctx->voxel_merge_phases : 1u);
-    int n_partials = 0;
-    for (uint32_t ph = 0; ph < n_phases; ++ph) {
-      const uint32_t r0 = (uint32_t)((uint64_t)n_regions * ph / n_phases), r1 = (uint32_t)((uint64_t)n_regions * (ph + 1) / n_phases);
-      if (r1 == r0) continue;
-      if (n_phases > 1)
-        hipLaunchKernelGGL(voxel_touch_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted,
-                           (const uint32_t*)d_starts, r0, r1, static_cast<uint32_t*>(nullptr));
-      const unsigned merge_blocks = std::min<uint32_t>(r1 - r0, merge_grid);   // persistent workgroups: the loop inside is a pipeline
-#define R3D_LAUNCH_MERGE(L2)                                                                                                      \
-  hipLaunchKernelGGL(voxel_merge_kernel<L2>, dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint64_t*)sorted,         \
-                     (const uint32_t*)d_starts, r1, vs->d_table, vs->log2cap, vs->d_counters, d_spill, d_spill_count,            \
-                     (unsigned long long)spill_cap, pristine, r0, d_partials + 2 * (size_t)n_partials)
-      if (region_log2 == 11) R3D_LAUNCH_MERGE(11);
-      else if (region_log2 == 12) R3D_LAUNCH_MERGE(12);
-      else R3D_LAUNCH_MERGE(13);
+    const unsigned merge_blocks = std::min<uint32_t>(n_regions, merge_grid);   // persistent workgroups: the loop inside is a pipeline
+#define R3D_LAUNCH_MERGE(L2)                                                                                                            \
+  hipLaunchKernelGGL(voxel_merge_kernel<L2>, dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,                \
+                     (const uint32_t*)d_starts, n_regions, sub_log2, vs->d_table, vs->log2cap, d_spill, d_spill_count,                  \
+                     (unsigned long long)spill_cap, pristine, d_partials)
+    if (region_log2 == 11) R3D_LAUNCH_MERGE(11);
+    else if (region_log2 == 12) R3D_LAUNCH_MERGE(12);
+    else R3D_LAUNCH_MERGE(13);
 #undef R3D_LAUNCH_MERGE
-      n_partials += (int)merge_blocks;
-    }
     hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
                        (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters,
-                       (const unsigned long long*)d_partials, n_partials);
+                       (const unsigned long long*)d_partials, (int)merge_blocks);
     R3D_HIP(hipGetLastError());
   }
   return R3D_OK;

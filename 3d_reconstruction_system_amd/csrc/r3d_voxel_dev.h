@@ -117,9 +117,27 @@ __device__ __forceinline__ void flush_counts(unsigned n_new, unsigned n_ignored,
   if (threadIdx.x < 3 && wg[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)wg[threadIdx.x]);
 }
 
+// Where a packed key lives in the table: the top log2cap bits of h48 = key * G mod 2^48.  G is odd, so key -> h48 is a
+// BIJECTION of the 48-bit keys (key = h48 * G^-1 mod 2^48): the top 16 bits of h48 name one of 65536 consecutive pieces of the
+// table and the low 32 bits say which of the 2^32 keys of that piece it is.  The sort-merge insert (r3d_voxel.hip) lives on
+// that: once the keys are in piece order a key is its 32-bit remainder -- the sort moves 4-byte words, not 8-byte ones.
+// (Rounds 2-4 hashed with the 64-bit golden-ratio multiplier; the table is internal, its layout was free to change.)
+constexpr uint64_t kMask48 = ((uint64_t)1 << 48) - 1;
+constexpr uint64_t kHashMul48 = 0x9E3779B97F4Bull;   // ~ 2^48 / golden ratio, odd
+constexpr uint64_t inverse_mod_2_64(uint64_t a) {      // Newton: x <- x (2 - a x) doubles the correct low bits (a odd)
+  uint64_t x = a;
+  for (int k = 0; k < 6; ++k) x *= 2 - a * x;
+  return x;
+}
+constexpr uint64_t kHashInv48 = inverse_mod_2_64(kHashMul48) & kMask48;
+static_assert(((kHashMul48 * kHashInv48) & kMask48) == 1, "48-bit multiplicative inverse");
+__host__ __device__ __forceinline__ uint64_t hash48(uint64_t key) { return (key * kHashMul48) & kMask48; }
+__host__ __device__ __forceinline__ uint64_t unhash48(uint64_t h48) { return (h48 * kHashInv48) & kMask48; }
+__host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, int log2cap) { return hash48(key) >> (48 - log2cap); }
+
 // One code into the global open-addressing table (64-bit CAS, linear probing).  Returns 1 new, 0 already there, -1 no slot.
 __device__ __forceinline__ int table_insert(uint64_t* __restrict__ table, uint64_t mask, int log2cap, uint64_t code) {
-  uint64_t slot = (code * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+  uint64_t slot = home_slot(code, log2cap);
   for (uint64_t probe = 0; probe <= mask; ++probe) {
     const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty,
                                    (unsigned long long)code);
