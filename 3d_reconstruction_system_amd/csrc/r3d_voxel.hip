@@ -443,27 +443,41 @@ __global__ __launch_bounds__(kThreads) void piece_scatter_kernel(const uint32_t*
   }
 }
 
-// REGION_LOG2: slots per LDS region.  sub_log2: log2 of the pieces per region (0 when a piece IS a region: tables of 2^27 slots
-// and more; smaller tables have pieces of fewer than 2048 slots, a region then takes 2^sub_log2 consecutive ones).
-template <int REGION_LOG2>
+// REGION_LOG2: slots per LDS region.  SUB: several pieces per region (tables below 2^27 slots, whose pieces have fewer than
+// 2048 slots: a region then takes 2^sub_log2 consecutive ones); otherwise a piece IS a region and sub_log2 is 0.
+//
+// What this kernel waits for is not only HBM (round 5, one stage switched off at a time on one box: everything 350 us; without
+// the compare-and-swaps 294, without the element loads 267, without the table stores 248, the loop's skeleton alone -- bounds,
+// barriers, LDS initialisation -- 96).  Two things are therefore done differently from round 4, each measured in the SAME process
+// against the old form (BATCHED / PIPED = false; medians of 7 launches, twice): bounds alone 412 -> 397 us, attempts alone
+// 412 -> 401, both 412 -> 385.  (1) BATCHED: a workgroup fetches the bounds of 128 of its regions at once into LDS instead of
+// two scalar loads per region that the next barrier waits for (their lines are evicted from the L2 by the table stream all the
+// time: a memory round trip per region, exposed); (2) PIPED: a thread's four elements make their first compare-and-swap attempt
+// back to back, four LDS round trips in flight, before the (rare) re-probes are walked one by one.  (The kernel's duration
+// differs by up to 1.4x between boxes of the pool -- 283 us and 412 us for the same binary -- while the streaming kernels
+// around it agree within 2 %: compare variants inside one process only.)
+template <int REGION_LOG2, bool SUB, bool BATCHED = true, bool PIPED = true>
 __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
-                                                               uint32_t n_regions, int sub_log2, uint64_t* __restrict__ table, int log2cap,
+                                                               uint32_t n_regions, int sub_log2_arg, uint64_t* __restrict__ table, int log2cap,
                                                                uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
                                                                unsigned long long spill_cap, int pristine,
                                                                unsigned long long* __restrict__ partials) {
+  const int sub_log2 = SUB ? sub_log2_arg : 0;
   constexpr int kSlots = 1 << REGION_LOG2;
-  constexpr int kAhead = 4;   // elements per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
+  constexpr int kAhead = 4;    // elements per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
+  constexpr int kBatch = 128;  // regions whose bounds a workgroup holds in LDS at a time
   __shared__ unsigned wg_count[2];
   if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;   // (ordered before its first use by the barrier in front of the adds at the end)
   __shared__ __attribute__((aligned(16))) unsigned long long region[kSlots];
+  __shared__ uint32_t s_lo[kBatch + 1], s_hi[kBatch + 1];
   __shared__ unsigned changed;
   const int lane = threadIdx.x & 63;
   unsigned n_new = 0, n_over = 0;
   bool mine_changed = false;
   // element i of region r: which piece it belongs to (its position says so), hence its h48, its key and its home slot
-  auto insert = [&](uint32_t r, uint32_t i, uint32_t rem) {
+  auto hash_of = [&](uint32_t r, uint32_t i, uint32_t rem) -> uint64_t {
     uint32_t piece = r << sub_log2;
-    if (sub_log2) {   // the last piece of the region whose run starts at or before i
+    if (SUB) {   // the last piece of the region whose run starts at or before i
       uint32_t a = 0, b = (1u << sub_log2) - 1;
       while (a < b) {
         const uint32_t mid = (a + b + 1) >> 1;
@@ -471,24 +485,36 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
       }
       piece += a;
     }
-    const uint64_t h = ((uint64_t)piece << 32) | rem;
-    if (h == kMask48) return;   // an element that carries no key
-    const uint64_t key = unhash48(h);
+    return ((uint64_t)piece << 32) | rem;
+  };
+  // the probe from slot s on (the first attempt at the home slot may already have been made: `old` is what it found)
+  auto probe_on = [&](uint64_t key, uint32_t s, unsigned long long old) {
     bool done = false;
-    for (uint32_t s = (uint32_t)(h >> (48 - log2cap)) & (kSlots - 1); s < (uint32_t)kSlots && !done; ++s) {
-      const unsigned long long old = atomicCAS(&region[s], (unsigned long long)kEmpty, (unsigned long long)key);
+    for (;;) {
       if (old == kEmpty) {
         ++n_new;
         mine_changed = true;
         done = true;
-      } else if (old == key) {
-        done = true;
+        break;
       }
+      if (old == key) {
+        done = true;
+        break;
+      }
+      if (++s >= (uint32_t)kSlots) break;
+      old = atomicCAS(&region[s], (unsigned long long)kEmpty, (unsigned long long)key);
     }
     if (!done) {   // every slot from home to the region's end is taken by others: the probe goes on in the next region -- later
       const unsigned long long at = atomicAdd(spill_count, 1ull);
       if (at < spill_cap) spill[at] = key; else ++n_over;
     }
+  };
+  auto insert_one = [&](uint32_t r, uint32_t i, uint32_t rem) {
+    const uint64_t h = hash_of(r, i, rem);
+    if (h == kMask48) return;   // an element that carries no key
+    const uint64_t key = unhash48(h);
+    const uint32_t s = (uint32_t)(h >> (48 - log2cap)) & (kSlots - 1);
+    probe_on(key, s, atomicCAS(&region[s], (unsigned long long)kEmpty, (unsigned long long)key));
   };
   auto fetch = [&](uint32_t lo_, uint32_t hi_, uint32_t (&dst)[kAhead]) {
 #pragma unroll
@@ -497,20 +523,41 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
       dst[k] = i < hi_ ? rems[i] : 0;
     }
   };
-  // The loop is a pipeline: a region's first elements are fetched while the region before it is being worked on (its bounds one
-  // step earlier still) -- per region the workgroup otherwise sat out three dependent memory round trips (bounds, elements, and
-  // with a table that is not fresh its slots) between barriers.
-  uint32_t r = blockIdx.x, lo = 0, hi = 0;
-  if (r < n_regions) {
+  // the bounds of the regions of batch `it0`: iteration j of the batch works on region blockIdx.x + (it0 + j) * gridDim.x
+  auto load_bounds = [&](uint32_t it0) {
+    if (threadIdx.x <= (unsigned)kBatch) {
+      const uint64_t rr = (uint64_t)blockIdx.x + (uint64_t)(it0 + threadIdx.x) * gridDim.x;
+      uint32_t a = 0, b = 0;
+      if (rr < n_regions) {
+        a = starts[(uint32_t)rr << sub_log2];
+        b = starts[((uint32_t)rr + 1) << sub_log2];
+      }
+      s_lo[threadIdx.x] = a;
+      s_hi[threadIdx.x] = b;
+    }
+  };
+  // The loop is a pipeline: a region's first elements are fetched while the region before it is being worked on.
+  uint32_t it = 0, r = blockIdx.x;
+  if (BATCHED) load_bounds(0);
+  __syncthreads();
+  uint32_t lo = 0, hi = 0;
+  if (BATCHED) {
+    lo = s_lo[0];
+    hi = s_hi[0];
+  } else if (r < n_regions) {
     lo = starts[r << sub_log2];
     hi = starts[(r + 1) << sub_log2];
   }
   uint32_t cur[kAhead];
   fetch(lo, hi, cur);
   while (r < n_regions) {   // workgroup-uniform trip count
+    const uint32_t j = it % kBatch;
     const uint32_t rn = r + gridDim.x;
     uint32_t lon = 0, hin = 0;
-    if (rn < n_regions) {
+    if (BATCHED) {
+      lon = s_lo[j + 1];   // (entry kBatch of a batch = entry 0 of the next one)
+      hin = s_hi[j + 1];
+    } else if (rn < n_regions) {
       lon = starts[rn << sub_log2];
       hin = starts[(rn + 1) << sub_log2];
     }
@@ -529,12 +576,34 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
       r3d_vox::lds_barrier();
       fetch(lon, hin, nxt);   // in flight while this region's keys go in (and across the barriers: they order LDS only)
       mine_changed = false;
+      if (!PIPED) {
 #pragma unroll
-      for (int k = 0; k < kAhead; ++k) {
-        const uint32_t i = lo + (uint32_t)k * kThreads + threadIdx.x;
-        if (i < hi) insert(r, i, cur[k]);
+        for (int k = 0; k < kAhead; ++k) {
+          const uint32_t i = lo + (uint32_t)k * kThreads + threadIdx.x;
+          if (i < hi) insert_one(r, i, cur[k]);
+        }
+      } else {
+        // first attempts of the thread's (up to) four elements back to back, then the re-probes
+        uint64_t key[kAhead];
+        uint32_t slot[kAhead];
+        unsigned long long old[kAhead];
+        bool has[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+          const uint32_t i = lo + (uint32_t)k * kThreads + threadIdx.x;
+          const uint64_t h = i < hi ? hash_of(r, i, cur[k]) : kMask48;
+          has[k] = h != kMask48;
+          key[k] = unhash48(h);
+          slot[k] = (uint32_t)(h >> (48 - log2cap)) & (kSlots - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k)
+          old[k] = has[k] ? atomicCAS(&region[slot[k]], (unsigned long long)kEmpty, (unsigned long long)key[k]) : 0ull;
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k)
+          if (has[k]) probe_on(key[k], slot[k], old[k]);
       }
-      for (uint32_t i = lo + kAhead * kThreads + threadIdx.x; i < hi; i += kThreads) insert(r, i, rems[i]);   // a longer run than usual
+      for (uint32_t i = lo + kAhead * kThreads + threadIdx.x; i < hi; i += kThreads) insert_one(r, i, rems[i]);   // a longer run than usual
       if (mine_changed) changed = 1;   // (benign race: everybody writes the same value)
       r3d_vox::lds_barrier();
       if (changed) {   // (nontemporal stores change nothing here: measured)
@@ -549,6 +618,12 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
     r = rn;
     lo = lon;
     hi = hin;
+    ++it;
+    if (BATCHED && it % kBatch == 0) {   // the next batch of bounds (workgroup-uniform)
+      __syncthreads();        // everybody has read entry kBatch
+      load_bounds(it);
+      __syncthreads();
+    }
   }
   // The counts leave as ONE pair of words per workgroup, each in a slot of its own, summed by voxel_spill_kernel.  (One
   // atomicAdd per wave on the set's counters -- the first form -- was what the whole kernel waited for: adds to ONE address
@@ -1064,13 +1139,14 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     const int pristine = vs->pristine ? 1 : 0;
     vs->pristine = false;
     const unsigned merge_blocks = std::min<uint32_t>(n_regions, merge_grid);   // persistent workgroups: the loop inside is a pipeline
-#define R3D_LAUNCH_MERGE(L2)                                                                                                            \
-  hipLaunchKernelGGL(voxel_merge_kernel<L2>, dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,                \
+#define R3D_LAUNCH_MERGE(L2, SUB)                                                                                                       \
+  hipLaunchKernelGGL((voxel_merge_kernel<L2, SUB>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,         \
                      (const uint32_t*)d_starts, n_regions, sub_log2, vs->d_table, vs->log2cap, d_spill, d_spill_count,                  \
                      (unsigned long long)spill_cap, pristine, d_partials)
-    if (region_log2 == 11) R3D_LAUNCH_MERGE(11);
-    else if (region_log2 == 12) R3D_LAUNCH_MERGE(12);
-    else R3D_LAUNCH_MERGE(13);
+    if (sub_log2 > 0) R3D_LAUNCH_MERGE(11, true);       // tables below 2^27 slots: several pieces per 2048-slot region
+    else if (region_log2 == 11) R3D_LAUNCH_MERGE(11, false);
+    else if (region_log2 == 12) R3D_LAUNCH_MERGE(12, false);
+    else R3D_LAUNCH_MERGE(13, false);
 #undef R3D_LAUNCH_MERGE
     hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
                        (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters,

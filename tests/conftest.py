@@ -29,7 +29,7 @@ def pytest_configure(config):
 # that starts bench.py or needs more than one GPU LAST -- a wobble in a measurement must never stand between the run and the
 # correctness evidence (round 3 lost 450 parity tests to a timing assertion in the file that sorted first).
 GPU_ORDER = ["test_gpu_fusion", "test_gpu_textfmt", "test_gpu_dropin", "test_gpu_c_consumer", "test_gpu_icp", "test_gpu_plane_icp", "test_gpu_voxel",
-             "test_gpu_torch_ops", "test_gpu_comm", "test_gpu_dist", "test_gpu_eight_ranks", "test_gpu_bench_contract",
+             "test_gpu_torch_ops", "test_gpu_config5_full", "test_gpu_comm", "test_gpu_dist", "test_gpu_eight_ranks", "test_gpu_bench_contract",
              "test_gpu_multi_device"]
 
 

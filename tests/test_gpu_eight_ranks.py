@@ -74,6 +74,22 @@ def test_four_ranks_ragged_1001_frames(tmp_path, mock_rccl):
     assert "lo=0 hi=251" in open(out + ".rank0").read() and "lo=753 hi=1001" in open(out + ".rank3").read()
 
 
+def test_config4_whole_1000_frames_over_four_ranks_bit_for_bit(tmp_path, mock_rccl):
+    """BASELINE config 4 at its full size: 1000 frames of 1280x384 = 491.52 M points, 5.9 GB of xyz, through dist.ShardedFusion
+    over four ranks -- both assemblies, every rank comparing EVERY bit of the assembled cloud with the cloud of one launch over
+    all 1000 frames (tests/_dist_c4_worker.py)."""
+    if shm_free_bytes() < 24 << 30:
+        pytest.skip("the stand-in transport needs ~18 GB of /dev/shm for this exchange (%d MB free)" % (shm_free_bytes() >> 20))
+    out = str(tmp_path / "c4")
+    r = launch(4, [os.path.join(ROOT, "tests", "_dist_c4_worker.py"), out, "1000"], mock_rccl)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for rank in range(4):
+        line = open("%s.rank%d" % (out, rank)).read()
+        assert "ok=1" in line and "R3D_RCCL_PATH" in line and "points=491520000" in line, line
+        assert "outputs: True" in line and "inputs: True" in line, line
+    assert "lo=0 hi=250" in open(out + ".rank0").read() and "lo=750 hi=1000" in open(out + ".rank3").read()
+
+
 def test_four_ranks_equal_shards_take_the_nccl_allgather_too(tmp_path, mock_rccl):
     out = str(tmp_path / "res")
     r = launch(4, [os.path.join(ROOT, "tests", "_dist_mock_worker.py"), out, "1000"], mock_rccl)
