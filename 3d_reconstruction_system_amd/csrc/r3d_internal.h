@@ -147,7 +147,7 @@ int r3d_radix_sort_u64(r3d_ctx* ctx, uint64_t* d_keys, uint64_t* d_tmp, int64_t 
                        uint64_t** d_result = nullptr, bool first_hist_done = false);
 constexpr int kSortTile = 4096;   // keys per workgroup of every sort kernel
 int r3d_radix_sort_workspace(r3d_ctx* ctx, int64_t n, uint32_t** hist_out, int* n_blocks_out);
-static inline int r3d_sort_stride(int n_blocks) { return (n_blocks + 3) & ~3; }   // counters per histogram row (16-byte aligned rows)
+static inline int r3d_sort_stride(int n_blocks) { return (n_blocks + 7) & ~7; }   // counters per histogram row (32-byte aligned rows)
 // hist[bin][tile] (256 rows of `stride` counters) -> exclusive prefixes over the tiles, in place; totals[bin] = the bin's count
 void r3d_sort_launch_scan(r3d_ctx* ctx, uint32_t* hist, int n_blocks, int stride, uint32_t* totals);
 

@@ -229,16 +229,12 @@ using r3d_vox::unhash48;
 
 // One workgroup per SORT TILE (4096 points): rem / hl for every point of the tile (live or not) and the tile's histogram of the
 // low piece byte, hist[bin][tile] (what the first pass would otherwise have to count from the elements again).
-__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor,
-                                                              uint32_t* __restrict__ rem, uint16_t* __restrict__ hl,
-                                                              uint32_t* __restrict__ hist, int hist_stride,
-                                                              uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                              unsigned long long spill_cap, unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t bins[256];
+template <bool FULL>   // FULL: the tile lies wholly inside the cloud (all tiles but the last): no bounds in the loop
+__device__ __forceinline__ unsigned keys_of_tile(const float* __restrict__ xyz, int64_t n, double factor, uint32_t* __restrict__ rem,
+                                                 uint16_t* __restrict__ hl, uint32_t* bins, uint64_t* __restrict__ spill,
+                                                 unsigned long long* __restrict__ spill_count, unsigned long long spill_cap) {
   const int lane = threadIdx.x & 63;
   unsigned n_ignored = 0;
-  bins[threadIdx.x] = 0;
-  __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortTile + threadIdx.x;
 #pragma unroll
   for (int q = 0; q < kSortTile / (kThreads * 4); ++q) {
@@ -246,35 +242,50 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = base + (int64_t)(q * 4 + r) * kThreads;
-      p[r] = reinterpret_cast<const P3*>(xyz)[i < n ? i : n - 1];
+      p[r] = reinterpret_cast<const P3*>(xyz)[FULL || i < n ? i : n - 1];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = base + (int64_t)(q * 4 + r) * kThreads;
+      const bool inside = FULL || i < n;
       uint64_t key = kEmpty;
-      bool live = i < n;
+      bool live = inside;
       if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
         ++n_ignored;
         live = false;
         key = kEmpty;
       }
       const uint64_t prev = prev_lane_u64(key);
-      if (live && lane > 0 && prev == key) live = false;
-      uint64_t h = kMask48;   // no key
-      if (live) {
-        h = hash48(key);
-        if (h == kMask48) {   // the one key whose h48 reads as "no key": it takes the deferred way in
-          const unsigned long long at = atomicAdd(spill_count, 1ull);   // (the list holds one entry per point: always room)
-          if (at < spill_cap) spill[at] = key;
-        }
+      if (lane > 0 && prev == key) live = false;
+      uint64_t h = live ? hash48(key) : kMask48;   // kMask48: no key
+      if (live && h == kMask48) {   // the one key whose h48 reads as "no key": it takes the deferred way in
+        const unsigned long long at = atomicAdd(spill_count, 1ull);   // (the list holds one entry per point: always room)
+        if (at < spill_cap) spill[at] = key;
       }
-      if (i < n) {
+      if (inside) {
         rem[i] = (uint32_t)h;
         hl[i] = (uint16_t)(h >> 32);
         atomicAdd(&bins[(uint32_t)(h >> 32) & 0xff], 1u);
       }
     }
   }
+  return n_ignored;
+}
+
+__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor,
+                                                              uint32_t* __restrict__ rem, uint16_t* __restrict__ hl,
+                                                              uint32_t* __restrict__ hist, int hist_stride,
+                                                              uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                              unsigned long long spill_cap, unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t bins[256];
+  const int lane = threadIdx.x & 63;
+  bins[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned n_ignored;
+  if ((int64_t)(blockIdx.x + 1) * kSortTile <= n)
+    n_ignored = keys_of_tile<true>(xyz, n, factor, rem, hl, bins, spill, spill_count, spill_cap);
+  else
+    n_ignored = keys_of_tile<false>(xyz, n, factor, rem, hl, bins, spill, spill_count, spill_cap);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
   if (lane == 0 && n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);   // (rare: non-finite / far points only)
@@ -283,19 +294,23 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
   hist[(int64_t)threadIdx.x * hist_stride + blockIdx.x] = bins[threadIdx.x];
 }
 
-// hist[bin][tile] of a byte array, 4096 bytes per tile.  A workgroup takes FOUR tiles, one per wave (12 000 one-tile workgroups
-// of a single 16-byte load per thread were bound by their own launch: 34 us for 49 MB): four 16-byte loads per lane in flight,
-// 64 LDS adds into the wave's own 256 bins.
+// hist[bin][tile] of a byte array, 4096 bytes per tile.  A workgroup takes EIGHT consecutive tiles, two per wave: bin b's eight
+// counters are then 32 consecutive, 32-byte-aligned bytes of row b -- one whole sector.  (One tile per workgroup: 12 000
+// workgroups bound by their own launch and 4-byte pieces; four tiles: 16-byte pieces, 73 MB written for 12 MB of counters
+// -- rocprofv3 WRITE_SIZE -- and 40 us.)  Four 16-byte loads per lane in flight, 64 LDS adds into the wave's own bins.
 __global__ __launch_bounds__(kThreads) void byte_histogram_kernel(const uint8_t* __restrict__ bytes, int64_t n, int n_tiles,
                                                                   uint32_t* __restrict__ hist, int stride) {
-  __shared__ uint32_t bins[4][256];
+  __shared__ uint32_t bins[8][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) bins[w][threadIdx.x] = 0;
+  for (int w = 0; w < 8; ++w) bins[w][threadIdx.x] = 0;
   __syncthreads();
-  const int tile = blockIdx.x * 4 + wave;
-  const int64_t t0 = (int64_t)tile * kSortTile;
-  if (tile < n_tiles) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int slot = wave * 2 + half;
+    const int tile = blockIdx.x * 8 + slot;
+    if (tile >= n_tiles) continue;
+    const int64_t t0 = (int64_t)tile * kSortTile;
     uint4 v[4];
     bool whole[4];
 #pragma unroll
@@ -310,22 +325,26 @@ __global__ __launch_bounds__(kThreads) void byte_histogram_kernel(const uint8_t*
         const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          atomicAdd(&bins[wave][w4[c] & 0xff], 1u);
-          atomicAdd(&bins[wave][(w4[c] >> 8) & 0xff], 1u);
-          atomicAdd(&bins[wave][(w4[c] >> 16) & 0xff], 1u);
-          atomicAdd(&bins[wave][w4[c] >> 24], 1u);
+          atomicAdd(&bins[slot][w4[c] & 0xff], 1u);
+          atomicAdd(&bins[slot][(w4[c] >> 8) & 0xff], 1u);
+          atomicAdd(&bins[slot][(w4[c] >> 16) & 0xff], 1u);
+          atomicAdd(&bins[slot][w4[c] >> 24], 1u);
         }
       } else {
         const int64_t at = t0 + (int64_t)(k * 64 + lane) * 16;
-        for (int c = 0; c < 16 && at + c < n; ++c) atomicAdd(&bins[wave][bytes[at + c]], 1u);
+        for (int c = 0; c < 16 && at + c < n; ++c) atomicAdd(&bins[slot][bytes[at + c]], 1u);
       }
     }
   }
   r3d_vox::lds_settle();
   __syncthreads();
-#pragma unroll
-  for (int w = 0; w < 4; ++w)
-    if (blockIdx.x * 4 + w < n_tiles) hist[(int64_t)threadIdx.x * stride + blockIdx.x * 4 + w] = bins[w][threadIdx.x];
+  uint32_t* row = hist + (int64_t)threadIdx.x * stride + blockIdx.x * 8;
+  if (blockIdx.x * 8 + 8 <= n_tiles) {   // (rows are 32-byte aligned: r3d_sort_stride)
+    reinterpret_cast<uint4*>(row)[0] = uint4{bins[0][threadIdx.x], bins[1][threadIdx.x], bins[2][threadIdx.x], bins[3][threadIdx.x]};
+    reinterpret_cast<uint4*>(row)[1] = uint4{bins[4][threadIdx.x], bins[5][threadIdx.x], bins[6][threadIdx.x], bins[7][threadIdx.x]};
+  } else {
+    for (int w = 0; w < 8 && blockIdx.x * 8 + w < n_tiles; ++w) row[w] = bins[w][threadIdx.x];
+  }
 }
 
 // One radix pass over the elements of the sort-merge insert.  PASS 1: digit = lo (of hl), carries rem + hi; any order inside a
@@ -1130,7 +1149,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     hipLaunchKernelGGL(piece_scatter_kernel<1>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
                        (const uint16_t*)hl_a, (const uint8_t*)nullptr, m, (const uint32_t*)hist_lo, stride, (const uint32_t*)totals_lo,
                        (const uint32_t*)nullptr, rem_b, hi_b, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(byte_histogram_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b, m, n_tiles,
+    hipLaunchKernelGGL(byte_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b, m, n_tiles,
                        hist_hi, stride);
     r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
     hipLaunchKernelGGL(piece_scatter_kernel<2>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
