@@ -11,6 +11,7 @@
 #include <functional>
 
 #include "r3d.h"
+#include "r3d_internal_api.h"
 
 struct r3d_ctx {
   int device = -1;

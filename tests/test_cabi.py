@@ -12,10 +12,15 @@ import pytest
 from helpers import PKG, ROOT
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "r3d.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(r3d_[a-z0-9_A-Z]+)\s*\(", text)))
+def header_symbols(names=("r3d.h", "r3d_internal_api.h")):
+    """Every function include/*.h declares: the drop-in boundary (r3d.h) and the ICP driver's building blocks
+    (r3d_internal_api.h)."""
+    out = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(r3d_[a-z0-9_A-Z]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_library_exports_every_header_symbol():
@@ -26,6 +31,12 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libr3d_hip.so does not export %s" % s
     assert sorted(L.SIGNATURES) == syms, set(L.SIGNATURES) ^ set(syms)
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["r3d.h", "r3d_internal_api.h"]
+    # the stable header stays small: what a drop-in host needs; selection / partial-sum / reordering helpers live in the other
+    stable, internal = header_symbols(("r3d.h",)), header_symbols(("r3d_internal_api.h",))
+    assert not set(stable) & set(internal) and len(internal) >= 15
+    for s in ("r3d_selftest_magic_div", "r3d_permutation_invert", "r3d_remap_u32", "r3d_gather_rows_strided", "r3d_select_quantile_f32"):
+        assert s in internal and s not in stable
     assert lib.r3d_version() == 200
 
 
