@@ -45,7 +45,9 @@ def rccl_debug_env(world):
     rank 0 parses after the survey (`comm.rccl_log`).  Must run before anything loads RCCL."""
     if world <= 1 and os.environ.get("R3D_BENCH_FORCE_COLLECTIVES", "0") in ("", "0"):
         return None
-    if "NCCL_DEBUG" in os.environ or os.environ.get("R3D_BENCH_NCCL_DEBUG", "1") in ("", "0"):
+    if os.environ.get("R3D_BENCH_NCCL_DEBUG", "1") in ("", "0"):
+        return None
+    if "NCCL_DEBUG_FILE" in os.environ:          # the caller routes RCCL's log already: leave it alone
         return None
     d = tempfile.mkdtemp(prefix="r3d_nccl_")
     os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,TUNING", NCCL_DEBUG_FILE=os.path.join(d, "rccl.%p.log"))
@@ -56,7 +58,7 @@ def parse_rccl_log(log_dir):
     """What RCCL said it chose: one entry per distinct (collective, bytes) TUNING line -- `AllGather: 49152000 Bytes -> Algo
     RING proto SIMPLE channel{Lo..Hi}={0..15}` -- and the INIT lines that describe the fabric (rings / trees / channels)."""
     if not log_dir:
-        return None
+        return {"picked": {}, "init_lines": [], "how": "not captured (R3D_BENCH_NCCL_DEBUG=0, or NCCL_DEBUG_FILE set by the caller)"}
     picks, init = {}, []
     for path in glob.glob(os.path.join(log_dir, "rccl.%d.log*" % os.getpid())) or glob.glob(os.path.join(log_dir, "rccl.*")):
         try:
