@@ -3,7 +3,7 @@
 # the headline kernel (HBM traffic), and stats of every kernel at BASELINE sizes.  Output: gpurun_out/prof_$1/...
 # Summaries are made afterwards with tools/summarise_profile.py and committed under profiles/.
 set -o pipefail
-R=${1:-r03}
+R=${1:-r05}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp

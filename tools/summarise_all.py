@@ -32,10 +32,12 @@ ALGO = {
                                                       "the atomics' worst case)", N_C2 * 13),
     "voxel_compact_kernel": ("hash table (2^27 slots, 1.07 GB) -> dense list of its ~48 M codes (read table + write codes)", (1 << 27) * 8 + 48_000_000 * 8),
     "cache_touch_kernel": ("input staging sweep of the C2 raster (read-only, 49 MB)", N_C2),
-    "voxel_keys_kernel": ("sort-merge insert, stage 1: 12 B/point in, 8 B region-tagged key out (+ the first digit's histogram)", N_C2 * 20),
-    "voxel_bounds_kernel": ("sort-merge insert, stage 3: where each table region's run of keys starts (8 B/key read)", N_C2 * 8),
-    "voxel_merge_kernel": ("sort-merge insert, stage 4: keys (8 B) into their table regions in LDS; 2^27-slot table written back "
-                           "(and read first unless nothing was inserted since clear)", N_C2 * 8 + (1 << 27) * 8),
+    "voxel_keys_kernel": ("sort-merge insert, stage 1: 12 B/point in; 4-byte remainder + 2 digit bytes out (+ the first pass's histogram)", N_C2 * 18),
+    "piece_scatter_kernel<1>": ("sort-merge insert, pass 1 (by the low piece byte): 6 B in, remainder + 1 byte out", N_C2 * 11),
+    "byte_histogram_kernel": ("sort-merge insert: histogram of the carried digit byte (1 B/point read)", N_C2 * 1),
+    "piece_scatter_kernel<2>": ("sort-merge insert, pass 2 (by the high piece byte): 5 B in, remainder out + the 65536 run starts", N_C2 * 9),
+    "voxel_merge_kernel": ("sort-merge insert, merge: remainders (4 B) into their table regions in LDS; 2^27-slot table written back "
+                           "(and read first unless nothing was inserted since clear)", N_C2 * 4 + (1 << 27) * 8),
     "digit_scatter_kernel": ("radix scatter pass, 49.2 M 64-bit words (8 B read + 8 B written per key); other sizes share the symbol: "
                              "see calls / min / max", N_C2 * 16),
     "digit_histogram_kernel": ("radix histogram pass, 49.2 M words (8 B read per key); other sizes share the symbol", N_C2 * 8),
