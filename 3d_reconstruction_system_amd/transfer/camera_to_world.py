@@ -231,10 +231,18 @@ def get_file_name(qt_path):
     n_frames = len(names)
     if not n_frames:
         return _get_file_name_host_text(qt_path, announce=False)     # a header-only PLY: nothing for the GPU to do
-    depths = r3d.cloud_io.read_depth_batch([os.path.join('./depth/', n) for n in names])
-    _common.stamp("pose file + %d depth files decoded" % n_frames)
-    ctx = _common.context()
-    _common.stamp("GPU context")
+    # the HIP context comes up (70 ms, no GIL held) on a helper thread while the library's host threads decode the rasters
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        ctx_job = pool.submit(_common.context)
+        try:
+            depths = r3d.cloud_io.read_depth_batch([os.path.join('./depth/', n) for n in names])
+        finally:
+            ctx_error = ctx_job.exception()
+        if ctx_error is not None:
+            raise ctx_error
+        ctx = ctx_job.result()
+    _common.stamp("pose file + %d depth files decoded, GPU context up" % n_frames)
     per = depths.shape[1] * depths.shape[2]
     n = n_frames * per
     cam = ctx.camera(depths.shape[1], depths.shape[2], *_common.intrinsics())

@@ -117,6 +117,18 @@ def test_headline_line_is_complete_and_self_consistent():
     assert drop["cpu_reference_s_per_frame"] == f2f["s_per_frame"]
 
 
+def test_cached_inputs_regime_is_still_a_flag_away():
+    """`--inputs cached` = rounds 1-4's headline regime (ONE raster re-read every step, served by the Infinity Cache): the
+    line says which regime it ran, no sweep is in its steps (the library's own counter), and the HBM-side fraction counts
+    the 12 B/point of xyz only."""
+    d = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--inputs", "cached", "--no-regimes", "--no-end-to-end", "--no-cpu-baseline"])
+    rf = d["roofline"]
+    assert d["config"]["inputs"] == "cached" and "SAME raster" in d["config"]["workload"]
+    assert [k["name"] for k in rf["kernels"]] == ["fuse_lane_kernel<u8,f32,pose>"] and rf["staging_sweeps_in_timed_region"] == 0
+    assert abs(rf["frac_hbm_side"] - rf["frac"] * 12 / 13) < 1e-3 and rf["frac_fresh_inputs"] is None and rf["other_regimes"] is None
+    assert rf["traffic"] is None            # the recorded PMC figure belongs to the fresh-input step
+
+
 def test_multi_rank_code_path_rehearsed_with_one_rccl_rank(real_rccl):
     d = run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], env={"R3D_BENCH_FORCE_COLLECTIVES": "1"})
     assert "r3d_comm over RCCL" in d["transport"], d["transport"]

@@ -63,6 +63,8 @@ def test_bench_two_gpus_as_the_driver_launches_it(n_gpus):
     assert d["n_gpus"] == 2 and "watchdog" not in d and "r3d_comm over RCCL" in d["transport"], d.get("transport")
     for m in ("none", "outputs", "inputs", "outputs_direct", "inputs_direct", "inputs_overlap"):
         assert "ms_per_step" in d["assemble"][m], (m, d["assemble"][m])
+        assert d["assemble"][m]["same_bits_as_single_launch"] is True, (m, d["assemble"][m])      # real RCCL, every strategy, bit for bit
+    assert d["comm"]["rccl"]["world"] == 2 and d["comm"]["rccl"]["version"] > 0 and "picked" in d["comm"]["rccl_log"]
     # (how the rates compare is for the reader of the line: no timing-vs-timing assertion stands in the gate)
     assert d["value_shards_resident"] == d["assemble"]["none"]["Mpoints_s"] > 0
     assert d["assemble"]["outputs_direct"]["xgmi_GBps_per_link"] > 0
