@@ -229,32 +229,48 @@ using r3d_vox::unhash48;
 
 // One workgroup per SORT TILE (4096 points): rem / hl for every point of the tile (live or not) and the tile's histogram of the
 // low piece byte, hist[bin][tile] (what the first pass would otherwise have to count from the elements again).
+// The kernel is bound by instruction issue, not by HBM (rocprofv3 SQ_WAIT_INST_ANY: 63 % of its wave-cycles wait for an issue
+// slot, profiles/r05_voxel_sq_counters.txt), so the common case is kept short: tile-relative 32-bit offsets, and three f32
+// compares that prove all three keys in range (|x|, |y|, |z| < safe_abs, a bound the host derives from the resolution;
+// a NaN fails them -- a max3 would drop it) before the exact fp64 floor -- only a point near the map's edge or a non-finite one takes voxel_key()'s six
+// fp64 comparisons.
 template <bool FULL>   // FULL: the tile lies wholly inside the cloud (all tiles but the last): no bounds in the loop
-__device__ __forceinline__ unsigned keys_of_tile(const float* __restrict__ xyz, int64_t n, double factor, uint32_t* __restrict__ rem,
-                                                 uint16_t* __restrict__ hl, uint32_t* bins, uint64_t* __restrict__ spill,
-                                                 unsigned long long* __restrict__ spill_count, unsigned long long spill_cap) {
+__device__ __forceinline__ unsigned keys_of_tile(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
+                                                 uint32_t* __restrict__ rem, uint16_t* __restrict__ hl, uint32_t* bins,
+                                                 uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                 unsigned long long spill_cap) {
   const int lane = threadIdx.x & 63;
   unsigned n_ignored = 0;
-  const int64_t base = (int64_t)blockIdx.x * kSortTile + threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * kSortTile;
+  const P3* __restrict__ tile_xyz = reinterpret_cast<const P3*>(xyz) + t0;
+  uint32_t* __restrict__ tile_rem = rem + t0;
+  uint16_t* __restrict__ tile_hl = hl + t0;
+  const uint32_t n_tile = FULL ? (uint32_t)kSortTile : (uint32_t)(n - t0);
 #pragma unroll
   for (int q = 0; q < kSortTile / (kThreads * 4); ++q) {
     P3 p[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + (int64_t)(q * 4 + r) * kThreads;
-      p[r] = reinterpret_cast<const P3*>(xyz)[FULL || i < n ? i : n - 1];
+      const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
+      p[r] = tile_xyz[FULL || e < n_tile ? e : n_tile - 1];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + (int64_t)(q * 4 + r) * kThreads;
-      const bool inside = FULL || i < n;
+      const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
+      const bool inside = FULL || e < n_tile;
       uint64_t key = kEmpty;
       bool live = inside;
-      if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
+      if (fabsf(p[r].x) < safe_abs && fabsf(p[r].y) < safe_abs && fabsf(p[r].z) < safe_abs) {   // in range for sure (a NaN fails: fmaxf would drop it): the same fp64 floors, no range test
+        const uint32_t ix = (uint32_t)((int)floor(factor * (double)p[r].x) + r3d_vox::kTreeMaxVal);
+        const uint32_t iy = (uint32_t)((int)floor(factor * (double)p[r].y) + r3d_vox::kTreeMaxVal);
+        const uint32_t iz = (uint32_t)((int)floor(factor * (double)p[r].z) + r3d_vox::kTreeMaxVal);
+        key = (uint64_t)(ix | (iy << 16)) | ((uint64_t)iz << 32);
+      } else if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
         ++n_ignored;
         live = false;
         key = kEmpty;
       }
+      if (!live) key = kEmpty;
       const uint64_t prev = prev_lane_u64(key);
       if (lane > 0 && prev == key) live = false;
       uint64_t h = live ? hash48(key) : kMask48;   // kMask48: no key
@@ -263,8 +279,8 @@ __device__ __forceinline__ unsigned keys_of_tile(const float* __restrict__ xyz, 
         if (at < spill_cap) spill[at] = key;
       }
       if (inside) {
-        rem[i] = (uint32_t)h;
-        hl[i] = (uint16_t)(h >> 32);
+        tile_rem[e] = (uint32_t)h;
+        tile_hl[e] = (uint16_t)(h >> 32);
         atomicAdd(&bins[(uint32_t)(h >> 32) & 0xff], 1u);
       }
     }
@@ -272,7 +288,7 @@ __device__ __forceinline__ unsigned keys_of_tile(const float* __restrict__ xyz, 
   return n_ignored;
 }
 
-__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor,
+__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
                                                               uint32_t* __restrict__ rem, uint16_t* __restrict__ hl,
                                                               uint32_t* __restrict__ hist, int hist_stride,
                                                               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
@@ -283,9 +299,9 @@ __global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __res
   __syncthreads();
   unsigned n_ignored;
   if ((int64_t)(blockIdx.x + 1) * kSortTile <= n)
-    n_ignored = keys_of_tile<true>(xyz, n, factor, rem, hl, bins, spill, spill_count, spill_cap);
+    n_ignored = keys_of_tile<true>(xyz, n, factor, safe_abs, rem, hl, bins, spill, spill_count, spill_cap);
   else
-    n_ignored = keys_of_tile<false>(xyz, n, factor, rem, hl, bins, spill, spill_count, spill_cap);
+    n_ignored = keys_of_tile<false>(xyz, n, factor, safe_abs, rem, hl, bins, spill, spill_count, spill_cap);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
   if (lane == 0 && n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);   // (rare: non-finite / far points only)
@@ -1143,7 +1159,10 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     uint32_t* totals_hi = totals_lo + 256;
     uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
     R3D_HIP(hipMemsetAsync(d_spill_count, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, rem_a, hl_a, hist_lo,
+    // |x| < safe_abs  =>  |factor x| < 32767: every key in range whatever the rounding of the fp64 product (a bound strictly
+    // inside the map's edge 32768 / factor, rounded towards zero and shrunk by 2^-20 on top)
+    const float safe_abs = nextafterf((float)((32767.0 / vs->factor) * (1.0 - 1.0 / 1048576.0)), 0.0f);
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, rem_a, hl_a, hist_lo,
                        stride, d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
     r3d_sort_launch_scan(ctx, hist_lo, n_tiles, stride, totals_lo);
     hipLaunchKernelGGL(piece_scatter_kernel<1>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
