@@ -69,7 +69,8 @@ SIGNATURES = {
     "r3d_backproject_depth_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "r3d_parse_xyz_text": (_i, [_vp, _sz, _i, _vp, _i64, _vp, _vp]),
     "r3d_format_text_device": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i, _i64, _vp, _sz, _vp, _vp]),
-    "r3d_write_device_text_files": (_i, [_vp, _vp, _vp, _i]),
+    "r3d_write_device_text_files": (_i, [_vp, _vp, _i]),
+    "r3d_write_ply_binary": (_i, [C.c_char_p, _vp, _i, _i64]),
     "r3d_project3d_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "r3d_project3d_grad_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "r3d_se3_apply": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i]),

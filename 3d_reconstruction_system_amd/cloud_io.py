@@ -367,6 +367,13 @@ def write_ply(path, xyz):
     L.check(L.load().r3d_write_ply(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0]))
 
 
+def write_ply_binary(path, xyz):
+    """f1's optional binary flag: the vertices as a standard binary_little_endian PLY (float32 x, y, z; 12 B/vertex).  NOT the
+    reference's file -- an opt-in for users whose next tool reads PLY (the drop-in takes it under R3D_PLY_BINARY=1)."""
+    xyz = _cloud(xyz)
+    L.check(L.load().r3d_write_ply_binary(os.fsencode(path), xyz.ctypes.data, xyz_code(xyz.dtype), xyz.shape[0]))
+
+
 def write_ply_rgb(path, xyz, rgb):
     """Coloured PLY in the reference layout (p2c:55-91).  rgb: [N,3] uint8 (R,G,B), or the [N] uint32 rgba words of
     fuse_frames_rgb (bytes R,G,B,0); the alpha column is the literal 0 either way."""
@@ -435,7 +442,7 @@ def read_xyz_txt(path):
 
 def read_ply(path):
     """Vertices of an ASCII PLY in the reference layout -> [N,3] float64 (the first three blank-separated numbers of each
-    of the `element vertex` rows; colour columns are ignored)."""
+    of the `element vertex` rows; colour columns are ignored); also reads write_ply_binary's files."""
     with open(path, 'rb') as f:
         data = bytearray(f.read())
     n, start, pos = None, None, 0
@@ -451,6 +458,8 @@ def read_ply(path):
             break
     if n is None or start is None:
         raise ValueError("%s: not a PLY with an 'element vertex' header" % path)
+    if b'format binary_little_endian' in bytes(data[:start]):       # write_ply_binary's layout: float32 x, y, z per vertex
+        return np.frombuffer(bytes(data[start:start + n * 12]), dtype='<f4').reshape(-1, 3).astype(np.float64)
     got = _parse_rows_native(data, min(start, len(data)), ' ') if start < len(data) else np.empty((0, 3))
     if got is not None and got.shape[0] == n:
         return got                                   # the whole body is the vertex list (the reference's layout)

@@ -572,28 +572,28 @@ int r3d_format_text_device(r3d_ctx* ctx, int kind, const void* d_xyz, int dtype,
 // stream of its own -- piece k+1 crosses PCIe while piece k goes into the file with write().  One file is ONE sequential
 // write stream (tmpfs takes 6.2 GB/s from one stream and less from several on the same inode), different files run side by
 // side: the fused PLY beside the per-frame camera txts.
-int r3d_write_device_text_files(r3d_ctx* ctx, const char* d_text, const r3d_text_file* files, int n_files) {
+int r3d_write_device_text_files(r3d_ctx* ctx, const r3d_text_file* files, int n_files) {
   int rc = r3d_ctx_enter(ctx);
   if (rc) return rc;
   R3D_REQUIRE(n_files >= 0 && (n_files == 0 || files != nullptr), "bad file list");
   if (n_files == 0) return R3D_OK;
   for (int k = 0; k < n_files; ++k) {
     R3D_REQUIRE(files[k].path != nullptr, "path %d is NULL", k);
-    R3D_REQUIRE(files[k].text_bytes == 0 || d_text != nullptr, "device text is NULL");
+    R3D_REQUIRE(files[k].n_bytes == 0 || files[k].d_bytes != nullptr, "device bytes of file %d are NULL", k);
     R3D_REQUIRE((files[k].head_bytes == 0 || files[k].head) && (files[k].tail_bytes == 0 || files[k].tail), "head / tail of file %d is NULL", k);
   }
   R3D_HIP(hipStreamSynchronize(ctx->stream));   // the text is complete
   std::vector<int> order((size_t)n_files);
   for (int k = 0; k < n_files; ++k) order[k] = k;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return files[a].text_bytes > files[b].text_bytes; });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return files[a].n_bytes > files[b].n_bytes; });
   // How many writers: the largest file is one stream (~6 GB/s into tmpfs, measured on the MI355X box's host; several streams on
   // ONE inode are slower, an mmap half as fast: tools/tmpfs_write_probe.cpp) and sets the finishing time; the other files need
   // about (rest / largest) streams to be done by then, plus one to spare.  More than that only competes with the critical
   // stream for the process's CPU quota: C2's 3.29 GB took 298 / 269 / 242 / 227 ms with 32 / 16 / 8 / 4 writers.
   size_t all_bytes = 0;
-  for (int k = 0; k < n_files; ++k) all_bytes += files[k].text_bytes;
-  const size_t big_bytes = std::max<size_t>(files[order[0]].text_bytes, 1);
-  const unsigned want_workers = (unsigned)std::min<size_t>(2 + (all_bytes - files[order[0]].text_bytes + big_bytes - 1) / big_bytes,
+  for (int k = 0; k < n_files; ++k) all_bytes += files[k].n_bytes;
+  const size_t big_bytes = std::max<size_t>(files[order[0]].n_bytes, 1);
+  const unsigned want_workers = (unsigned)std::min<size_t>(2 + (all_bytes - files[order[0]].n_bytes + big_bytes - 1) / big_bytes,
                                                             std::max(1u, r3d_host::cpu_budget() / 2));
   const unsigned n_workers = std::max(1u, std::min<unsigned>(want_workers, (unsigned)n_files));
   constexpr size_t kPiece = (size_t)1 << 20;
@@ -638,17 +638,18 @@ int r3d_write_device_text_files(r3d_ctx* ctx, const char* d_text, const r3d_text
           return true;
         };
         bool ok = put(f.head, f.head_bytes);
-        const size_t n_pieces = (f.text_bytes + kPiece - 1) / kPiece;
+        const size_t n_pieces = (f.n_bytes + kPiece - 1) / kPiece;
+        const char* d_src = static_cast<const char*>(f.d_bytes);
         auto fetch = [&](size_t c) {
-          const size_t lo = c * kPiece, n = std::min(kPiece, f.text_bytes - lo);
-          return hipMemcpyAsync(buf[c & 1], d_text + f.text_offset + lo, n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+          const size_t lo = c * kPiece, n = std::min(kPiece, f.n_bytes - lo);
+          return hipMemcpyAsync(buf[c & 1], d_src + lo, n, hipMemcpyDeviceToHost, st) == hipSuccess &&
                  hipEventRecord(ev[c & 1], st) == hipSuccess;
         };
         bool hip_ok = n_pieces == 0 || fetch(0);
         for (size_t c = 0; ok && hip_ok && c < n_pieces; ++c) {
           if (c + 1 < n_pieces) hip_ok = fetch(c + 1);
           hip_ok = hip_ok && hipEventSynchronize(ev[c & 1]) == hipSuccess;
-          if (hip_ok) ok = put(buf[c & 1], std::min(kPiece, f.text_bytes - c * kPiece));
+          if (hip_ok) ok = put(buf[c & 1], std::min(kPiece, f.n_bytes - c * kPiece));
         }
         (void)hipStreamSynchronize(st);   // nothing of this file is in flight into the buffers any more
         ok = ok && hip_ok && put(f.tail, f.tail_bytes);

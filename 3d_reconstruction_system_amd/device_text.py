@@ -22,8 +22,14 @@ TEXT_XYZ_TXT, TEXT_PLY_ROWS, TEXT_PLY_ROWS_RGB = 0, 1, 2
 
 
 class _TextFile(C.Structure):
-    _fields_ = [("path", C.c_char_p), ("head", C.c_char_p), ("head_bytes", C.c_size_t), ("text_offset", C.c_size_t),
-                ("text_bytes", C.c_size_t), ("tail", C.c_char_p), ("tail_bytes", C.c_size_t)]
+    _fields_ = [("path", C.c_char_p), ("head", C.c_char_p), ("head_bytes", C.c_size_t), ("d_bytes", C.c_void_p),
+                ("n_bytes", C.c_size_t), ("tail", C.c_char_p), ("tail_bytes", C.c_size_t)]
+
+
+def ply_header_binary(n_points):
+    """Header of cloud_io.write_ply_binary's file (a standard PLY header: no indents)."""
+    return ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+            "end_header\n" % n_points).encode()
 
 
 def ply_header(n_points, colour=False):
@@ -54,6 +60,7 @@ class TextWriter:
     def __init__(self, ctx):
         self.ctx = ctx
         self._jobs = []       # (kind, d_xyz, dtype, n, d_aux, aux_code, segment_points, n_bytes, offsets, files)
+        self._raw = []        # (path, head, device pointer, bytes, tail): device bytes that go into a file as they are
         self._host_jobs = []  # callables: what the device formatter refused
 
     def _add(self, kind, d_xyz, dtype, n, d_aux, aux_code, seg, files_of):
@@ -75,6 +82,10 @@ class TextWriter:
         if n_points == 0 or not self._add(kind, d_xyz, dtype, n_points, d_rgb, rgb_stride if d_rgb is not None else 0, 0,
                                           lambda offs: [(path, head, 0, int(offs[-1]), PLY_TRAILER)]):
             self._host_jobs.append(lambda: self._host_ply(path, d_xyz, dtype, n_points, d_rgb, rgb_stride))
+
+    def add_ply_binary(self, path, d_xyz_f32, n_points):
+        """cloud_io.write_ply_binary's file from a device-resident FLOAT32 cloud: header + the cloud's own bytes."""
+        self._raw.append((os.fspath(path), ply_header_binary(n_points), d_xyz_f32 if n_points else None, n_points * 12, b""))
 
     def add_xyz_txt(self, paths, d_xyz, dtype, n_points, d_z_raw=None, z_dtype=None):
         """`X,Y,Z\\n` files with repr() floats: file k takes rows [k*P, (k+1)*P), P = n_points / len(paths) -- the
@@ -114,6 +125,7 @@ class TextWriter:
         ctx = self.ctx
         from .transfer import _common
         total = sum(j[7] for j in self._jobs)
+        raw_total = sum(r[3] for r in self._raw)
         files, keep = [], []
         buf = ctx.alloc(max(total, 16)) if self._jobs else None
         try:
@@ -125,17 +137,20 @@ class TextWriter:
                     raise RuntimeError("device text changed size between the two passes (%d -> %d bytes)" % (n_bytes, got))
                 for path, head, off, nb, tail in jf:
                     keep += [os.fsencode(path), head, tail]
-                    files.append(_TextFile(keep[-3], head or None, len(head), at + off, nb, tail or None, len(tail)))
+                    files.append(_TextFile(keep[-3], head or None, len(head), buf.ptr + at + off, nb, tail or None, len(tail)))
                 at += n_bytes
+            for path, head, ptr, nb, tail in self._raw:
+                keep += [os.fsencode(path), head, tail]
+                files.append(_TextFile(keep[-3], head or None, len(head), ptr, nb, tail or None, len(tail)))
             ctx.sync()
             _common.stamp("text formatted (pass A + scan + pass B per cloud)")
             if files:
                 arr = (_TextFile * len(files))(*files)
-                L.check(ctx.lib.r3d_write_device_text_files(ctx.handle, buf.ptr, arr, len(files)))
+                L.check(ctx.lib.r3d_write_device_text_files(ctx.handle, arr, len(files)))
             for job in self._host_jobs:
                 job()
         finally:
             if buf is not None:
                 buf.free()
-            self._jobs, self._host_jobs = [], []
-        return total
+            self._jobs, self._raw, self._host_jobs = [], [], []
+        return total + raw_total

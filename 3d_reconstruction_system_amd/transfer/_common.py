@@ -12,6 +12,8 @@ Environment (all optional; the defaults are the reference's hard-coded values):
   WORLD_SIZE RANK LOCAL_RANK    set by a one-process-per-GPU launcher (torch.distributed.run ...): frames are sharded
   R3D_HOST_TEXT=1               camera_to_world.py: format the txt / PLY text on the host (csrc/r3d_format.cpp) instead of on the GPU
                                 (csrc/r3d_textfmt.hip); same bytes, for A/B timing
+  R3D_PLY_BINARY=1              camera_to_world.py: write ./ply/small_035_p8.ply as a standard binary PLY (float32 x, y, z) instead of the
+                                reference's ASCII layout -- f1's optional flag; 12 B/vertex instead of ~26
   R3D_TIMING=1                  stage times on stderr (stamp() below)
 """
 import importlib
@@ -73,6 +75,10 @@ def pose_scale():
     except ValueError:
         with open(v) as f:
             return float(f.read().split()[0])
+
+
+def ply_binary():
+    return os.environ.get("R3D_PLY_BINARY", "0") not in ("", "0")
 
 
 def skip_intermediate():

@@ -253,7 +253,13 @@ def get_file_name(qt_path):
         bufs += [d_depth, d_pose, d_world]
         r3d.fuse_frames_device(ctx, cam, d_depth.ptr, depths.dtype, n_frames, d_pose.ptr, d_world.ptr, np.float64)
         text = r3d.device_text.TextWriter(ctx)
-        text.add_ply('./ply/small_035_p8.ply', d_world.ptr, np.float64, n)     # the same bytes genply(world, ...) writes
+        if _common.ply_binary():      # f1's optional flag (R3D_PLY_BINARY=1): a standard binary PLY of the f32 cloud, NOT the reference's text
+            d_world32 = ctx.alloc(n * 12)
+            bufs.append(d_world32)
+            r3d.fuse_frames_device(ctx, cam, d_depth.ptr, depths.dtype, n_frames, d_pose.ptr, d_world32.ptr, np.float32)
+            text.add_ply_binary('./ply/small_035_p8.ply', d_world32.ptr, n)
+        else:
+            text.add_ply('./ply/small_035_p8.ply', d_world.ptr, np.float64, n)     # the same bytes genply(world, ...) writes
         if not _common.skip_intermediate():
             d_cam = ctx.alloc(n * 24)
             bufs.append(d_cam)

@@ -316,6 +316,9 @@ int r3d_format_ply(const void* h_xyz, int dtype, int64_t n_points, char* h_buf, 
                    size_t* n_bytes_out);
 /* Same bytes straight to a file (formatted and written in slabs; replaces the open/write of c2w:122-132). */
 int r3d_write_ply(const char* path, const void* h_xyz, int dtype, int64_t n_points);
+/* f1's optional binary flag: the same vertices as a STANDARD binary_little_endian PLY (float x, y, z; the header without the
+ * reference template's indents).  12 bytes per vertex; not the reference's bytes -- an opt-in. */
+int r3d_write_ply_binary(const char* path, const void* h_xyz, int dtype, int64_t n_points);
 /* f4: the coloured layout of genply_noRGB() (pixel_to_camera.py:55-91): uchar red/green/blue/alpha header lines and
  * "%.4f %.4f %.4f R G B 0\n" rows; h_rgb is [n][3] uint8 in R,G,B order, point k takes colour k. */
 int r3d_write_ply_rgb(const char* path, const void* h_xyz, int dtype, const unsigned char* h_rgb, int64_t n_points);
@@ -360,18 +363,20 @@ int r3d_parse_xyz_text(const char* h_text, size_t n_bytes, int separator, double
 int r3d_format_text_device(r3d_ctx* ctx, int kind, const void* d_xyz, int dtype, int64_t n_points, const void* d_aux, int aux_dtype,
                            int64_t segment_points, char* d_text, size_t text_cap, int64_t* h_segment_offsets_out,
                            int64_t* n_bytes_out);
-/* Device text -> files: file k = head (host bytes), then text_bytes of d_text from text_offset, then tail (host bytes).
+/* Device bytes -> files: file k = head (host bytes), then d_bytes[0 .. n_bytes) (device memory: text made by
+ * r3d_format_text_device, or any other bytes -- the f32 cloud itself for a binary PLY), then tail (host bytes).
  * Host threads take the files largest first, each through its own pinned 1 MiB pieces and stream (PCIe and write() overlap);
  * one file is one sequential write stream, different files are written side by side.  Waits for the ctx's stream first. */
 typedef struct r3d_text_file {
   const char* path;
   const char* head;
   size_t head_bytes;
-  size_t text_offset, text_bytes;
+  const void* d_bytes;
+  size_t n_bytes;
   const char* tail;
   size_t tail_bytes;
 } r3d_text_file;
-int r3d_write_device_text_files(r3d_ctx* ctx, const char* d_text, const r3d_text_file* files, int n_files);
+int r3d_write_device_text_files(r3d_ctx* ctx, const r3d_text_file* files, int n_files);
 
 /* ---- f3 ingestion: the depth rasters of camera_to_world.py:160 (`cv.imread(path, IMREAD_GRAYSCALE)`) decoded by host
  * threads.  Native path: non-interlaced greyscale PNG, 8 bits (-> uint8, same bytes as OpenCV) or 16 bits (-> uint16);

@@ -77,6 +77,15 @@ def test_camera_to_world_device_text_equals_host_text(tmp_path):
         for rel in ["ply/small_035_p8.ply", "point_world/small_worldpoint_5_23_5.txt"] + ["point/%03d.txt" % k for k in range(F)]:
             assert (a / rel).read_bytes() == (b / rel).read_bytes(), (bits, rel)
         assert os.path.getsize(a / "ply" / "small_035_p8.ply") > F * H * W * 20
+    # f1's optional binary flag: the same cloud as float32, in a standard binary PLY; every other file as before
+    a = tmp_path / "a8"
+    text_ply = O.read_ply_vertices(str(a / "ply" / "small_035_p8.ply"))
+    run_script("transfer/camera_to_world.py", str(a), env={"R3D_PLY_BINARY": "1"})
+    R = _r3d()
+    got = R.cloud_io.read_ply(str(a / "ply" / "small_035_p8.ply"))
+    assert got.shape == (F * H * W, 3) and os.path.getsize(a / "ply" / "small_035_p8.ply") == len(R.device_text.ply_header_binary(F * H * W)) + 12 * F * H * W
+    assert np.abs(got - text_ply).max() <= 0.5001e-4 + 1e-6 * np.abs(got).max()          # the text holds 4 decimals, the floats ~7 digits
+    assert (a / "point" / "000.txt").read_bytes() == (tmp_path / "b8" / "point" / "000.txt").read_bytes()
 
 
 def test_camera_to_world_functions_keep_reference_semantics(tmp_path, golden_dir, monkeypatch):

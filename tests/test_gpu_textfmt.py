@@ -235,7 +235,15 @@ def test_writer_many_files_and_errors(R, ctx, tmp_path):
     w.add_xyz_txt(paths, d_xyz.ptr, np.float64, per * F, d_z_raw=d_z.ptr, z_dtype=np.uint16)
     w.add_ply(tmp_path / "all.ply", d_xyz.ptr, np.float64, per * F)
     w.add_ply(tmp_path / "empty.ply", None, np.float64, 0)
+    xyz32 = xyz.astype(np.float32)
+    d_32 = ctx.alloc(xyz32.nbytes).upload(xyz32)
+    w.add_ply_binary(tmp_path / "bin.ply", d_32.ptr, per * F)           # f1's optional flag: the cloud's own bytes behind a header
+    w.add_ply_binary(tmp_path / "bin0.ply", None, 0)
     w.write()
+    R.cloud_io.write_ply_binary(str(tmp_path / "bin_host.ply"), xyz32)
+    assert (tmp_path / "bin.ply").read_bytes() == (tmp_path / "bin_host.ply").read_bytes()
+    assert (tmp_path / "bin0.ply").read_bytes() == R.device_text.ply_header_binary(0)
+    d_32.free()
     for k in (0, 1, 57, 99):
         assert paths[k].read_bytes() == R.cloud_io.format_xyz_txt(xyz[k * per:(k + 1) * per], z_raw=z[k * per:(k + 1) * per])
     assert (tmp_path / "all.ply").read_bytes() == R.cloud_io.format_ply(xyz)

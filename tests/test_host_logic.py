@@ -1013,3 +1013,47 @@ def test_file_writers_across_slab_boundaries(R, tmp_path):
         blk = b"".join(plain[i] + b" %d %d %d 0\n" % (rgb[i, 0], rgb[i, 1], rgb[i, 2]) for i in range(i0, min(k, i0 + 500_000)))
         want.update(blk)
     assert hashlib.sha256(lines[:-5]).hexdigest() == want.hexdigest()
+
+
+def test_device_text_header_and_bench_modules_on_the_cpu(R):
+    """What the GPU text path shares with the host: the PLY header / trailer device_text puts around the GPU's rows are the
+    host formatter's own bytes (genply's template, c2w:122-132; genply_noRGB's, p2c:62-75); and bench.py's workload modules
+    (tools/bench_*.py) import without a GPU -- the driver's line must not die on an import."""
+    import subprocess
+    import sys
+    T = R.device_text
+    xyz = np.array([[1.0, 2.0, 3.0], [-4.5, 0.25, 1e-5]])
+    whole = R.cloud_io.format_ply(xyz)
+    head = T.ply_header(2)
+    assert whole.startswith(head) and whole.endswith(T.PLY_TRAILER)
+    assert whole[len(head):-len(T.PLY_TRAILER)] == b"1.0000 2.0000 3.0000 \n-4.5000 0.2500 0.0000 \n"
+    assert T.ply_header(0) == R.cloud_io.format_ply(np.zeros((0, 3)))[:-len(T.PLY_TRAILER)]
+    colour = T.ply_header(7, colour=True).decode()
+    assert "element vertex 7\n" in colour and colour.count("property uchar") == 4 and colour.endswith("end_header\n    ")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "import bench_common, bench_regimes, bench_e2e, bench_secondary, bench_assemble; "
+            "assert bench_assemble.step_text('inputs_overlap').endswith('fused]'); print('ok')"
+            % (ROOT, os.path.join(ROOT, "tools")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--inputs" in r.stdout
+
+
+def test_binary_ply_flag_round_trips(R, tmp_path):
+    """f1's optional binary flag: a standard binary_little_endian PLY of float32 x, y, z -- readable by
+    read_ply, header without the reference template's indents, 12 bytes per vertex, f64 clouds rounded once."""
+    xyz = np.random.default_rng(0).normal(0, 50, (70_001, 3))
+    xyz[5] = (np.inf, -0.0, 1e-40)
+    for dt in (np.float64, np.float32):
+        R.cloud_io.write_ply_binary(str(tmp_path / "b.ply"), xyz.astype(dt))
+        raw = (tmp_path / "b.ply").read_bytes()
+        head = R.device_text.ply_header_binary(len(xyz))
+        assert raw.startswith(head) and len(raw) == len(head) + 12 * len(xyz)
+        assert head == b"ply\nformat binary_little_endian 1.0\nelement vertex 70001\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+        assert raw[len(head):] == xyz.astype(np.float32).astype("<f4").tobytes()
+        np.testing.assert_array_equal(R.cloud_io.read_ply(str(tmp_path / "b.ply")).astype(np.float32), xyz.astype(np.float32))
+    R.cloud_io.write_ply_binary(str(tmp_path / "e.ply"), np.zeros((0, 3)))
+    assert R.cloud_io.read_ply(str(tmp_path / "e.ply")).shape == (0, 3)
+    with pytest.raises(R.R3DError):
+        R.cloud_io.write_ply_binary(str(tmp_path / "no_such_dir" / "x.ply"), xyz)
