@@ -677,6 +677,176 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
   if (threadIdx.x < 2) partials[2 * (uint64_t)blockIdx.x + threadIdx.x] = wg_count[threadIdx.x];
 }
 
+// The merge with 32-BIT slots in LDS, for tables whose regions ARE pieces (2^27 slots and more): inside a region every key
+// shares the top 16 bits of h48, so a slot only needs the 32-bit remainder -- half the LDS traffic of the 64-bit form, 32-bit
+// compare-and-swaps (the 64-bit returning ones are what this kernel spends its LDS time on), and the home slot is simply the
+// remainder's top bits.  0xffffffff marks a free slot, 0xfffffffe (a table that is not fresh only) a slot that holds a key of
+// ANOTHER piece -- put there by the CAS path's probing across a region's end -- which must stay as it is; the two keys per piece
+// whose remainders are those values take the deferred way in.
+template <int REGION_LOG2, bool PRISTINE>
+__global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
+                                                                 uint32_t n_regions, uint64_t* __restrict__ table,
+                                                                 uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                                 unsigned long long spill_cap, unsigned long long* __restrict__ partials) {
+  constexpr int kSlots = 1 << REGION_LOG2;
+  constexpr int kAhead = 4;
+  constexpr int kBatch = 128;
+  constexpr int kPairs = kSlots / 2 / kThreads;   // slot pairs per thread
+  constexpr uint32_t kFree = 0xffffffffu, kForeign = 0xfffffffeu;
+  __shared__ unsigned wg_count[2];
+  if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;
+  __shared__ __attribute__((aligned(16))) uint32_t region[kSlots];
+  __shared__ uint32_t s_lo[kBatch + 1], s_hi[kBatch + 1];
+  __shared__ unsigned changed;
+  const int lane = threadIdx.x & 63;
+  unsigned n_new = 0, n_over = 0;
+  bool mine_changed = false;
+  auto defer = [&](uint64_t key) {
+    const unsigned long long at = atomicAdd(spill_count, 1ull);
+    if (at < spill_cap) spill[at] = key; else ++n_over;
+  };
+  auto probe_on = [&](uint32_t piece, uint32_t rem, uint32_t s, uint32_t old) {
+    for (;;) {
+      if (old == kFree) {
+        ++n_new;
+        mine_changed = true;
+        return;
+      }
+      if (old == rem) return;
+      if (++s >= (uint32_t)kSlots) break;
+      old = atomicCAS(&region[s], kFree, rem);
+    }
+    defer(unhash48(((uint64_t)piece << 32) | rem));   // every slot from home to the region's end is taken: the probe goes on later
+  };
+  auto fetch = [&](uint32_t lo_, uint32_t hi_, uint32_t (&dst)[kAhead]) {
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      const uint32_t i = lo_ + (uint32_t)k * kThreads + threadIdx.x;
+      dst[k] = i < hi_ ? rems[i] : kFree;
+    }
+  };
+  auto load_bounds = [&](uint32_t it0) {
+    if (threadIdx.x <= (unsigned)kBatch) {
+      const uint64_t rr = (uint64_t)blockIdx.x + (uint64_t)(it0 + threadIdx.x) * gridDim.x;
+      uint32_t a = 0, b = 0;
+      if (rr < n_regions) {
+        a = starts[(uint32_t)rr];
+        b = starts[(uint32_t)rr + 1];
+      }
+      s_lo[threadIdx.x] = a;
+      s_hi[threadIdx.x] = b;
+    }
+  };
+  // an element: free marker on piece 65535 = no key; the two reserved remainders go the deferred way; else slot + first attempt
+  auto usable = [&](uint32_t r, uint32_t rem) -> bool {
+    if (rem < kForeign) return true;
+    if (!(r == kPieces - 1 && rem == kFree)) defer(unhash48(((uint64_t)r << 32) | rem));
+    return false;
+  };
+  uint32_t it = 0, r = blockIdx.x;
+  load_bounds(0);
+  __syncthreads();
+  uint32_t lo = s_lo[0], hi = s_hi[0];
+  uint32_t cur[kAhead];
+  fetch(lo, hi, cur);
+  while (r < n_regions) {   // workgroup-uniform trip count
+    const uint32_t j = it % kBatch;
+    const uint32_t rn = r + gridDim.x;
+    const uint32_t lon = s_lo[j + 1], hin = s_hi[j + 1];
+    uint32_t nxt[kAhead];
+    if (lo != hi) {
+      ulonglong2* g = reinterpret_cast<ulonglong2*>(table + ((uint64_t)r << REGION_LOG2));
+      ulonglong2 orig[PRISTINE ? 1 : kPairs];
+      r3d_vox::lds_barrier();
+      if (threadIdx.x == 0) changed = 0;
+      if (PRISTINE) {
+#pragma unroll
+        for (int k = 0; k < kSlots / 4 / kThreads; ++k) reinterpret_cast<uint4*>(region)[k * kThreads + threadIdx.x] = uint4{kFree, kFree, kFree, kFree};
+      } else {
+#pragma unroll
+        for (int k = 0; k < kPairs; ++k) orig[k] = g[k * kThreads + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kPairs; ++k) {
+          uint32_t v[2];
+          const uint64_t key[2] = {orig[k].x, orig[k].y};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint64_t h = hash48(key[q]);
+            v[q] = key[q] == kEmpty ? kFree : (((uint32_t)(h >> 32) == r && (uint32_t)h < kForeign) ? (uint32_t)h : kForeign);
+          }
+          reinterpret_cast<uint2*>(region)[k * kThreads + threadIdx.x] = uint2{v[0], v[1]};
+        }
+      }
+      r3d_vox::lds_barrier();
+      fetch(lon, hin, nxt);
+      mine_changed = false;
+      {
+        uint32_t slot[kAhead], old[kAhead];
+        bool has[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+          const uint32_t i = lo + (uint32_t)k * kThreads + threadIdx.x;
+          has[k] = i < hi && usable(r, cur[k]);
+          slot[k] = cur[k] >> (32 - REGION_LOG2);
+        }
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) old[k] = has[k] ? atomicCAS(&region[slot[k]], kFree, cur[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k)
+          if (has[k]) probe_on(r, cur[k], slot[k], old[k]);
+      }
+      for (uint32_t i = lo + kAhead * kThreads + threadIdx.x; i < hi; i += kThreads) {   // a longer run than usual
+        const uint32_t rem = rems[i];
+        if (usable(r, rem)) {
+          const uint32_t s = rem >> (32 - REGION_LOG2);
+          probe_on(r, rem, s, atomicCAS(&region[s], kFree, rem));
+        }
+      }
+      if (mine_changed) changed = 1;
+      r3d_vox::lds_barrier();
+      if (changed) {
+#pragma unroll
+        for (int k = 0; k < kPairs; ++k) {
+          const uint2 v = reinterpret_cast<const uint2*>(region)[k * kThreads + threadIdx.x];
+          ulonglong2 out;
+          out.x = v.x == kFree ? kEmpty : unhash48(((uint64_t)r << 32) | v.x);
+          out.y = v.y == kFree ? kEmpty : unhash48(((uint64_t)r << 32) | v.y);
+          if (!PRISTINE) {
+            if (v.x == kForeign) out.x = orig[k].x;
+            if (v.y == kForeign) out.y = orig[k].y;
+          }
+          g[k * kThreads + threadIdx.x] = out;
+        }
+      }
+    } else {
+      fetch(lon, hin, nxt);
+    }
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) cur[k] = nxt[k];
+    r = rn;
+    lo = lon;
+    hi = hin;
+    ++it;
+    if (it % kBatch == 0) {
+      __syncthreads();
+      load_bounds(it);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  r3d_vox::lds_barrier();
+  if (lane == 0) {
+    if (n_new) atomicAdd(&wg_count[0], n_new);
+    if (n_over) atomicAdd(&wg_count[1], n_over);
+  }
+  r3d_vox::lds_barrier();
+  if (threadIdx.x < 2) partials[2 * (uint64_t)blockIdx.x + threadIdx.x] = wg_count[threadIdx.x];
+}
+
 // the deferred keys, by the ordinary CAS (their count is known on the device only: fixed grid, device-side bound)
 __global__ __launch_bounds__(kThreads) void voxel_spill_kernel(const uint64_t* __restrict__ spill, const unsigned long long* __restrict__ spill_count,
                                                                unsigned long long spill_cap, uint64_t* __restrict__ table, int log2cap,
@@ -1181,11 +1351,19 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
   hipLaunchKernelGGL((voxel_merge_kernel<L2, SUB>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,         \
                      (const uint32_t*)d_starts, n_regions, sub_log2, vs->d_table, vs->log2cap, d_spill, d_spill_count,                  \
                      (unsigned long long)spill_cap, pristine, d_partials)
-    if (sub_log2 > 0) R3D_LAUNCH_MERGE(11, true);       // tables below 2^27 slots: several pieces per 2048-slot region
+#define R3D_LAUNCH_MERGE32(L2, PR)                                                                                                      \
+  hipLaunchKernelGGL((voxel_merge32_kernel<L2, PR>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,        \
+                     (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials)
+    const bool narrow = sub_log2 == 0;   // regions are pieces: 32-bit slots in LDS (same-process A/B against the 64-bit form: 385-397 -> 359-362 us)
+    if (narrow && region_log2 == 11) { if (pristine) R3D_LAUNCH_MERGE32(11, true); else R3D_LAUNCH_MERGE32(11, false); }
+    else if (narrow && region_log2 == 12) { if (pristine) R3D_LAUNCH_MERGE32(12, true); else R3D_LAUNCH_MERGE32(12, false); }
+    else if (narrow) { if (pristine) R3D_LAUNCH_MERGE32(13, true); else R3D_LAUNCH_MERGE32(13, false); }
+    else if (sub_log2 > 0) R3D_LAUNCH_MERGE(11, true);       // tables below 2^27 slots: several pieces per 2048-slot region
     else if (region_log2 == 11) R3D_LAUNCH_MERGE(11, false);
     else if (region_log2 == 12) R3D_LAUNCH_MERGE(12, false);
     else R3D_LAUNCH_MERGE(13, false);
 #undef R3D_LAUNCH_MERGE
+#undef R3D_LAUNCH_MERGE32
     hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
                        (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters,
                        (const unsigned long long*)d_partials, (int)merge_blocks);

@@ -513,6 +513,42 @@ def test_sort_merge_insert_matches_oracle_and_the_cas_path(V, ctx, n, log2cap, s
         d_xyz.free()
 
 
+def test_sort_merge_into_a_crowded_2_27_slot_table_agrees_with_the_cas_path(V, ctx):
+    """The 32-bit-slot merge (tables of 2^27 slots and more: a region is a piece) on a table that is NOT fresh and is crowded:
+    100 M random points, half of them CAS-placed first (load 0.33: probe runs cross region ends, so regions hold keys of their
+    neighbours -- the slots the merge must leave as they are), then everything through the merge (80 M distinct voxels, load 0.60:
+    thousands of deferred keys).  Against the same points through the CAS path alone: same counters, same codes."""
+    n = 100_000_000
+    rng = np.random.default_rng(2027)
+    d_xyz = ctx.alloc(n * 12)
+    chunk = 10_000_000
+    for k in range(n // chunk):
+        pts = (rng.random((chunk, 3), dtype=np.float32) * 60.0 - 30.0)
+        ctx.lib.r3d_memcpy_h2d(ctx.handle, d_xyz.ptr + k * chunk * 12, pts.ctypes.data, pts.nbytes)
+        ctx.sync()
+    a, b = V.VoxelSet(0.1, 1 << 27, ctx), V.VoxelSet(0.1, 1 << 27, ctx)
+    try:
+        ctx.set_tuning("voxel_path", 1)
+        a.insert_device(d_xyz.ptr, n)
+        b.insert_device(d_xyz.ptr, n // 2)
+        ctx.set_tuning("voxel_path", 2)
+        b.insert_device(d_xyz.ptr, n)
+        assert ctx.get_tuning("voxel_last_path") == 2
+        sa, sb = a.stats(), b.stats()
+        assert sa["overflow"] == 0 and sb["overflow"] == 0 and sa["voxels"] == sb["voxels"] > 75_000_000, (sa, sb)
+        assert sa["ignored_points"] * 3 == sb["ignored_points"] * 2            # (a saw the points once, b one and a half times)
+        assert np.array_equal(a.codes(), b.codes())
+        c = V.VoxelSet(0.1, 1 << 27, ctx)                                      # ... and a fresh table through the merge alone
+        c.insert_device(d_xyz.ptr, n)
+        assert c.stats()["voxels"] == sa["voxels"] and np.array_equal(c.codes(), a.codes())
+        c.close()
+    finally:
+        ctx.set_tuning("voxel_path", 0)
+        a.close()
+        b.close()
+        d_xyz.free()
+
+
 def test_sort_merge_insert_on_a_nearly_full_table_spills_and_still_agrees(V, ctx):
     """load factor 0.93: long probe runs cross region boundaries all the time (thousands of deferred keys), some keys were
     CAS-placed in the NEXT region before -- and the set is still the oracle's; a table that is too small reports overflow"""
