@@ -11,4 +11,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/voxel_sort_once.py 2 6 > $OUT/unprofiled.log 2>&1
 python3 tools/voxel_sort_once.py 1 3 > $OUT/unprofiled_cas.log 2>&1
-tail -1 $OUT/unprofiled.log $OUT/unprofiled_cas.log
+tail -n 1 $OUT/unprofiled.log; tail -n 1 $OUT/unprofiled_cas.log

@@ -17,7 +17,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "voxel_" + rnd)
 N = 100 * 384 * 1280
 DESIGNED = {"voxel_keys_kernel": 18 * N, "piece_scatter_kernel<1>": 11 * N, "byte_histogram_kernel": 1 * N, "piece_scatter_kernel<2>": 9 * N,
-            "voxel_merge_kernel": 4 * N + (1 << 27) * 8, "digit_scan_kernel": 2 * 12e6, "voxel_spill_kernel": 0}
+            "voxel_merge": 4 * N + (1 << 27) * 8, "digit_scan_kernel": 2 * 12e6, "voxel_spill_kernel": 0}
 
 
 def newest(pattern):
