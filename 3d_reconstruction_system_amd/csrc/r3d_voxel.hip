@@ -683,6 +683,10 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
 // remainder's top bits.  0xffffffff marks a free slot, 0xfffffffe (a table that is not fresh only) a slot that holds a key of
 // ANOTHER piece -- put there by the CAS path's probing across a region's end -- which must stay as it is; the two keys per piece
 // whose remainders are those values take the deferred way in.
+// Tried on top of it, each in a same-process A/B, and not kept: two LDS copies of a region so that region k is written back
+// while region k + 1 is filled (one barrier fewer per region: 363 -> 393 us, slower); a read-only sweep of the remainders into
+// the Infinity Cache in front of the launch (359 vs 362 us, + 29 us for the sweep); the deferred keys through an LDS list and
+// one counter add per workgroup (379-391 either way).
 template <int REGION_LOG2, bool PRISTINE>
 __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
                                                                  uint32_t n_regions, uint64_t* __restrict__ table,
