@@ -242,7 +242,6 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out) {
 
 static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "fuse_blocks")) return &ctx->fuse_blocks;
-  if (!strcmp(key, "fuse_loads")) return &ctx->fuse_loads;
   if (!strcmp(key, "fuse_prefetch")) return &ctx->fuse_prefetch;
   if (!strcmp(key, "fuse_chunk_mb")) return &ctx->fuse_chunk_mb;
   if (!strcmp(key, "fuse_stage_auto_mb")) return &ctx->fuse_stage_auto_mb;
@@ -251,12 +250,10 @@ static int* tuning_slot(r3d_ctx* ctx, const char* key) {
   if (!strcmp(key, "fuse_sweeps")) return &ctx->fuse_sweeps;
   if (!strcmp(key, "nn_variant")) return &ctx->nn_variant;
   if (!strcmp(key, "nn_warm")) return &ctx->nn_warm;
-  if (!strcmp(key, "nn_blocks")) return &ctx->nn_blocks;
   if (!strcmp(key, "apply_blocks")) return &ctx->apply_blocks;
   if (!strcmp(key, "voxel_dedupe")) return &ctx->voxel_dedupe;
   if (!strcmp(key, "voxel_path")) return &ctx->voxel_path;
   if (!strcmp(key, "voxel_last_path")) return &ctx->voxel_last_path;
-  if (!strcmp(key, "voxel_merge_blocks")) return &ctx->voxel_merge_blocks;
   return nullptr;
 }
 

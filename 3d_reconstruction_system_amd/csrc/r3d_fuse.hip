@@ -622,7 +622,7 @@ int fuse_common(r3d_ctx* ctx, const r3d_camera* cam, const void* d_depth, int de
   }
   const bool colour_after = d_rgb && out_dtype == R3D_F64;  // f64 xyz: colour goes through its own pass
   // byte-raster unprojection: dword loads + in-wave redistribution (load_tile_wave); knob 1 = element loads (A/B)
-  const bool wave = ctx->fuse_loads != 1 && !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !(d_rgb && !colour_after);
+  const bool wave = !with_pose && out_dtype == R3D_F32 && depth_dtype == R3D_DEPTH_U8 && !(d_rgb && !colour_after);
   // Inputs staged through the Infinity Cache chunk by chunk (cache_touch_kernel).  auto = when the inputs are a small share of
   // the launch's traffic (the sweep is an extra pass over them; measured at 1000 frames, profiles/r02_cold_inputs.log: u8
   // 4.3 -> 6.4 TB/s, u8 + colour 3.8 -> 5.5, u16 4.8 -> 6.3, f32 depth -> f64 xyz 4.4 -> 5.6, but f32 depth + colour (7 of

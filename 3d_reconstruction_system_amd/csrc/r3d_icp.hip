@@ -273,7 +273,7 @@ int r3d_icp_nn(r3d_ctx* ctx, const float* d_src, int64_t n_src, const float* d_t
   const int64_t src_blocks = (n_src + per_block - 1) / per_block;
   R3D_REQUIRE(src_blocks < ((int64_t)1 << 31), "source cloud too large");
   const int64_t n_tiles = (n_tgt + kTgtTile - 1) / kTgtTile;
-  int64_t want_blocks = ctx->nn_blocks > 0 ? ctx->nn_blocks : (int64_t)ctx->num_cus * 32;
+  int64_t want_blocks = (int64_t)ctx->num_cus * 32;
   int64_t n_seg = (want_blocks + src_blocks - 1) / src_blocks;
   if (n_seg > n_tiles) n_seg = n_tiles;
   if (n_seg > 65535) n_seg = 65535;

@@ -20,7 +20,6 @@ struct r3d_ctx {
   int num_cus = 256;
   // tuning knobs (r3d_ctx_set_tuning)
   int fuse_blocks = 0;   // 0 auto
-  int fuse_loads = 0;    // 0 auto (vector loads + in-wave redistribution where the raster allows), 1 element loads (A/B)
   int fuse_prefetch = 0; // 0 auto, 1 off, 2 on: stage the inputs of a launch in the Infinity Cache with a read-only sweep first
   int fuse_chunk_mb = 0; // 0 auto: input bytes staged (and fused) per step when the prefetch is on
   // fuse_prefetch auto: stage a launch's small-share inputs when they exceed this many MB.  Round 2 had 64 ("less than that
@@ -45,10 +44,8 @@ struct r3d_ctx {
   int select_ws_buckets = 0;         // ... for this many classes
   int nn_warm = 0;        // 0 auto: repeated presorted queries start from the previous matches' distances, ICP loops use
                           // nn_warm_kernel from their second iteration on; 1 off; 2 / 3: never / always nn_warm_kernel (A/B)
-  int nn_blocks = 0;      // target workgroup count for the NN sweep (0 = auto)
   int apply_blocks = 0;
   int voxel_path = 0;     // big inserts: 0 auto (a sample of the cloud decides), 1 LDS-set + CAS kernel, 2 sort-merge (r3d_voxel.hip)
-  int voxel_merge_blocks = 0; // sort-merge insert: workgroups of a merge launch (0 auto)
   int voxel_last_path = 0; // read-only: the path the last r3d_voxelset_insert took (1 / 2)
   int voxel_dedupe = 0;   // 0 auto (on), 1 off, 2 on: per-workgroup LDS dedupe in front of the global hash set; 3: on, with the
                           // flush barrier inside its `if` (A/B against DESIGN 4.5b's finding only)

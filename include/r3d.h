@@ -70,7 +70,7 @@ int r3d_ctx_create(int device, void* stream, int flags, r3d_ctx** ctx_out);
 int r3d_ctx_destroy(r3d_ctx* ctx);
 int r3d_ctx_sync(r3d_ctx* ctx);
 int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
-/* tuning knobs (integers; 0 = auto everywhere): launch geometry only -- "fuse_blocks", "apply_blocks", "nn_blocks"
+/* tuning knobs (integers; 0 = auto everywhere): launch geometry only -- "fuse_blocks", "apply_blocks"
  * (workgroup counts), "nn_variant" (sources per lane of the NN sweeps: 1/2/4), "nn_warm" (0 auto: a presorted
  * index query with the same source / output buffers as the previous one starts from that one's matches as bounds, and the ICP
  * loops run their later iterations on the wave-local kernel; 1 off; 2 never the wave-local kernel; 3 always when there are bounds: A/B), "voxel_dedupe" (0 auto, 1 off, 2 on, 3 = the pre-round-3 form with the flush barrier inside its `if`: A/B only),
@@ -83,7 +83,7 @@ int r3d_ctx_stream(r3d_ctx* ctx, void** stream_out);
  * a raster an H2D copy has just written runs at 0.49 of the HBM peak plain, 0.82 staged; staging a cached one costs 8 %).
  * A FOREIGN producer (torch, another library) that rewrites an input buffer in place says so with
  * r3d_ctx_set_tuning(ctx, "fuse_inputs_fresh", 1): an event, not a state -- nothing on the device is presumed cached any more;
- * reading the key back gives the number of ranges on record; "fuse_sweeps" counts the staging sweeps enqueued so far), "fuse_loads" (0 auto, 1 element loads in the byte-raster unprojection; A/B).
+ * reading the key back gives the number of ranges on record; "fuse_sweeps" counts the staging sweeps enqueued so far).
  * No knob changes any result bit.  Unknown key -> R3D_ERR_INVALID.  (Kernel A/B variants live in tools/ab_kernels.hip,
  * not in the library.) */
 int r3d_ctx_set_tuning(r3d_ctx* ctx, const char* key, int value);

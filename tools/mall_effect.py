@@ -41,13 +41,10 @@ def run(k_out, k_in, reps=160):
     return sorted(ts)[2]
 
 
-for loads in (0, 1):
-    ctx.set_tuning("fuse_loads", loads)
-    for k_out, k_in in ((1, 1), (16, 1), (1, 16), (16, 16)):
-        ms = run(k_out, k_in)
-        print("fused u8->f32 (%s), C2 launch, %2d output buffer(s), %2d input buffer(s): %.4f ms = %.2f TB/s"
-              % ("element loads" if loads else "vector loads", k_out, k_in, ms, n * 13 / ms / 1e9), flush=True)
-ctx.set_tuning("fuse_loads", 0)
+for k_out, k_in in ((1, 1), (16, 1), (1, 16), (16, 16)):
+    ms = run(k_out, k_in)
+    print("fused u8->f32, C2 launch, %2d output buffer(s), %2d input buffer(s): %.4f ms = %.2f TB/s"
+          % (k_out, k_in, ms, n * 13 / ms / 1e9), flush=True)
 
 big = ctx.alloc(16 * n * 12)
 for nbytes, label in ((n * 12, "0.59 GB, same buffer"), (16 * n * 12, "9.4 GB")):

@@ -24,9 +24,8 @@ for F in frames:
     for dt, db in ((np.uint8, 1), (np.uint16, 2), (np.float32, 4)):
         d_depth = ctx.alloc(n * db)
         L.check(ctx.lib.r3d_memset(ctx.handle, d_depth.ptr, 0x41, n * db))
-        for loads in ((0, 1) if db < 4 else (0,)):
-          ctx.set_tuning("fuse_loads", loads)
-          row = "%4d frames %-7s %s" % (F, np.dtype(dt).name, "element loads " if loads else "vector loads  ")
+        for loads in (0,):
+          row = "%4d frames %-7s" % (F, np.dtype(dt).name)
           for odt, ob in ((np.float32, 12), (np.float64, 24)):
             def launch():
                 r3d.fuse_frames_device(ctx, cam, d_depth.ptr, dt, F, d_pose.ptr, d_out.ptr, odt)
@@ -43,7 +42,6 @@ for F in frames:
             ms = sorted(ts)[2]
             row += " | %s xyz %8.3f ms %5.2f TB/s" % (np.dtype(odt).name, ms, n * (db + ob) / ms / 1e9)
           print(row, flush=True)
-        ctx.set_tuning("fuse_loads", 0)
         d_depth.free()
     d_pose.free()
     d_out.free()

@@ -26,9 +26,6 @@ cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
 r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
 vs = V.VoxelSet(0.1, 1 << log2cap, ctx)
 ctx.set_tuning("voxel_path", path)
-for key in ("voxel_merge_blocks",):
-    if os.environ.get(key.upper()):
-        ctx.set_tuning(key, int(os.environ[key.upper()]))
 times = []
 for _ in range(reps + 1):
     vs.clear()
@@ -36,5 +33,4 @@ for _ in range(reps + 1):
     ctx.timer_start()
     vs.insert_device(d_xyz.ptr, n)
     times.append(ctx.timer_stop())
-print("blocks=%s " % os.environ.get("VOXEL_MERGE_BLOCKS", "auto"), end="")
 print("path %d, table 2^%d: %s ms, %d voxels" % (path, log2cap, " ".join("%.3f" % t for t in times[1:]), vs.stats()["voxels"]))
