@@ -264,14 +264,17 @@ def all_gather_voxel_codes(codes, group=None):
     return np.unique(merged.numpy().view(np.uint64))
 
 
-def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm, everywhere=False, algo=0, pose_scale=1.0):
+def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm, everywhere=False, algo=0, pose_scale=1.0, keep_on_device=False):
     """BASELINE config 4 as the drop-in runs it: the pose file's frames in contiguous blocks, one block per rank
     (camera_to_world.py:149-172 carries no state between frames).  Every rank decodes ITS depth PNGs, fuses them with one
     launch straight into its slot of the world cloud in HBM, and one all-gather over the C ABI (r3d_allgather_xyz: RCCL,
     unequal blocks) assembles the cloud on every GPU.  No torch.
 
     Returns (names, lo, hi, depths_local [hi-lo,H,W], world): `world` is the whole [F*H*W,3] cloud on rank 0 (on every rank
-    with everywhere=True), else None.  Same bits as the single-GPU fuse_frames: same kernel, same per-frame arithmetic."""
+    with everywhere=True), else None.  Same bits as the single-GPU fuse_frames: same kernel, same per-frame arithmetic.
+    keep_on_device=True: nothing is downloaded; `world` is a dict instead -- {"d_full": DeviceBuffer holding the whole cloud on
+    THIS rank's GPU, "d_depth": DeviceBuffer with this rank's rasters (None for an empty block), "per": points per frame} --
+    whose buffers the caller frees (the drop-in formats its text from them on the GPU, device_text.TextWriter)."""
     from . import cloud_io
     from .device import xyz_code
     from .fusion import fuse_frames_device
@@ -284,6 +287,8 @@ def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm,
     out_dtype = np.dtype(out_dtype)
     xyz_code(out_dtype)
     if n_frames == 0:
+        if keep_on_device:
+            return names, 0, 0, np.empty((0, 0, 0), np.uint8), {"d_full": None, "d_depth": None, "per": 0}
         return names, 0, 0, np.empty((0, 0, 0), np.uint8), (np.empty((0, 3), out_dtype) if rank == 0 or everywhere else None)
     paths = [os.path.join(depth_dir, n) for n in names]
     # a rank whose block is empty (more GPUs than frames) still needs the raster size: the first frame's.
@@ -318,6 +323,7 @@ def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm,
     pts = [c * per for c in counts]
     d_full = ctx.alloc(n_frames * per * row)
     bufs = [d_full]
+    d_depth = None
     try:
         mine = d_full.ptr + lo * per * row
         if hi > lo:
@@ -329,7 +335,11 @@ def fuse_pose_file_sharded(qt_path, depth_dir, intrinsics, out_dtype, ctx, comm,
             fuse_frames_device(ctx, cam, d_depth.ptr, depths.dtype, hi - lo, d_pose.ptr, mine, out_dtype)
         comm.allgather_xyz(mine, pts, out_dtype, d_full.ptr, algo)
         world = None
-        if rank == 0 or everywhere:
+        if keep_on_device:
+            ctx.sync()
+            world = {"d_full": d_full, "d_depth": d_depth, "per": per}
+            bufs = [b for b in bufs if b is not d_full and b is not d_depth]
+        elif rank == 0 or everywhere:
             world = d_full.download(out_dtype, n_frames * per * 3).reshape(-1, 3)
         else:
             ctx.sync()

@@ -150,14 +150,59 @@ def _write_camera_txts(names, cam, depths, per):
 
 
 def _get_file_name_sharded(qt_path):
-    """get_file_name when a launcher started one process per GPU (WORLD_SIZE > 1): BASELINE config 4."""
+    """get_file_name when a launcher started one process per GPU (WORLD_SIZE > 1): BASELINE config 4.  Every rank fuses its
+    block of frames into its slot of the world cloud, one all-gather (C ABI, RCCL) assembles the cloud in HBM on every rank,
+    and the text is formatted where the data is: every rank writes the ./point/<stem>.txt of ITS frames from its GPU, rank 0
+    the world txt and the fused PLY from the gathered cloud -- same bytes as one GPU (R3D_HOST_TEXT=1: through host memory
+    and the host formatter, rounds 2-4's way)."""
     D = _common.module("dist")
     ctx, comm = _common.sharded_context()
     if comm.rank == 0:
         print('data start transfer')
     t1 = time.time()
+    host_text = os.environ.get("R3D_HOST_TEXT", "0") not in ("", "0")
     names, lo, hi, depths, world = D.fuse_pose_file_sharded(qt_path, './depth/', _common.intrinsics(), np.float64, ctx, comm,
-                                                            pose_scale=_common.pose_scale())
+                                                            pose_scale=_common.pose_scale(), keep_on_device=not host_text)
+    n_frames = len(names)
+    if host_text:
+        return _sharded_files_host_text(names, lo, hi, depths, world, ctx, comm, t1)
+    bufs = [b for b in (world["d_full"], world["d_depth"]) if b is not None]
+    try:        # a rank that fails while writing its files must still meet the others at the barrier, then raise
+        per = world["per"]
+        text = r3d.device_text.TextWriter(ctx)
+        if comm.rank == 0:
+            if n_frames:
+                text.add_ply('./ply/small_035_p8.ply', world["d_full"].ptr, np.float64, n_frames * per)
+            else:
+                r3d.cloud_io.write_ply('./ply/small_035_p8.ply', np.empty((0, 3)))
+        if n_frames and not _common.skip_intermediate():
+            if hi > lo:
+                cam = ctx.camera(depths.shape[1], depths.shape[2], *_common.intrinsics())
+                d_cam = ctx.alloc((hi - lo) * per * 24)
+                bufs.append(d_cam)
+                r3d.unproject_device(ctx, cam, world["d_depth"].ptr, depths.dtype, hi - lo, d_cam.ptr, np.float64)
+                integral = depths.dtype in (np.uint8, np.uint16)
+                text.add_xyz_txt(['./point/' + nm[0:-4] + '.txt' for nm in names[lo:hi]], d_cam.ptr, np.float64, (hi - lo) * per,
+                                 d_z_raw=world["d_depth"].ptr if integral else None, z_dtype=depths.dtype if integral else None)
+            if comm.rank == 0:
+                text.add_xyz_txt(['./point_world/small_worldpoint_5_23_5.txt'], world["d_full"].ptr + (n_frames - 1) * per * 24, np.float64, per)
+        text.write()
+        t2 = time.time()
+        if comm.rank == 0:
+            print('##################')
+            print("%d frames cost ." % n_frames, t2 - t1)
+            print("Write into .ply file Done.")
+    finally:
+        for b in bufs:
+            try:
+                b.free()
+            except Exception:
+                pass
+        comm.barrier()                         # nobody leaves (and tears RCCL down) while rank 0 still needs its peers
+        comm.close()
+
+
+def _sharded_files_host_text(names, lo, hi, depths, world, ctx, comm, t1):
     n_frames = len(names)
     ply_done = None
     try:        # a rank that fails while writing its files must still meet the others at the barrier, then raise

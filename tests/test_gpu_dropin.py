@@ -215,12 +215,13 @@ def test_camera_to_world_script_c1_scene_digests(tmp_path, golden_dir):
     np.testing.assert_allclose(world.sum(0), g["world_last_frame_sum"], rtol=1e-11)
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_camera_to_world_script_frame_sharded_over_ranks(tmp_path, golden_dir, mock_rccl, world):
+@pytest.mark.parametrize("world,host_text", [(2, "0"), (3, "0"), (4, "0"), (2, "1"), (4, "1")])
+def test_camera_to_world_script_frame_sharded_over_ranks(tmp_path, golden_dir, mock_rccl, world, host_text):
     """BASELINE config 4's shape through the drop-in: `torch.distributed.run --nproc-per-node N camera_to_world.py`.
     scene3 has 3 frames: 2 ranks = ragged blocks (2 + 1), 3 ranks = one each, 4 ranks = an EMPTY last block.  The ranks share
     the box's one GPU against the stand-in transport (R3D_RCCL_PATH; RCCL refuses two ranks per device); the worker
-    processes never import torch.  Every file must equal what the reference wrote for the same inputs."""
+    processes never import torch.  Every file must equal what the reference wrote for the same inputs -- with every rank
+    formatting its own files' text on the GPU (the default) and through host memory and the host formatter (R3D_HOST_TEXT=1)."""
     scene = os.path.join(golden_dir, "scene3")
     for d in ("depth", "camera_pose"):
         shutil.copytree(os.path.join(scene, d), tmp_path / d)
@@ -231,7 +232,7 @@ def test_camera_to_world_script_frame_sharded_over_ranks(tmp_path, golden_dir, m
            "127.0.0.1", "--master-port", str(port), os.path.join(SCRIPTS, "transfer", "camera_to_world.py")]
     r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", R3D_RCCL_PATH=mock_rccl,
-                                R3D_SHARE_GPU="1"))
+                                R3D_SHARE_GPU="1", R3D_HOST_TEXT=host_text))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("Write into .ply file Done.") == 1                  # rank 0 only
     for name in ("000", "007", "frame_b"):
