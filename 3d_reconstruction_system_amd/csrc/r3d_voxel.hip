@@ -35,7 +35,7 @@ struct r3d_voxelset {
   uint64_t* d_table = nullptr;
   uint64_t capacity = 0;  // power of two
   int log2cap = 0;
-  unsigned long long* d_counters = nullptr;  // [0] voxels, [1] ignored points, [2] overflow, [3] compaction cursor
+  unsigned long long* d_counters = nullptr;  // [0] voxels, [1] ignored points, [2] overflow, [3] compaction cursor, [4] sort-merge inserts that fell back (of 8 words)
   bool pristine = true;   // nothing has gone into the table since it was created / cleared (the merge then need not read it)
 };
 
@@ -478,6 +478,279 @@ __global__ __launch_bounds__(kThreads) void piece_scatter_kernel(const uint32_t*
   }
 }
 
+// ---- the sort's front half without a histogram in front of the first pass ------------------------------------------------------
+// A radix pass needs every (tile, bin) offset before it can write, so the first pass above costs a round trip of the elements
+// through HBM: the key kernel writes them (6 B/point) for the scatter to read back (6 B/point) once the scan is done.  The first
+// pass does not have to be dense, though.  Here a workgroup takes a GROUP of consecutive tiles and owns, for every bin, a SEGMENT
+// of the output with room for three times what a hash spreads into it: points become keys and go straight into the segments
+// (12 B/point in, 5 out, nothing in between); the second pass gathers a bin's segments -- a fixed number per tile, so that a tile
+// lies inside ONE lo bin and the run starts of the 65536 pieces are simply its offsets -- and is dense as before.  Points without a
+// key and the previous lane's duplicates are dropped here instead of travelling on as markers.
+// A segment that overflows (a group whose points crowd into few voxels: not what this path is chosen for) raises a flag on the
+// device; the merge then leaves the table alone and voxel_spill_kernel inserts the whole cloud the ordinary way -- correct,
+// slow, and counted (r3d_voxelset_sort_fallbacks).
+struct SegPlan {
+  int tiles_per_group = 1;   // 4096-point tiles a first-pass workgroup walks
+  int n_groups = 1;
+  int cap = 128;             // elements per segment (a multiple of 128: byte segments start on a line)
+  int segs_per_tile = 1;     // segments of one bin a second-pass tile gathers
+  int tiles_per_bin = 1;
+  int n_tiles2 = 256;
+};
+constexpr int kSegTileMean = 3900;   // expected elements of a second-pass tile (4096 places; a fuller one takes a second round)
+
+static SegPlan seg_plan(int64_t n_points, int num_cus) {
+  SegPlan p;
+  const int64_t n_tiles = (n_points + kSortTile - 1) / kSortTile;
+  const int64_t resident = (int64_t)num_cus * 5;   // first-pass workgroups a chip holds at once (31 KB of LDS each)
+  p.tiles_per_group = (int)std::max<int64_t>(1, (n_tiles + resident - 1) / resident);
+  p.n_groups = (int)((n_tiles + p.tiles_per_group - 1) / p.tiles_per_group);
+  const int mean = p.tiles_per_group * (kSortTile / 256);
+  p.cap = (3 * mean + 64 + 127) / 128 * 128;   // (address space only: what is not written costs nothing)
+  const int want = std::max(1, std::min(p.n_groups, kSegTileMean / mean));
+  p.tiles_per_bin = (p.n_groups + want - 1) / want;
+  p.segs_per_tile = (p.n_groups + p.tiles_per_bin - 1) / p.tiles_per_bin;
+  p.n_tiles2 = 256 * p.tiles_per_bin;
+  return p;
+}
+
+// flags: [0] give up (see above), [1] times that happened, [2..3] points without a key (64 bits; added to the set's counter by
+// voxel_spill_kernel when the sort went through).  seg_count[lo * n_groups + group] = elements the group has of bin lo.
+__global__ __launch_bounds__(kThreads, 5) void voxel_bin_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
+                                                             int tiles_per_group, int n_groups, int cap,
+                                                             uint32_t* __restrict__ seg_rem, uint8_t* __restrict__ seg_hi,
+                                                             uint32_t* __restrict__ seg_count, uint64_t* __restrict__ spill,
+                                                             unsigned long long* __restrict__ spill_count, unsigned long long spill_cap,
+                                                             uint32_t* __restrict__ flags) {
+  using namespace r3d_sort;
+  __shared__ uint32_t s_rem[kTile];
+  __shared__ uint8_t s_dig[kTile];
+  __shared__ uint8_t s_hi[kTile];
+  __shared__ uint32_t cursor[kBins];
+  __shared__ RankShared rk;
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.x;
+  cursor[threadIdx.x] = 0;
+  unsigned n_ignored = 0;
+  for (int t = 0; t < tiles_per_group; ++t) {
+    const int64_t t0 = ((int64_t)group * tiles_per_group + t) * kSortTile;
+    if (t0 >= n) break;   // (uniform)
+    const uint32_t n_tile = n - t0 < (int64_t)kSortTile ? (uint32_t)(n - t0) : (uint32_t)kSortTile;
+    const bool full = n_tile == (uint32_t)kSortTile;
+    const P3* __restrict__ tile_xyz = reinterpret_cast<const P3*>(xyz) + t0;
+    uint32_t rem[kRounds], dc[kRounds], live_mask = 0;   // dc: lo | hi << 8, later | the place in the tile's bin << 16
+#pragma unroll
+    for (int q = 0; q < kRounds / 4; ++q) {
+      P3 p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
+        p[r] = tile_xyz[full || e < n_tile ? e : n_tile - 1];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
+        uint64_t key = kEmpty;
+        bool live = full || e < n_tile;
+        if (fabsf(p[r].x) < safe_abs && fabsf(p[r].y) < safe_abs && fabsf(p[r].z) < safe_abs) {   // in range for sure (a NaN fails)
+          const uint32_t ix = (uint32_t)((int)floor(factor * (double)p[r].x) + r3d_vox::kTreeMaxVal);
+          const uint32_t iy = (uint32_t)((int)floor(factor * (double)p[r].y) + r3d_vox::kTreeMaxVal);
+          const uint32_t iz = (uint32_t)((int)floor(factor * (double)p[r].z) + r3d_vox::kTreeMaxVal);
+          key = (uint64_t)(ix | (iy << 16)) | ((uint64_t)iz << 32);
+        } else if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
+          ++n_ignored;
+          live = false;
+        }
+        if (!live) key = kEmpty;
+        const uint64_t prev = prev_lane_u64(key);
+        if (lane > 0 && prev == key) live = false;
+        const uint64_t h = hash48(key & kMask48);
+        if (live && h == kMask48) {   // the one key whose h48 reads as "no key" in the merge: it takes the deferred way in
+          const unsigned long long at = atomicAdd(spill_count, 1ull);
+          if (at < spill_cap) spill[at] = key;
+          live = false;
+        }
+        rem[q * 4 + r] = (uint32_t)h;
+        dc[q * 4 + r] = (uint32_t)(h >> 32) & 0xffffu;   // lo | hi << 8
+        live_mask |= (live ? 1u : 0u) << (q * 4 + r);
+      }
+    }
+    rank_reset(rk);
+    __syncthreads();   // (also: the previous tile's readers of the staging arrays and of `cursor` are through)
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)   // rank_any_rounds, the place kept beside the digits (sixteen registers fewer: five workgroups per CU)
+      if ((live_mask >> r) & 1u) dc[r] |= atomicAdd(&rk.bin_count[dc[r] & 0xff], 1u) << 16;
+    r3d_vox::lds_settle();
+    __syncthreads();
+    rank_any_place_bins(rk);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      if ((live_mask >> r) & 1u) {
+        const uint32_t at = rk.bin_start[dc[r] & 0xff] + (dc[r] >> 16);
+        s_rem[at] = rem[r];
+        s_dig[at] = (uint8_t)dc[r];
+        s_hi[at] = (uint8_t)(dc[r] >> 8);
+      }
+    }
+    __syncthreads();
+    const int n_live = (int)(rk.bin_start[kBins - 1] + rk.bin_count[kBins - 1]);
+#pragma unroll 4
+    for (int j = threadIdx.x; j < n_live; j += kThreads) {
+      const uint32_t d = s_dig[j];
+      const uint32_t at = cursor[d] + (uint32_t)(j - (int)rk.bin_start[d]);
+      if (at < (uint32_t)cap) {
+        const uint64_t to = ((uint64_t)d * n_groups + group) * (uint64_t)cap + at;
+        seg_rem[to] = s_rem[j];
+        seg_hi[to] = s_hi[j];
+      }
+    }
+    __syncthreads();
+    cursor[threadIdx.x] += rk.bin_count[threadIdx.x];
+  }
+  const uint32_t mine = cursor[threadIdx.x];
+  seg_count[(uint64_t)threadIdx.x * n_groups + group] = mine < (uint32_t)cap ? mine : (uint32_t)cap;
+  if (mine > (uint32_t)cap) flags[0] = 1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
+  if (lane == 0 && n_ignored) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)n_ignored);
+}
+
+// hist[hi][tile] for the second pass's tiles: tile T = the segments [g0, g0 + segs_per_tile) of bin lo = T / tiles_per_bin.
+// Eight tiles per workgroup, two per wave (whole-sector stores, as byte_histogram_kernel); four lanes read a segment's bytes,
+// sixteen segments at a time.
+__global__ __launch_bounds__(kThreads) void segment_histogram_kernel(const uint8_t* __restrict__ seg_hi, const uint32_t* __restrict__ seg_count,
+                                                                     int n_groups, int cap, int segs_per_tile, int tiles_per_bin,
+                                                                     int n_tiles2, uint32_t* __restrict__ hist, int stride) {
+  __shared__ uint32_t bins[8][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) bins[w][threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int slot = wave * 2 + half;
+    const int tile = blockIdx.x * 8 + slot;
+    if (tile >= n_tiles2) continue;
+    const int lo = tile / tiles_per_bin, g0 = (tile % tiles_per_bin) * segs_per_tile;
+    const int g1 = g0 + segs_per_tile < n_groups ? g0 + segs_per_tile : n_groups;
+    for (int gs = g0 + (lane >> 2); gs < g1; gs += 16) {
+      const uint64_t seg = (uint64_t)lo * n_groups + gs;
+      const uint32_t c = seg_count[seg];
+      const uint8_t* __restrict__ bytes = seg_hi + seg * (uint64_t)cap;
+      for (uint32_t at = (uint32_t)(lane & 3) * 16; at < c; at += 64) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bytes + at);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t valid = c - at < 16u ? c - at : 16u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if ((uint32_t)k < valid) atomicAdd(&bins[slot][(w4[k >> 2] >> (8 * (k & 3))) & 0xff], 1u);
+      }
+    }
+  }
+  r3d_vox::lds_settle();
+  __syncthreads();
+  uint32_t* row = hist + (int64_t)threadIdx.x * stride + blockIdx.x * 8;
+  if (blockIdx.x * 8 + 8 <= n_tiles2) {   // (rows are 32-byte aligned: r3d_sort_stride)
+    reinterpret_cast<uint4*>(row)[0] = uint4{bins[0][threadIdx.x], bins[1][threadIdx.x], bins[2][threadIdx.x], bins[3][threadIdx.x]};
+    reinterpret_cast<uint4*>(row)[1] = uint4{bins[4][threadIdx.x], bins[5][threadIdx.x], bins[6][threadIdx.x], bins[7][threadIdx.x]};
+  } else {
+    for (int w = 0; w < 8 && blockIdx.x * 8 + w < n_tiles2; ++w) row[w] = bins[w][threadIdx.x];
+  }
+}
+
+// The second pass over segments: one workgroup per tile (a bin lo's segments g0 ...), digit = hi, any order inside a bin (every
+// element of the tile has the same lo), the remainders out in piece order -- and starts[hi * 256 + lo] from the tile that comes
+// first in its lo bin: its own offset in bin hi.  A tile is sized to hold ~3900 elements on average; the one in a thousand that
+// holds more than 4096 takes a second round.  Which segment element e lies in: s_blk gives the segment at the start of e's block
+// of 64 (a binary search per block, not per element), a step or two forward finds the rest.
+__global__ __launch_bounds__(kThreads) void segment_scatter_kernel(const uint32_t* __restrict__ seg_rem, const uint8_t* __restrict__ seg_hi,
+                                                                   const uint32_t* __restrict__ seg_count, int n_groups, int cap,
+                                                                   int segs_per_tile, int tiles_per_bin, const uint32_t* __restrict__ hist,
+                                                                   int stride, const uint32_t* __restrict__ totals,
+                                                                   uint32_t* __restrict__ rem_out, uint32_t* __restrict__ starts) {
+  using namespace r3d_sort;
+  __shared__ uint32_t s_rem[kTile];
+  __shared__ uint8_t s_dig[kTile];
+  __shared__ uint32_t s_first[kBins + 1];   // where each of the tile's segments starts in the tile
+  __shared__ uint32_t s_blk[kTile / 64];
+  __shared__ RankShared rk;
+  __shared__ uint64_t g_base[kBins];
+  __shared__ uint64_t wave_total[kWaves];
+  const int wave = threadIdx.x >> 6;
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int lo = tile / tiles_per_bin, g0 = (tile % tiles_per_bin) * segs_per_tile;
+  const int n_seg = (g0 + segs_per_tile < n_groups ? g0 + segs_per_tile : n_groups) - g0;   // (<= 256; may be <= 0 in a bin's last tile)
+  const uint64_t bin_base = block_exclusive_scan_256(totals[threadIdx.x], wave_total);
+  __syncthreads();   // wave_total is reused
+  const uint32_t mine = (int)threadIdx.x < n_seg ? seg_count[(uint64_t)lo * n_groups + g0 + threadIdx.x] : 0u;
+  const uint32_t first = (uint32_t)block_exclusive_scan_256(mine, wave_total);
+  s_first[threadIdx.x] = first;
+  if (threadIdx.x == kBins - 1) s_first[kBins] = first + mine;
+  const uint64_t my_base = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
+  g_base[threadIdx.x] = my_base;
+  if (g0 == 0) starts[threadIdx.x * kBins + lo] = (uint32_t)my_base;   // thread = hi
+  if (tile == 0 && threadIdx.x == kBins - 1) {
+    const uint32_t total = (uint32_t)(bin_base + totals[kBins - 1]);
+    starts[kPieces] = total;
+    starts[kPieces + 1] = total;
+  }
+  __syncthreads();
+  const uint32_t n_tile = s_first[kBins];
+  int steps = 0;
+  while ((1 << steps) < n_seg) ++steps;
+  const uint64_t seg_base = ((uint64_t)lo * n_groups + g0) * (uint64_t)cap;
+  for (uint32_t round0 = 0; round0 < n_tile; round0 += kTile) {   // (uniform; nearly always once)
+    rank_reset(rk);
+    if (threadIdx.x < kTile / 64) {
+      const uint32_t e = round0 + threadIdx.x * 64;
+      uint32_t sgm = 0;   // the last segment that starts at or before e
+      for (int b = steps - 1; b >= 0; --b) {
+        const uint32_t probe = sgm | (1u << b);
+        if (probe < (uint32_t)n_seg && s_first[probe] <= e) sgm = probe;
+      }
+      s_blk[threadIdx.x] = sgm;
+    }
+    __syncthreads();
+    uint32_t rem[kRounds], digit[kRounds], place[kRounds], live_mask = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const uint32_t e = round0 + (uint32_t)r * kThreads + threadIdx.x;
+      const bool live = e < n_tile;
+      uint32_t sgm = s_blk[r * kWaves + wave];
+      while (live && s_first[sgm + 1] <= e) ++sgm;   // (s_first[n_seg ...] = n_tile > e: the walk ends inside the tile's segments)
+      const uint64_t at = seg_base + (uint64_t)sgm * cap + (e - s_first[sgm]);
+      rem[r] = live ? seg_rem[at] : 0;
+      digit[r] = live ? seg_hi[at] : 0;
+      live_mask |= (live ? 1u : 0u) << r;
+    }
+    rank_any_rounds(digit, live_mask, place, rk);
+    __syncthreads();
+    rank_any_place_bins(rk);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      if ((live_mask >> r) & 1u) {
+        const uint32_t at = rk.bin_start[digit[r]] + place[r];
+        s_rem[at] = rem[r];
+        s_dig[at] = (uint8_t)digit[r];
+      }
+    }
+    __syncthreads();
+    const int n_round = (int)(n_tile - round0 < (uint32_t)kTile ? n_tile - round0 : (uint32_t)kTile);
+#pragma unroll 4
+    for (int j = threadIdx.x; j < n_round; j += kThreads) {
+      const uint32_t d = s_dig[j];
+      rem_out[g_base[d] + (uint32_t)(j - (int)rk.bin_start[d])] = s_rem[j];
+    }
+    if (round0 + kTile < n_tile) {   // (uniform) another round: the bins' places move on
+      __syncthreads();
+      g_base[threadIdx.x] += rk.bin_count[threadIdx.x];
+      __syncthreads();
+    }
+  }
+}
+
 // REGION_LOG2: slots per LDS region.  SUB: several pieces per region (tables below 2^27 slots, whose pieces have fewer than
 // 2048 slots: a region then takes 2^sub_log2 consecutive ones); otherwise a piece IS a region and sub_log2 is 0.
 //
@@ -496,7 +769,8 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
                                                                uint32_t n_regions, int sub_log2_arg, uint64_t* __restrict__ table, int log2cap,
                                                                uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
                                                                unsigned long long spill_cap, int pristine,
-                                                               unsigned long long* __restrict__ partials) {
+                                                               unsigned long long* __restrict__ partials, const uint32_t* __restrict__ gave_up) {
+  if (*gave_up) return;   // (uniform) the segmented sort raised its flag: voxel_spill_kernel inserts the cloud instead
   const int sub_log2 = SUB ? sub_log2_arg : 0;
   constexpr int kSlots = 1 << REGION_LOG2;
   constexpr int kAhead = 4;    // elements per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
@@ -691,11 +965,13 @@ template <int REGION_LOG2, bool PRISTINE>
 __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
                                                                  uint32_t n_regions, uint64_t* __restrict__ table,
                                                                  uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                                 unsigned long long spill_cap, unsigned long long* __restrict__ partials) {
+                                                                 unsigned long long spill_cap, unsigned long long* __restrict__ partials,
+                                                                 const uint32_t* __restrict__ gave_up) {
   constexpr int kSlots = 1 << REGION_LOG2;
   constexpr int kAhead = 4;
   constexpr int kBatch = 128;
   constexpr int kPairs = kSlots / 2 / kThreads;   // slot pairs per thread
+  if (*gave_up) return;   // (uniform) see voxel_merge_kernel
   constexpr uint32_t kFree = 0xffffffffu, kForeign = 0xfffffffeu;
   __shared__ unsigned wg_count[2];
   if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;
@@ -819,6 +1095,9 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
             if (v.x == kForeign) out.x = orig[k].x;
             if (v.y == kForeign) out.y = orig[k].y;
           }
+          // (Every pair is written, free or not.  A fresh table already says "empty" everywhere, but leaving out the free 16-byte
+          // pairs -- 4 in 10 at load 0.36 -- or only whole free 32-byte sectors -- 1 in 6 -- took 234 MB off the write traffic and
+          // ADDED 200 / 150 us: lines written in part are slow at the memory.  Same-process A/B, round 5.)
           g[k * kThreads + threadIdx.x] = out;
         }
       }
@@ -855,11 +1134,44 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
 __global__ __launch_bounds__(kThreads) void voxel_spill_kernel(const uint64_t* __restrict__ spill, const unsigned long long* __restrict__ spill_count,
                                                                unsigned long long spill_cap, uint64_t* __restrict__ table, int log2cap,
                                                                unsigned long long* __restrict__ counters,
-                                                               const unsigned long long* __restrict__ partials, int n_partials) {
+                                                               const unsigned long long* __restrict__ partials, int n_partials,
+                                                               uint32_t* __restrict__ flags, const float* __restrict__ xyz, int64_t n_points,
+                                                               double factor) {
   const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
+  unsigned long long n_new = 0, n_over = 0;
+  if (flags[0]) {   // (uniform) the segmented sort gave up (voxel_bin_kernel): nothing has reached the table -- every point the ordinary way
+    unsigned long long n_ignored = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kThreads) {
+      const P3 p = reinterpret_cast<const P3*>(xyz)[i];
+      uint64_t key;
+      if (!r3d_vox::voxel_key(p.x, p.y, p.z, factor, &key)) {
+        ++n_ignored;
+        continue;
+      }
+      const int r = table_insert(table, mask, log2cap, key);
+      n_new += r > 0 ? 1u : 0u;
+      n_over += r < 0 ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      n_new += __shfl_down(n_new, off, 64);
+      n_over += __shfl_down(n_over, off, 64);
+      n_ignored += __shfl_down(n_ignored, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (n_new) atomicAdd(&counters[0], n_new);
+      if (n_ignored) atomicAdd(&counters[1], n_ignored);
+      if (n_over) atomicAdd(&counters[2], n_over);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[4], 1ull);   // how often that happened (r3d_voxelset_sort_fallbacks)
+    return;
+  }
   unsigned long long n = *spill_count;
   if (n > spill_cap) n = spill_cap;
-  unsigned long long n_new = 0, n_over = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the points the key kernel found no key for
+    const unsigned long long ign = *reinterpret_cast<const unsigned long long*>(flags + 2);
+    if (ign) atomicAdd(&counters[1], ign);
+  }
   for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kThreads) {
     const int r = table_insert(table, mask, log2cap, spill[i]);
     n_new += r > 0 ? 1u : 0u;
@@ -1214,9 +1526,9 @@ int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_v
   while (((int64_t)1 << vs->log2cap) < capacity && vs->log2cap < 40) ++vs->log2cap;
   vs->capacity = (uint64_t)1 << vs->log2cap;
   hipError_t e = hipMalloc((void**)&vs->d_table, vs->capacity * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&vs->d_counters, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&vs->d_counters, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream);
   if (e != hipSuccess) {
     r3d_voxelset_destroy(vs);
     return r3d_fail_hip(e, "voxel set allocation", __FILE__, __LINE__);
@@ -1240,7 +1552,7 @@ int r3d_voxelset_clear(r3d_voxelset* vs) {
   int rc = r3d_ctx_enter(vs->ctx);
   if (rc) return rc;
   R3D_HIP(hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), vs->ctx->stream));
-  R3D_HIP(hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), vs->ctx->stream));
+  R3D_HIP(hipMemsetAsync(vs->d_counters, 0, 8 * sizeof(unsigned long long), vs->ctx->stream));
   vs->pristine = true;
   return R3D_OK;
 }
@@ -1254,8 +1566,8 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
   R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
   // big inserts: a sample of the cloud decides between the two paths ("voxel_path": 1 / 2 force one)
   int path = 1;
-  if (vs->ctx->voxel_path == 2 && r3d_voxelset_sort_feasible(vs, n_points, true)) {
-    path = 2;
+  if ((vs->ctx->voxel_path == 2 || vs->ctx->voxel_path == 3) && r3d_voxelset_sort_feasible(vs, n_points, true)) {
+    path = vs->ctx->voxel_path;
   } else if (vs->ctx->voxel_path == 0 && r3d_voxelset_sort_feasible(vs, n_points, false)) {
     bool sort = false;
     if ((rc = r3d_voxelset_sample(vs, d_xyz, n_points, &sort))) return rc;
@@ -1297,67 +1609,85 @@ int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, 
   return R3D_OK;
 }
 
-static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) {
+static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, bool segmented) {
   r3d_ctx* ctx = vs->ctx;
   const int region_log2 = std::max(kRegionMinLog2, vs->log2cap - kPieceBits);   // slots per LDS region
   const int sub_log2 = kPieceBits - (vs->log2cap - region_log2);                // pieces per region (log2)
   const uint32_t n_regions = (uint32_t)1 << (vs->log2cap - region_log2);
-  const int64_t chunk = (int64_t)1 << 27;   // points per round: 0.8 GB of elements + 0.7 GB of sort scratch
+  const int64_t chunk = (int64_t)1 << 27;   // points per round: 0.5 GB of sorted remainders + 1.5 GB of segments
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   int rc;
   for (int64_t off = 0; off < n_points; off += chunk) {
     const int64_t m = std::min(chunk, n_points - off);
     const float* src = d_xyz + off * 3;
     const uint64_t spill_cap = (uint64_t)m;   // every key may be deferred (a nearly full table): the list can take them all
-    const int64_t n_tiles64 = (m + kSortTile - 1) / kSortTile;
+    const SegPlan plan = seg_plan(m, ctx->num_cus);
+    const int64_t n_tiles64 = segmented ? (int64_t)plan.n_tiles2 : (m + kSortTile - 1) / kSortTile;
     const int n_tiles = (int)n_tiles64, stride = r3d_sort_stride(n_tiles);
+    const size_t seg_elems = (size_t)plan.n_groups * 256 * plan.cap;
     void *a_v = nullptr, *b_v = nullptr, *ws = nullptr;
-    if ((rc = r3d_scratch(ctx, 1, up((size_t)m * 4) + up((size_t)m * 2), &a_v))) return rc;   // rem | hl, later the sorted rem
-    if ((rc = r3d_scratch(ctx, 2, up((size_t)m * 4) + up((size_t)m), &b_v))) return rc;       // rem | hi after the first pass
+    if ((rc = r3d_scratch(ctx, 1, up((size_t)m * 4) + up((size_t)m * 2), &a_v))) return rc;   // rem | hl (the old front), later the sorted rem
+    if ((rc = r3d_scratch(ctx, 2, segmented ? up(seg_elems * 4) + up(seg_elems) : up((size_t)m * 4) + up((size_t)m), &b_v))) return rc;   // the first pass's output: rem | hi
     uint32_t* rem_a = static_cast<uint32_t*>(a_v);
     uint16_t* hl_a = reinterpret_cast<uint16_t*>(static_cast<char*>(a_v) + up((size_t)m * 4));
     uint32_t* rem_b = static_cast<uint32_t*>(b_v);
-    uint8_t* hi_b = reinterpret_cast<uint8_t*>(static_cast<char*>(b_v) + up((size_t)m * 4));
+    uint8_t* hi_b = reinterpret_cast<uint8_t*>(static_cast<char*>(b_v) + up(segmented ? seg_elems * 4 : (size_t)m * 4));
     const unsigned merge_grid = (unsigned)ctx->num_cus * 8;   // (1536 .. 4096 workgroups measured within 3 % of each other)
     const size_t partial_bytes = up((size_t)merge_grid * 2 * sizeof(unsigned long long));
     const size_t starts_bytes = up(((size_t)kPieces + 2) * sizeof(uint32_t));
     const size_t hist_bytes = up((size_t)256 * stride * sizeof(uint32_t));
-    if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + spill_cap * 8, &ws))) return rc;
+    const size_t count_bytes = up((size_t)plan.n_groups * 256 * sizeof(uint32_t));
+    if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + count_bytes + spill_cap * 8, &ws))) return rc;
     char* w = static_cast<char*>(ws);
     unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(w + 32);
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(w + 64);   // [0] the segmented sort gave up, [2..3] points without a key
     unsigned long long* d_partials = reinterpret_cast<unsigned long long*>(w + 256);
     uint32_t* d_starts = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes);
     uint32_t* hist_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes);
     uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes);
     uint32_t* totals_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes);
     uint32_t* totals_hi = totals_lo + 256;
-    uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
-    R3D_HIP(hipMemsetAsync(d_spill_count, 0, 8, ctx->stream));
+    uint32_t* seg_count = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
+    uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + count_bytes);
+    R3D_HIP(hipMemsetAsync(w + 32, 0, 64, ctx->stream));   // the deferred keys' count and the flags
     // |x| < safe_abs  =>  |factor x| < 32767: every key in range whatever the rounding of the fp64 product (a bound strictly
     // inside the map's edge 32768 / factor, rounded towards zero and shrunk by 2^-20 on top)
     const float safe_abs = nextafterf((float)((32767.0 / vs->factor) * (1.0 - 1.0 / 1048576.0)), 0.0f);
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, rem_a, hl_a, hist_lo,
-                       stride, d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
-    r3d_sort_launch_scan(ctx, hist_lo, n_tiles, stride, totals_lo);
-    hipLaunchKernelGGL(piece_scatter_kernel<1>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
-                       (const uint16_t*)hl_a, (const uint8_t*)nullptr, m, (const uint32_t*)hist_lo, stride, (const uint32_t*)totals_lo,
-                       (const uint32_t*)nullptr, rem_b, hi_b, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(byte_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b, m, n_tiles,
-                       hist_hi, stride);
-    r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
-    hipLaunchKernelGGL(piece_scatter_kernel<2>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
-                       (const uint16_t*)nullptr, (const uint8_t*)hi_b, m, (const uint32_t*)hist_hi, stride, (const uint32_t*)totals_hi,
-                       (const uint32_t*)totals_lo, rem_a, (uint8_t*)nullptr, d_starts);
+    if (segmented) {
+      hipLaunchKernelGGL(voxel_bin_kernel, dim3((unsigned)plan.n_groups), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs,
+                         plan.tiles_per_group, plan.n_groups, plan.cap, rem_b, hi_b, seg_count, d_spill, d_spill_count,
+                         (unsigned long long)spill_cap, d_flags);
+      hipLaunchKernelGGL(segment_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b,
+                         (const uint32_t*)seg_count, plan.n_groups, plan.cap, plan.segs_per_tile, plan.tiles_per_bin, n_tiles, hist_hi, stride);
+      r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
+      hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
+                         (const uint8_t*)hi_b, (const uint32_t*)seg_count, plan.n_groups, plan.cap, plan.segs_per_tile, plan.tiles_per_bin,
+                         (const uint32_t*)hist_hi, stride, (const uint32_t*)totals_hi, rem_a, d_starts);
+    } else {
+      hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, rem_a, hl_a, hist_lo,
+                         stride, d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
+      r3d_sort_launch_scan(ctx, hist_lo, n_tiles, stride, totals_lo);
+      hipLaunchKernelGGL(piece_scatter_kernel<1>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
+                         (const uint16_t*)hl_a, (const uint8_t*)nullptr, m, (const uint32_t*)hist_lo, stride, (const uint32_t*)totals_lo,
+                         (const uint32_t*)nullptr, rem_b, hi_b, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(byte_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b, m, n_tiles,
+                         hist_hi, stride);
+      r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
+      hipLaunchKernelGGL(piece_scatter_kernel<2>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
+                         (const uint16_t*)nullptr, (const uint8_t*)hi_b, m, (const uint32_t*)hist_hi, stride, (const uint32_t*)totals_hi,
+                         (const uint32_t*)totals_lo, rem_a, (uint8_t*)nullptr, d_starts);
+    }
     const int pristine = vs->pristine ? 1 : 0;
     vs->pristine = false;
     const unsigned merge_blocks = std::min<uint32_t>(n_regions, merge_grid);   // persistent workgroups: the loop inside is a pipeline
 #define R3D_LAUNCH_MERGE(L2, SUB)                                                                                                       \
   hipLaunchKernelGGL((voxel_merge_kernel<L2, SUB>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,         \
                      (const uint32_t*)d_starts, n_regions, sub_log2, vs->d_table, vs->log2cap, d_spill, d_spill_count,                  \
-                     (unsigned long long)spill_cap, pristine, d_partials)
+                     (unsigned long long)spill_cap, pristine, d_partials, (const uint32_t*)d_flags)
 #define R3D_LAUNCH_MERGE32(L2, PR)                                                                                                      \
   hipLaunchKernelGGL((voxel_merge32_kernel<L2, PR>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,        \
-                     (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials)
+                     (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials, \
+                     (const uint32_t*)d_flags)
     const bool narrow = sub_log2 == 0;   // regions are pieces: 32-bit slots in LDS (same-process A/B against the 64-bit form: 385-397 -> 359-362 us)
     if (narrow && region_log2 == 11) { if (pristine) R3D_LAUNCH_MERGE32(11, true); else R3D_LAUNCH_MERGE32(11, false); }
     else if (narrow && region_log2 == 12) { if (pristine) R3D_LAUNCH_MERGE32(12, true); else R3D_LAUNCH_MERGE32(12, false); }
@@ -1370,7 +1700,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
 #undef R3D_LAUNCH_MERGE32
     hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
                        (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters,
-                       (const unsigned long long*)d_partials, (int)merge_blocks);
+                       (const unsigned long long*)d_partials, (int)merge_blocks, d_flags, src, m, vs->factor);
     R3D_HIP(hipGetLastError());
   }
   return R3D_OK;
@@ -1380,7 +1710,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
 int r3d_voxelset_insert_path(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int path) {
   if (n_points <= 0) return R3D_OK;
   vs->ctx->voxel_last_path = path;
-  if (path == 2) return insert_sorted(vs, d_xyz, n_points);
+  if (path == 2 || path == 3) return insert_sorted(vs, d_xyz, n_points, path == 2);   // (3: round 5's dense first pass, while both are compared)
   vs->pristine = false;
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
   int blocks = vs->ctx->num_cus * 8;
@@ -1425,6 +1755,17 @@ int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, 
   if (n_voxels) *n_voxels = (int64_t)c[0];
   if (n_ignored) *n_ignored = (int64_t)c[1];
   if (n_overflow) *n_overflow = (int64_t)c[2];
+  return R3D_OK;
+}
+
+int r3d_voxelset_sort_fallbacks(r3d_voxelset* vs, int64_t* n_out) {
+  R3D_REQUIRE(vs != nullptr && n_out != nullptr, "NULL argument");
+  int rc = r3d_ctx_enter(vs->ctx);
+  if (rc) return rc;
+  unsigned long long c = 0;
+  R3D_HIP(hipMemcpyAsync(&c, vs->d_counters + 4, sizeof(c), hipMemcpyDeviceToHost, vs->ctx->stream));
+  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
+  *n_out = (int64_t)c;
   return R3D_OK;
 }
 
