@@ -481,75 +481,97 @@ __global__ __launch_bounds__(kThreads) void piece_scatter_kernel(const uint32_t*
 // ---- the sort's front half without a histogram in front of the first pass ------------------------------------------------------
 // A radix pass needs every (tile, bin) offset before it can write, so the first pass above costs a round trip of the elements
 // through HBM: the key kernel writes them (6 B/point) for the scatter to read back (6 B/point) once the scan is done.  The first
-// pass does not have to be dense, though.  Here a workgroup takes a GROUP of consecutive tiles and owns, for every bin, a SEGMENT
-// of the output with room for three times what a hash spreads into it: points become keys and go straight into the segments
-// (12 B/point in, 5 out, nothing in between); the second pass gathers a bin's segments -- a fixed number per tile, so that a tile
-// lies inside ONE lo bin and the run starts of the 65536 pieces are simply its offsets -- and is dense as before.  Points without a
-// key and the previous lane's duplicates are dropped here instead of travelling on as markers.
-// A segment that overflows (a group whose points crowd into few voxels: not what this path is chosen for) raises a flag on the
-// device; the merge then leaves the table alone and voxel_spill_kernel inserts the whole cloud the ordinary way -- correct,
-// slow, and counted (r3d_voxelset_sort_fallbacks).
+// pass does not have to be dense, though, nor in any order.  Here every bin has one SEGMENT per XCD, with room for 1.25 x what
+// a hash spreads into it, and a cursor: a tile's workgroup turns its points into keys, ranks them by lo, takes room for each of
+// its 256 runs with one returning add on the cursor of (lo, its XCD) and writes -- 12 B/point in, 5 out, nothing in between.  The
+// workgroups that share a cursor run on one XCD: runs taken one after the other lie side by side and the lines they share are
+// completed in that XCD's L2 (private segments per workgroup, tried first, were not: a run's neighbour came a tile later, the
+// line had left the L2 half written -- 437 MB written for 241, and a partly written line is slow at the memory:
+// tools/scatter_runs.hip).  The second pass walks the segments in chunks of 4096 -- a tile lies inside ONE lo bin, so the run
+// starts of the 65536 pieces are simply its offsets -- and is dense as before.  Points without a key and the previous lane's
+// duplicates are dropped here instead of travelling on as markers.
+// A segment that overflows (keys that crowd into few bins: not what this path is chosen for) raises a flag on the device; the
+// merge then leaves the table alone and voxel_spill_kernel inserts the whole cloud the ordinary way -- correct, slow, and
+// counted (r3d_voxelset_sort_fallbacks).
+constexpr int kXcds = 8;
+constexpr int kSegments = 256 * kXcds;
+constexpr int kCursorStride = 32;   // words between two cursors: a line each
 struct SegPlan {
-  int tiles_per_group = 1;   // 4096-point tiles a first-pass workgroup walks
-  int n_groups = 1;
-  int cap = 128;             // elements per segment (a multiple of 128: byte segments start on a line)
-  int segs_per_tile = 1;     // segments of one bin a second-pass tile gathers
-  int tiles_per_bin = 1;
-  int n_tiles2 = 256;
+  int cap = kSortTile;       // elements per segment (a multiple of 4096)
+  int chunks = 1;            // second-pass tiles per segment
+  int n_tiles2 = kSegments;
 };
-constexpr int kSegTileMean = 3900;   // expected elements of a second-pass tile (4096 places; a fuller one takes a second round)
 
-static SegPlan seg_plan(int64_t n_points, int num_cus) {
+static SegPlan seg_plan(int64_t n_points) {
   SegPlan p;
-  const int64_t n_tiles = (n_points + kSortTile - 1) / kSortTile;
-  const int64_t resident = (int64_t)num_cus * 5;   // first-pass workgroups a chip holds at once (31 KB of LDS each)
-  p.tiles_per_group = (int)std::max<int64_t>(1, (n_tiles + resident - 1) / resident);
-  p.n_groups = (int)((n_tiles + p.tiles_per_group - 1) / p.tiles_per_group);
-  const int mean = p.tiles_per_group * (kSortTile / 256);
-  p.cap = (3 * mean + 64 + 127) / 128 * 128;   // (address space only: what is not written costs nothing)
-  const int want = std::max(1, std::min(p.n_groups, kSegTileMean / mean));
-  p.tiles_per_bin = (p.n_groups + want - 1) / want;
-  p.segs_per_tile = (p.n_groups + p.tiles_per_bin - 1) / p.tiles_per_bin;
-  p.n_tiles2 = 256 * p.tiles_per_bin;
+  const int64_t mean = (n_points + kSegments - 1) / kSegments;
+  p.chunks = (int)((mean + mean / 4 + 1024 + kSortTile - 1) / kSortTile);
+  p.cap = p.chunks * kSortTile;
+  p.n_tiles2 = kSegments * p.chunks;
   return p;
 }
 
-// flags: [0] give up (see above), [1] times that happened, [2..3] points without a key (64 bits; added to the set's counter by
-// voxel_spill_kernel when the sort went through).  seg_count[lo * n_groups + group] = elements the group has of bin lo.
-__global__ __launch_bounds__(kThreads, 5) void voxel_bin_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
-                                                             int tiles_per_group, int n_groups, int cap,
-                                                             uint32_t* __restrict__ seg_rem, uint8_t* __restrict__ seg_hi,
-                                                             uint32_t* __restrict__ seg_count, uint64_t* __restrict__ spill,
-                                                             unsigned long long* __restrict__ spill_count, unsigned long long spill_cap,
-                                                             uint32_t* __restrict__ flags) {
-  using namespace r3d_sort;
-  __shared__ uint32_t s_rem[kTile];
-  __shared__ uint8_t s_dig[kTile];
-  __shared__ uint8_t s_hi[kTile];
-  __shared__ uint32_t cursor[kBins];
-  __shared__ RankShared rk;
-  const int lane = threadIdx.x & 63;
-  const int group = blockIdx.x;
-  cursor[threadIdx.x] = 0;
+// flags: [0] give up (see above), [2..3] points without a key (64 bits; added to the set's counter by voxel_spill_kernel when
+// the sort went through).  cursors[(lo * 8 + xcd) * kCursorStride]: elements in the segment (may exceed cap: clamp).
+// 512 threads, eight points each: the kernel waits for latencies in turn (points, LDS adds, the cursor, the stores), so it wants
+// waves -- four workgroups of eight per CU fill it (256 threads x 16 points: five of four, 20 of 32 wave slots, 272 -> ... us).
+constexpr int kBinThreads = 512;
+constexpr int kBinRounds = kSortTile / kBinThreads;
+template <int EXP>
+__global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
+                                                                   int n_tiles, int cap, uint32_t* __restrict__ seg_rem,
+                                                                   uint8_t* __restrict__ seg_hi, uint32_t* __restrict__ cursors,
+                                                                   uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                                   unsigned long long spill_cap, uint32_t* __restrict__ flags) {
+  constexpr int kBins = r3d_sort::kBins;
+  __shared__ uint2 s_el[kSortTile];   // the tile in bin order: rem, lo | hi << 8 (one LDS write and one read per element)
+  __shared__ uint32_t s_base[kBins];
+  __shared__ uint32_t bin_count[kBins], bin_start[kBins], wave_sum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & (kXcds - 1);   // (workgroups go round the XCDs; nothing but locality depends on it)
   unsigned n_ignored = 0;
-  for (int t = 0; t < tiles_per_group; ++t) {
-    const int64_t t0 = ((int64_t)group * tiles_per_group + t) * kSortTile;
-    if (t0 >= n) break;   // (uniform)
+  bool over = false;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {   // (gridDim.x is a multiple of 8: a workgroup stays with its cursors)
+    const int64_t t0 = (int64_t)tile * kSortTile;
     const uint32_t n_tile = n - t0 < (int64_t)kSortTile ? (uint32_t)(n - t0) : (uint32_t)kSortTile;
     const bool full = n_tile == (uint32_t)kSortTile;
     const P3* __restrict__ tile_xyz = reinterpret_cast<const P3*>(xyz) + t0;
-    uint32_t rem[kRounds], dc[kRounds], live_mask = 0;   // dc: lo | hi << 8, later | the place in the tile's bin << 16
+    uint32_t rem[kBinRounds], dc[kBinRounds], live_mask = 0;   // dc: lo | hi << 8, later | the place in the tile's bin << 16
+    // the lane's eight points: nontemporal 12-byte loads, all in flight together, in ONE asm statement with the wait that
+    // completes them (the compiler does not count inline-asm loads: r3d_apply.hip).  Plain loads four at a time read the cloud
+    // at 3.9 TB/s (153 us with everything else switched off), this form at 6.9 (86 us).  One lane offset and eight scalar
+    // bases (a full tile's addresses are affine in the round) instead of eight 64-bit lane addresses: no spills at 64 registers.
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    f32x3 raw[kBinRounds];
+    static_assert(kBinRounds == 8, "eight loads are written out below");
+    if (full) {
+      const uint32_t voff = threadIdx.x * 12u;
+      const char* b0 = reinterpret_cast<const char*>(tile_xyz);
+      constexpr int kStep = kBinThreads * 12;
+#define R3D_LD3(o, b) "global_load_dwordx3 %" #o ", %8, %" #b " nt\n\t"
+      asm volatile(R3D_LD3(0, 9) R3D_LD3(1, 10) R3D_LD3(2, 11) R3D_LD3(3, 12) R3D_LD3(4, 13) R3D_LD3(5, 14) R3D_LD3(6, 15) R3D_LD3(7, 16)
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3]), "=&v"(raw[4]), "=&v"(raw[5]), "=&v"(raw[6]), "=&v"(raw[7])
+                   : "v"(voff), "s"(b0), "s"(b0 + kStep), "s"(b0 + 2 * kStep), "s"(b0 + 3 * kStep), "s"(b0 + 4 * kStep), "s"(b0 + 5 * kStep),
+                     "s"(b0 + 6 * kStep), "s"(b0 + 7 * kStep)
+                   : "memory");
+#undef R3D_LD3
+    } else {   // the cloud's last tile: clamped addresses, ordinary loads
 #pragma unroll
-    for (int q = 0; q < kRounds / 4; ++q) {
+      for (int r = 0; r < kBinRounds; ++r) {
+        const uint32_t e = (uint32_t)r * kBinThreads + threadIdx.x;
+        const P3 v = tile_xyz[e < n_tile ? e : n_tile - 1];
+        raw[r] = f32x3{v.x, v.y, v.z};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kBinRounds / 4; ++q) {
       P3 p[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
-        p[r] = tile_xyz[full || e < n_tile ? e : n_tile - 1];
-      }
+      for (int r = 0; r < 4; ++r) p[r] = P3{raw[q * 4 + r].x, raw[q * 4 + r].y, raw[q * 4 + r].z};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
+        const uint32_t e = (uint32_t)(q * 4 + r) * kBinThreads + threadIdx.x;
         uint64_t key = kEmpty;
         bool live = full || e < n_tile;
         if (fabsf(p[r].x) < safe_abs && fabsf(p[r].y) < safe_abs && fabsf(p[r].z) < safe_abs) {   // in range for sure (a NaN fails)
@@ -564,64 +586,84 @@ __global__ __launch_bounds__(kThreads, 5) void voxel_bin_kernel(const float* __r
         if (!live) key = kEmpty;
         const uint64_t prev = prev_lane_u64(key);
         if (lane > 0 && prev == key) live = false;
-        const uint64_t h = hash48(key & kMask48);
+        uint64_t h = hash48(key & kMask48);
+        if (EXP == 6) { h = (uint64_t)__float_as_uint(p[r].x) ^ ((uint64_t)__float_as_uint(p[r].y) << 13) ^ ((uint64_t)__float_as_uint(p[r].z) << 27); live = true; }
+        if (EXP == 3) h = ((uint64_t)__float_as_uint(p[r].x) * 0x9E3779B1u) ^ ((uint64_t)__float_as_uint(p[r].y) << 20);
         if (live && h == kMask48) {   // the one key whose h48 reads as "no key" in the merge: it takes the deferred way in
           const unsigned long long at = atomicAdd(spill_count, 1ull);
           if (at < spill_cap) spill[at] = key;
           live = false;
         }
         rem[q * 4 + r] = (uint32_t)h;
-        dc[q * 4 + r] = (uint32_t)(h >> 32) & 0xffffu;   // lo | hi << 8
+        dc[q * 4 + r] = (uint32_t)(h >> 32) & 0xffffu;
         live_mask |= (live ? 1u : 0u) << (q * 4 + r);
       }
     }
-    rank_reset(rk);
-    __syncthreads();   // (also: the previous tile's readers of the staging arrays and of `cursor` are through)
+    if (EXP == 5 || EXP == 6) {
+      uint32_t acc = live_mask;
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r)   // rank_any_rounds, the place kept beside the digits (sixteen registers fewer: five workgroups per CU)
-      if ((live_mask >> r) & 1u) dc[r] |= atomicAdd(&rk.bin_count[dc[r] & 0xff], 1u) << 16;
+      for (int r = 0; r < kBinRounds; ++r) acc += rem[r] ^ dc[r];
+      if (acc == 0x12345u) seg_rem[tile] = acc;
+      continue;
+    }
+    if (threadIdx.x < kBins) bin_count[threadIdx.x] = 0;
+    __syncthreads();   // (also: the previous tile's readers of the staging arrays are through)
+#pragma unroll
+    for (int r = 0; r < kBinRounds; ++r)   // any order inside a bin: the arrival number, kept beside the digits
+      if ((live_mask >> r) & 1u) dc[r] |= atomicAdd(&bin_count[dc[r] & 0xff], 1u) << 16;
     r3d_vox::lds_settle();
     __syncthreads();
-    rank_any_place_bins(rk);
+    uint32_t mine = 0, inc = 0, base = 0;
+    if (threadIdx.x < kBins) {   // thread = bin (waves 0..3)
+      mine = bin_count[threadIdx.x];
+      inc = r3d_sort::wave_inclusive_scan(mine, lane);
+      if (lane == 63) wave_sum[wave] = inc;
+      // room for this tile's run of the bin: the add is on its way while the tile is staged
+      if (EXP == 2) base = (uint32_t)(tile >> 3) * 20u; else
+      if (mine) base = atomicAdd(&cursors[(threadIdx.x * kXcds + xcd) * kCursorStride], mine);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins) {
+      uint32_t start = inc - mine;
+      for (int w = 0; w < wave; ++w) start += wave_sum[w];
+      bin_start[threadIdx.x] = start;
+    }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
+    for (int r = 0; r < kBinRounds; ++r) {
       if ((live_mask >> r) & 1u) {
-        const uint32_t at = rk.bin_start[dc[r] & 0xff] + (dc[r] >> 16);
-        s_rem[at] = rem[r];
-        s_dig[at] = (uint8_t)dc[r];
-        s_hi[at] = (uint8_t)(dc[r] >> 8);
+        const uint32_t at = bin_start[dc[r] & 0xff] + (dc[r] >> 16);
+        s_el[at] = uint2{rem[r], dc[r] & 0xffffu};
       }
     }
+    if (threadIdx.x < kBins) {
+      s_base[threadIdx.x] = base - bin_start[threadIdx.x];   // (modulo 2^32: element j of the bin order goes to s_base[its bin] + j)
+      over |= base + mine > (uint32_t)cap;
+    }
     __syncthreads();
-    const int n_live = (int)(rk.bin_start[kBins - 1] + rk.bin_count[kBins - 1]);
+    const int n_live = (int)(bin_start[kBins - 1] + bin_count[kBins - 1]);
 #pragma unroll 4
-    for (int j = threadIdx.x; j < n_live; j += kThreads) {
-      const uint32_t d = s_dig[j];
-      const uint32_t at = cursor[d] + (uint32_t)(j - (int)rk.bin_start[d]);
-      if (at < (uint32_t)cap) {
-        const uint64_t to = ((uint64_t)d * n_groups + group) * (uint64_t)cap + at;
-        seg_rem[to] = s_rem[j];
-        seg_hi[to] = s_hi[j];
+    for (int j = threadIdx.x; j < n_live; j += kBinThreads) {
+      const uint2 el = s_el[j];
+      const uint32_t d = el.y & 0xff;
+      const uint32_t at = s_base[d] + (uint32_t)j;
+      if (at < (uint32_t)cap && (EXP != 1 || el.x == 0x12345u)) {
+        const uint64_t to = (uint64_t)(d * kXcds + xcd) * (uint64_t)cap + at;
+        seg_rem[to] = el.x;
+        if (EXP != 4) seg_hi[to] = (uint8_t)(el.y >> 8);
       }
     }
-    __syncthreads();
-    cursor[threadIdx.x] += rk.bin_count[threadIdx.x];
   }
-  const uint32_t mine = cursor[threadIdx.x];
-  seg_count[(uint64_t)threadIdx.x * n_groups + group] = mine < (uint32_t)cap ? mine : (uint32_t)cap;
-  if (mine > (uint32_t)cap) flags[0] = 1;
+  if (over) flags[0] = 1;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
   if (lane == 0 && n_ignored) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)n_ignored);
 }
 
-// hist[hi][tile] for the second pass's tiles: tile T = the segments [g0, g0 + segs_per_tile) of bin lo = T / tiles_per_bin.
-// Eight tiles per workgroup, two per wave (whole-sector stores, as byte_histogram_kernel); four lanes read a segment's bytes,
-// sixteen segments at a time.
-__global__ __launch_bounds__(kThreads) void segment_histogram_kernel(const uint8_t* __restrict__ seg_hi, const uint32_t* __restrict__ seg_count,
-                                                                     int n_groups, int cap, int segs_per_tile, int tiles_per_bin,
-                                                                     int n_tiles2, uint32_t* __restrict__ hist, int stride) {
+// hist[hi][tile] for the second pass's tiles: tile T = chunk T % chunks of segment T / chunks.  Eight tiles per workgroup, two per
+// wave (whole-sector stores, as byte_histogram_kernel).
+__global__ __launch_bounds__(kThreads) void segment_histogram_kernel(const uint8_t* __restrict__ seg_hi, const uint32_t* __restrict__ cursors,
+                                                                     int cap, int chunks, int n_tiles2, uint32_t* __restrict__ hist, int stride) {
   __shared__ uint32_t bins[8][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -632,19 +674,35 @@ __global__ __launch_bounds__(kThreads) void segment_histogram_kernel(const uint8
     const int slot = wave * 2 + half;
     const int tile = blockIdx.x * 8 + slot;
     if (tile >= n_tiles2) continue;
-    const int lo = tile / tiles_per_bin, g0 = (tile % tiles_per_bin) * segs_per_tile;
-    const int g1 = g0 + segs_per_tile < n_groups ? g0 + segs_per_tile : n_groups;
-    for (int gs = g0 + (lane >> 2); gs < g1; gs += 16) {
-      const uint64_t seg = (uint64_t)lo * n_groups + gs;
-      const uint32_t c = seg_count[seg];
-      const uint8_t* __restrict__ bytes = seg_hi + seg * (uint64_t)cap;
-      for (uint32_t at = (uint32_t)(lane & 3) * 16; at < c; at += 64) {
-        const uint4 v = *reinterpret_cast<const uint4*>(bytes + at);
-        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t valid = c - at < 16u ? c - at : 16u;
+    const int seg = tile / chunks, chunk = tile % chunks;
+    uint32_t count = cursors[seg * kCursorStride];
+    if (count > (uint32_t)cap) count = cap;
+    const uint32_t c0 = (uint32_t)chunk * kSortTile;
+    if (count <= c0) continue;
+    const uint32_t n_tile = count - c0 < (uint32_t)kSortTile ? count - c0 : (uint32_t)kSortTile;
+    const uint8_t* __restrict__ bytes = seg_hi + (uint64_t)seg * cap + c0;
+    uint4 v[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if ((uint32_t)k < valid) atomicAdd(&bins[slot][(w4[k >> 2] >> (8 * (k & 3))) & 0xff], 1u);
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t at = (uint32_t)(k * 64 + lane) * 16;
+      v[k] = at < n_tile ? *reinterpret_cast<const uint4*>(bytes + at) : uint4{0, 0, 0, 0};   // (inside the segment: cap is a multiple of 4096)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t at = (uint32_t)(k * 64 + lane) * 16;
+      if (at >= n_tile) continue;
+      const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      const uint32_t valid = n_tile - at < 16u ? n_tile - at : 16u;
+      if (valid == 16u) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          atomicAdd(&bins[slot][w4[c] & 0xff], 1u);
+          atomicAdd(&bins[slot][(w4[c] >> 8) & 0xff], 1u);
+          atomicAdd(&bins[slot][(w4[c] >> 16) & 0xff], 1u);
+          atomicAdd(&bins[slot][w4[c] >> 24], 1u);
+        }
+      } else {
+        for (uint32_t c = 0; c < valid; ++c) atomicAdd(&bins[slot][(w4[c >> 2] >> (8 * (c & 3))) & 0xff], 1u);
       }
     }
   }
@@ -659,95 +717,68 @@ __global__ __launch_bounds__(kThreads) void segment_histogram_kernel(const uint8
   }
 }
 
-// The second pass over segments: one workgroup per tile (a bin lo's segments g0 ...), digit = hi, any order inside a bin (every
-// element of the tile has the same lo), the remainders out in piece order -- and starts[hi * 256 + lo] from the tile that comes
-// first in its lo bin: its own offset in bin hi.  A tile is sized to hold ~3900 elements on average; the one in a thousand that
-// holds more than 4096 takes a second round.  Which segment element e lies in: s_blk gives the segment at the start of e's block
-// of 64 (a binary search per block, not per element), a step or two forward finds the rest.
+// The second pass over segments: one workgroup per tile (a chunk of a segment: one lo), digit = hi, any order inside a bin, the
+// remainders out in piece order -- and starts[hi * 256 + lo] from the tile that comes first in its lo bin: its own offset in bin hi.
 __global__ __launch_bounds__(kThreads) void segment_scatter_kernel(const uint32_t* __restrict__ seg_rem, const uint8_t* __restrict__ seg_hi,
-                                                                   const uint32_t* __restrict__ seg_count, int n_groups, int cap,
-                                                                   int segs_per_tile, int tiles_per_bin, const uint32_t* __restrict__ hist,
-                                                                   int stride, const uint32_t* __restrict__ totals,
-                                                                   uint32_t* __restrict__ rem_out, uint32_t* __restrict__ starts) {
+                                                                   const uint32_t* __restrict__ cursors, int cap, int chunks,
+                                                                   const uint32_t* __restrict__ hist, int stride,
+                                                                   const uint32_t* __restrict__ totals, uint32_t* __restrict__ rem_out,
+                                                                   uint32_t* __restrict__ starts) {
   using namespace r3d_sort;
   __shared__ uint32_t s_rem[kTile];
   __shared__ uint8_t s_dig[kTile];
-  __shared__ uint32_t s_first[kBins + 1];   // where each of the tile's segments starts in the tile
-  __shared__ uint32_t s_blk[kTile / 64];
   __shared__ RankShared rk;
   __shared__ uint64_t g_base[kBins];
   __shared__ uint64_t wave_total[kWaves];
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int lo = tile / tiles_per_bin, g0 = (tile % tiles_per_bin) * segs_per_tile;
-  const int n_seg = (g0 + segs_per_tile < n_groups ? g0 + segs_per_tile : n_groups) - g0;   // (<= 256; may be <= 0 in a bin's last tile)
+  const int seg = tile / chunks, chunk = tile % chunks;
+  uint32_t count = cursors[seg * kCursorStride];
+  if (count > (uint32_t)cap) count = cap;
+  const uint32_t c0 = (uint32_t)chunk * kSortTile;
+  const bool first_of_lo = tile % (chunks * kXcds) == 0;
+  if (count <= c0 && !first_of_lo && tile != 0) return;   // (uniform) nothing in this chunk, nothing to announce
+  const int n_tile = count <= c0 ? 0 : (int)(count - c0 < (uint32_t)kSortTile ? count - c0 : (uint32_t)kSortTile);
+  rank_reset(rk);
   const uint64_t bin_base = block_exclusive_scan_256(totals[threadIdx.x], wave_total);
-  __syncthreads();   // wave_total is reused
-  const uint32_t mine = (int)threadIdx.x < n_seg ? seg_count[(uint64_t)lo * n_groups + g0 + threadIdx.x] : 0u;
-  const uint32_t first = (uint32_t)block_exclusive_scan_256(mine, wave_total);
-  s_first[threadIdx.x] = first;
-  if (threadIdx.x == kBins - 1) s_first[kBins] = first + mine;
   const uint64_t my_base = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
   g_base[threadIdx.x] = my_base;
-  if (g0 == 0) starts[threadIdx.x * kBins + lo] = (uint32_t)my_base;   // thread = hi
+  if (first_of_lo) starts[threadIdx.x * kBins + seg / kXcds] = (uint32_t)my_base;   // thread = hi
   if (tile == 0 && threadIdx.x == kBins - 1) {
     const uint32_t total = (uint32_t)(bin_base + totals[kBins - 1]);
     starts[kPieces] = total;
     starts[kPieces + 1] = total;
   }
+  if (n_tile == 0) return;   // (uniform)
+  const uint64_t base = (uint64_t)seg * cap + c0;
+  const int first = wave * kPerWave + lane;
+  uint32_t rem[kRounds], digit[kRounds], place[kRounds], live_mask = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int i = first + r * 64;
+    const bool live = i < n_tile;
+    rem[r] = live ? seg_rem[base + i] : 0;
+    digit[r] = live ? seg_hi[base + i] : 0;
+    live_mask |= (live ? 1u : 0u) << r;
+  }
   __syncthreads();
-  const uint32_t n_tile = s_first[kBins];
-  int steps = 0;
-  while ((1 << steps) < n_seg) ++steps;
-  const uint64_t seg_base = ((uint64_t)lo * n_groups + g0) * (uint64_t)cap;
-  for (uint32_t round0 = 0; round0 < n_tile; round0 += kTile) {   // (uniform; nearly always once)
-    rank_reset(rk);
-    if (threadIdx.x < kTile / 64) {
-      const uint32_t e = round0 + threadIdx.x * 64;
-      uint32_t sgm = 0;   // the last segment that starts at or before e
-      for (int b = steps - 1; b >= 0; --b) {
-        const uint32_t probe = sgm | (1u << b);
-        if (probe < (uint32_t)n_seg && s_first[probe] <= e) sgm = probe;
-      }
-      s_blk[threadIdx.x] = sgm;
-    }
-    __syncthreads();
-    uint32_t rem[kRounds], digit[kRounds], place[kRounds], live_mask = 0;
+  rank_any_rounds(digit, live_mask, place, rk);
+  __syncthreads();
+  rank_any_place_bins(rk);
+  __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const uint32_t e = round0 + (uint32_t)r * kThreads + threadIdx.x;
-      const bool live = e < n_tile;
-      uint32_t sgm = s_blk[r * kWaves + wave];
-      while (live && s_first[sgm + 1] <= e) ++sgm;   // (s_first[n_seg ...] = n_tile > e: the walk ends inside the tile's segments)
-      const uint64_t at = seg_base + (uint64_t)sgm * cap + (e - s_first[sgm]);
-      rem[r] = live ? seg_rem[at] : 0;
-      digit[r] = live ? seg_hi[at] : 0;
-      live_mask |= (live ? 1u : 0u) << r;
+  for (int r = 0; r < kRounds; ++r) {
+    if ((live_mask >> r) & 1u) {
+      const uint32_t at = rk.bin_start[digit[r]] + place[r];
+      s_rem[at] = rem[r];
+      s_dig[at] = (uint8_t)digit[r];
     }
-    rank_any_rounds(digit, live_mask, place, rk);
-    __syncthreads();
-    rank_any_place_bins(rk);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      if ((live_mask >> r) & 1u) {
-        const uint32_t at = rk.bin_start[digit[r]] + place[r];
-        s_rem[at] = rem[r];
-        s_dig[at] = (uint8_t)digit[r];
-      }
-    }
-    __syncthreads();
-    const int n_round = (int)(n_tile - round0 < (uint32_t)kTile ? n_tile - round0 : (uint32_t)kTile);
+  }
+  __syncthreads();
 #pragma unroll 4
-    for (int j = threadIdx.x; j < n_round; j += kThreads) {
-      const uint32_t d = s_dig[j];
-      rem_out[g_base[d] + (uint32_t)(j - (int)rk.bin_start[d])] = s_rem[j];
-    }
-    if (round0 + kTile < n_tile) {   // (uniform) another round: the bins' places move on
-      __syncthreads();
-      g_base[threadIdx.x] += rk.bin_count[threadIdx.x];
-      __syncthreads();
-    }
+  for (int j = threadIdx.x; j < n_tile; j += kThreads) {
+    const uint32_t d = s_dig[j];
+    rem_out[g_base[d] + (uint32_t)(j - (int)rk.bin_start[d])] = s_rem[j];
   }
 }
 
@@ -1621,10 +1652,11 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
     const int64_t m = std::min(chunk, n_points - off);
     const float* src = d_xyz + off * 3;
     const uint64_t spill_cap = (uint64_t)m;   // every key may be deferred (a nearly full table): the list can take them all
-    const SegPlan plan = seg_plan(m, ctx->num_cus);
-    const int64_t n_tiles64 = segmented ? (int64_t)plan.n_tiles2 : (m + kSortTile - 1) / kSortTile;
+    const SegPlan plan = seg_plan(m);
+    const int64_t n_tiles1 = (m + kSortTile - 1) / kSortTile;   // the first pass's tiles
+    const int64_t n_tiles64 = segmented ? (int64_t)plan.n_tiles2 : n_tiles1;
     const int n_tiles = (int)n_tiles64, stride = r3d_sort_stride(n_tiles);
-    const size_t seg_elems = (size_t)plan.n_groups * 256 * plan.cap;
+    const size_t seg_elems = (size_t)kSegments * plan.cap;
     void *a_v = nullptr, *b_v = nullptr, *ws = nullptr;
     if ((rc = r3d_scratch(ctx, 1, up((size_t)m * 4) + up((size_t)m * 2), &a_v))) return rc;   // rem | hl (the old front), later the sorted rem
     if ((rc = r3d_scratch(ctx, 2, segmented ? up(seg_elems * 4) + up(seg_elems) : up((size_t)m * 4) + up((size_t)m), &b_v))) return rc;   // the first pass's output: rem | hi
@@ -1636,7 +1668,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
     const size_t partial_bytes = up((size_t)merge_grid * 2 * sizeof(unsigned long long));
     const size_t starts_bytes = up(((size_t)kPieces + 2) * sizeof(uint32_t));
     const size_t hist_bytes = up((size_t)256 * stride * sizeof(uint32_t));
-    const size_t count_bytes = up((size_t)plan.n_groups * 256 * sizeof(uint32_t));
+    const size_t count_bytes = up((size_t)kSegments * kCursorStride * sizeof(uint32_t));   // the segments' cursors, a line each
     if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + count_bytes + spill_cap * 8, &ws))) return rc;
     char* w = static_cast<char*>(ws);
     unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(w + 32);
@@ -1647,22 +1679,25 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
     uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes);
     uint32_t* totals_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes);
     uint32_t* totals_hi = totals_lo + 256;
-    uint32_t* seg_count = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
+    uint32_t* d_cursors = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
     uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + count_bytes);
     R3D_HIP(hipMemsetAsync(w + 32, 0, 64, ctx->stream));   // the deferred keys' count and the flags
     // |x| < safe_abs  =>  |factor x| < 32767: every key in range whatever the rounding of the fp64 product (a bound strictly
     // inside the map's edge 32768 / factor, rounded towards zero and shrunk by 2^-20 on top)
     const float safe_abs = nextafterf((float)((32767.0 / vs->factor) * (1.0 - 1.0 / 1048576.0)), 0.0f);
     if (segmented) {
-      hipLaunchKernelGGL(voxel_bin_kernel, dim3((unsigned)plan.n_groups), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs,
-                         plan.tiles_per_group, plan.n_groups, plan.cap, rem_b, hi_b, seg_count, d_spill, d_spill_count,
-                         (unsigned long long)spill_cap, d_flags);
+      R3D_HIP(hipMemsetAsync(d_cursors, 0, count_bytes, ctx->stream));
+      const unsigned bin_grid = (unsigned)((n_tiles1 + 7) / 8 * 8);   // a tile each (a multiple of 8: see the kernel)
+#define R3D_BIN(E) hipLaunchKernelGGL(voxel_bin_kernel<E>, dim3(bin_grid), dim3(kBinThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, (int)n_tiles1, \
+                         plan.cap, rem_b, hi_b, d_cursors, d_spill, d_spill_count, (unsigned long long)spill_cap, d_flags)
+      switch (ctx->voxel_dedupe >= 10 ? ctx->voxel_dedupe - 10 : 0) { case 1: R3D_BIN(1); break; case 2: R3D_BIN(2); break; case 3: R3D_BIN(3); break; case 4: R3D_BIN(4); break; case 5: R3D_BIN(5); break; case 6: R3D_BIN(6); break; default: R3D_BIN(0); }
+#undef R3D_BIN
       hipLaunchKernelGGL(segment_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b,
-                         (const uint32_t*)seg_count, plan.n_groups, plan.cap, plan.segs_per_tile, plan.tiles_per_bin, n_tiles, hist_hi, stride);
+                         (const uint32_t*)d_cursors, plan.cap, plan.chunks, n_tiles, hist_hi, stride);
       r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
       hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
-                         (const uint8_t*)hi_b, (const uint32_t*)seg_count, plan.n_groups, plan.cap, plan.segs_per_tile, plan.tiles_per_bin,
-                         (const uint32_t*)hist_hi, stride, (const uint32_t*)totals_hi, rem_a, d_starts);
+                         (const uint8_t*)hi_b, (const uint32_t*)d_cursors, plan.cap, plan.chunks, (const uint32_t*)hist_hi, stride,
+                         (const uint32_t*)totals_hi, rem_a, d_starts);
     } else {
       hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, rem_a, hl_a, hist_lo,
                          stride, d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
