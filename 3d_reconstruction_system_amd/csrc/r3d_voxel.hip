@@ -719,66 +719,88 @@ __global__ __launch_bounds__(kThreads) void segment_histogram_kernel(const uint8
 
 // The second pass over segments: one workgroup per tile (a chunk of a segment: one lo), digit = hi, any order inside a bin, the
 // remainders out in piece order -- and starts[hi * 256 + lo] from the tile that comes first in its lo bin: its own offset in bin hi.
-__global__ __launch_bounds__(kThreads) void segment_scatter_kernel(const uint32_t* __restrict__ seg_rem, const uint8_t* __restrict__ seg_hi,
-                                                                   const uint32_t* __restrict__ cursors, int cap, int chunks,
-                                                                   const uint32_t* __restrict__ hist, int stride,
-                                                                   const uint32_t* __restrict__ totals, uint32_t* __restrict__ rem_out,
-                                                                   uint32_t* __restrict__ starts) {
-  using namespace r3d_sort;
-  __shared__ uint32_t s_rem[kTile];
-  __shared__ uint8_t s_dig[kTile];
-  __shared__ RankShared rk;
-  __shared__ uint64_t g_base[kBins];
-  __shared__ uint64_t wave_total[kWaves];
+// 512 threads; a thread takes EIGHT CONSECUTIVE elements (any assignment will do for an any-order ranking): two 16-byte loads of
+// remainders and one 8-byte load of hi bytes instead of sixteen 4-byte and 1-byte ones.
+__global__ __launch_bounds__(kBinThreads, 8) void segment_scatter_kernel(const uint32_t* __restrict__ seg_rem, const uint8_t* __restrict__ seg_hi,
+                                                                         const uint32_t* __restrict__ cursors, int cap, int chunks,
+                                                                         const uint32_t* __restrict__ hist, int stride,
+                                                                         const uint32_t* __restrict__ totals, uint32_t* __restrict__ rem_out,
+                                                                         uint32_t* __restrict__ starts) {
+  constexpr int kBins = r3d_sort::kBins;
+  __shared__ uint2 s_el[kSortTile];   // the tile in bin order: rem, hi
+  __shared__ uint32_t s_to[kBins];    // where bin d's first element goes, minus its place in the tile
+  __shared__ uint32_t bin_count[kBins], bin_start[kBins], wave_sum[4], total_of_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tile = r3d_sort::xcd_contiguous(blockIdx.x, gridDim.x);
   const int seg = tile / chunks, chunk = tile % chunks;
   uint32_t count = cursors[seg * kCursorStride];
   if (count > (uint32_t)cap) count = cap;
   const uint32_t c0 = (uint32_t)chunk * kSortTile;
   const bool first_of_lo = tile % (chunks * kXcds) == 0;
   if (count <= c0 && !first_of_lo && tile != 0) return;   // (uniform) nothing in this chunk, nothing to announce
-  const int n_tile = count <= c0 ? 0 : (int)(count - c0 < (uint32_t)kSortTile ? count - c0 : (uint32_t)kSortTile);
-  rank_reset(rk);
-  const uint64_t bin_base = block_exclusive_scan_256(totals[threadIdx.x], wave_total);
-  const uint64_t my_base = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
-  g_base[threadIdx.x] = my_base;
-  if (first_of_lo) starts[threadIdx.x * kBins + seg / kXcds] = (uint32_t)my_base;   // thread = hi
-  if (tile == 0 && threadIdx.x == kBins - 1) {
-    const uint32_t total = (uint32_t)(bin_base + totals[kBins - 1]);
-    starts[kPieces] = total;
-    starts[kPieces + 1] = total;
-  }
-  if (n_tile == 0) return;   // (uniform)
+  const uint32_t n_tile = count <= c0 ? 0u : (count - c0 < (uint32_t)kSortTile ? count - c0 : (uint32_t)kSortTile);
+  // the elements first: they are on their way while the bins' bases are worked out
   const uint64_t base = (uint64_t)seg * cap + c0;
-  const int first = wave * kPerWave + lane;
-  uint32_t rem[kRounds], digit[kRounds], place[kRounds], live_mask = 0;
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int i = first + r * 64;
-    const bool live = i < n_tile;
-    rem[r] = live ? seg_rem[base + i] : 0;
-    digit[r] = live ? seg_hi[base + i] : 0;
-    live_mask |= (live ? 1u : 0u) << r;
+  const uint32_t e0 = threadIdx.x * kBinRounds;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+  u32x2 hb = {0, 0};
+  if (e0 < n_tile) {   // (whole loads: the segment's capacity is a multiple of the tile)
+    ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(seg_rem + base + e0));
+    rb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(seg_rem + base + e0) + 1);
+    hb = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(seg_hi + base + e0));
+  }
+  uint32_t my_base = 0;
+  if (threadIdx.x < kBins) {   // thread = hi: bin base = the totals below it, + this tile's offset in the bin
+    bin_count[threadIdx.x] = 0;
+    const uint32_t tot = totals[threadIdx.x];
+    const uint32_t inc = r3d_sort::wave_inclusive_scan(tot, lane);
+    if (lane == 63) total_of_wave[wave] = inc;
+    my_base = inc - tot + hist[(int64_t)threadIdx.x * stride + tile];
   }
   __syncthreads();
-  rank_any_rounds(digit, live_mask, place, rk);
-  __syncthreads();
-  rank_any_place_bins(rk);
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    if ((live_mask >> r) & 1u) {
-      const uint32_t at = rk.bin_start[digit[r]] + place[r];
-      s_rem[at] = rem[r];
-      s_dig[at] = (uint8_t)digit[r];
+  if (threadIdx.x < kBins) {
+    for (int w = 0; w < wave; ++w) my_base += total_of_wave[w];
+    if (first_of_lo) starts[threadIdx.x * kBins + seg / kXcds] = my_base;
+    if (tile == 0 && threadIdx.x == kBins - 1) {
+      const uint32_t total = my_base - hist[(int64_t)threadIdx.x * stride + tile] + totals[kBins - 1];
+      starts[kPieces] = total;
+      starts[kPieces + 1] = total;
     }
   }
+  if (n_tile == 0) return;   // (uniform)
+  const uint32_t rem[kBinRounds] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+  uint32_t dg[kBinRounds];
+#pragma unroll
+  for (int r = 0; r < kBinRounds; ++r) dg[r] = ((r < 4 ? hb.x : hb.y) >> (8 * (r & 3))) & 0xff;
+#pragma unroll
+  for (int r = 0; r < kBinRounds; ++r)
+    if (e0 + r < n_tile) dg[r] |= atomicAdd(&bin_count[dg[r]], 1u) << 16;
+  r3d_vox::lds_settle();
+  __syncthreads();
+  uint32_t mine = 0, inc = 0;
+  if (threadIdx.x < kBins) {
+    mine = bin_count[threadIdx.x];
+    inc = r3d_sort::wave_inclusive_scan(mine, lane);
+    if (lane == 63) wave_sum[wave] = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < kBins) {
+    uint32_t start = inc - mine;
+    for (int w = 0; w < wave; ++w) start += wave_sum[w];
+    bin_start[threadIdx.x] = start;
+    s_to[threadIdx.x] = my_base - start;   // (modulo 2^32)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kBinRounds; ++r)
+    if (e0 + r < n_tile) s_el[bin_start[dg[r] & 0xff] + (dg[r] >> 16)] = uint2{rem[r], dg[r] & 0xff};
   __syncthreads();
 #pragma unroll 4
-  for (int j = threadIdx.x; j < n_tile; j += kThreads) {
-    const uint32_t d = s_dig[j];
-    rem_out[g_base[d] + (uint32_t)(j - (int)rk.bin_start[d])] = s_rem[j];
+  for (uint32_t j = threadIdx.x; j < n_tile; j += kBinThreads) {
+    const uint2 el = s_el[j];
+    rem_out[s_to[el.y] + j] = el.x;
   }
 }
 
@@ -1695,7 +1717,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
       hipLaunchKernelGGL(segment_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b,
                          (const uint32_t*)d_cursors, plan.cap, plan.chunks, n_tiles, hist_hi, stride);
       r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
-      hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
+      hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)n_tiles), dim3(kBinThreads), 0, ctx->stream, (const uint32_t*)rem_b,
                          (const uint8_t*)hi_b, (const uint32_t*)d_cursors, plan.cap, plan.chunks, (const uint32_t*)hist_hi, stride,
                          (const uint32_t*)totals_hi, rem_a, d_starts);
     } else {
