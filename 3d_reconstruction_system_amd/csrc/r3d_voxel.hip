@@ -968,7 +968,7 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
       for (uint32_t i = lo + kAhead * kThreads + threadIdx.x; i < hi; i += kThreads) insert_one(r, i, rems[i]);   // a longer run than usual
       if (mine_changed) changed = 1;   // (benign race: everybody writes the same value)
       r3d_vox::lds_barrier();
-      if (changed) {   // (nontemporal stores change nothing here: measured)
+      if (changed) {   // (nontemporal stores changed nothing here in round 4; in the 32-bit form they are worth 8 %)
 #pragma unroll
         for (int k = 0; k < kSlots / 2 / kThreads; ++k) g[k * kThreads + threadIdx.x] = reinterpret_cast<const ulonglong2*>(region)[k * kThreads + threadIdx.x];
       }
@@ -1010,7 +1010,9 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
 // remainder's top bits.  0xffffffff marks a free slot, 0xfffffffe (a table that is not fresh only) a slot that holds a key of
 // ANOTHER piece -- put there by the CAS path's probing across a region's end -- which must stay as it is; the two keys per piece
 // whose remainders are those values take the deferred way in.
-// Tried on top of it, each in a same-process A/B, and not kept: two LDS copies of a region so that region k is written back
+// Tried on top of it, each in a same-process A/B, and not kept: two / four pieces per iteration (one set of barriers for 4096 /
+// 8192 slots: 345 -> 385 / 520 us) and 128-thread workgroups (4096 of them: 344, no gain) -- the kernel wants what it has, many
+// small independent regions; two LDS copies of a region so that region k is written back
 // while region k + 1 is filled (one barrier fewer per region: 363 -> 393 us, slower); a read-only sweep of the remainders into
 // the Infinity Cache in front of the launch (359 vs 362 us, + 29 us for the sweep); the deferred keys through an LDS list and
 // one counter add per workgroup (379-391 either way).
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
       const uint32_t i = lo_ + (uint32_t)k * kThreads + threadIdx.x;
-      dst[k] = i < hi_ ? rems[i] : kFree;
+      dst[k] = i < hi_ ? rems[i] : kFree;   // (plain loads: nontemporal ones 305 -> 322 us)
     }
   };
   auto load_bounds = [&](uint32_t it0) {
@@ -1151,7 +1153,9 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
           // (Every pair is written, free or not.  A fresh table already says "empty" everywhere, but leaving out the free 16-byte
           // pairs -- 4 in 10 at load 0.36 -- or only whole free 32-byte sectors -- 1 in 6 -- took 234 MB off the write traffic and
           // ADDED 200 / 150 us: lines written in part are slow at the memory.  Same-process A/B, round 5.)
-          g[k * kThreads + threadIdx.x] = out;
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          // (nontemporal: 325 -> 296-310 us against the plain store, same process)
+          __builtin_nontemporal_store(u64x2{out.x, out.y}, reinterpret_cast<u64x2*>(g) + k * kThreads + threadIdx.x);
         }
       }
     } else {

@@ -14,7 +14,9 @@ cam = ctx.camera(H, W, *r3d.REF_INTRINSICS)
 r3d.fuse_frames_device(ctx, cam, d_depth.ptr, np.uint8, F, d_pose.ptr, d_xyz.ptr, np.float32)
 vs = V.VoxelSet(0.1, 1 << 27, ctx)
 ctx.set_tuning("voxel_path", 2)
-for exp in (0, 6, 1, 0):
-    ctx.set_tuning("voxel_dedupe", 10 + exp if exp else 0)
+for pp in (0, 1, 0, 1):
+    ctx.set_tuning("voxel_dedupe", 20 + pp if pp else 0)
+    ts = []
     for _ in range(6):
-        vs.clear(); ctx.sync(); vs.insert_device(d_xyz.ptr, n); ctx.sync()
+        vs.clear(); ctx.sync(); ctx.timer_start(); vs.insert_device(d_xyz.ptr, n); ts.append(ctx.timer_stop())
+    print("P", pp, "%.3f" % float(np.median(ts)), vs.stats(), flush=True)
