@@ -143,7 +143,6 @@ SIGNATURES = {
     "r3d_voxelset_insert_codes": (_i, [_vp, _vp, _i64]),
     "r3d_voxelset_union": (_i, [_vp, _vp]),
     "r3d_voxelset_stats": (_i, [_vp, _vp, _vp, _vp]),
-    "r3d_voxelset_sort_fallbacks": (_i, [_vp, _vp]),
     "r3d_voxelset_codes": (_i, [_vp, _vp, _i64, _vp]),
     "r3d_sort_u64": (_i, [_vp, _vp, _i64, _i]),
     "r3d_octree_format_bt": (_i, [_vp, _i64, _d, _vp, _sz, _psz, _vp]),

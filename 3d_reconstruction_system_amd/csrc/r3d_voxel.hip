@@ -35,7 +35,7 @@ struct r3d_voxelset {
   uint64_t* d_table = nullptr;
   uint64_t capacity = 0;  // power of two
   int log2cap = 0;
-  unsigned long long* d_counters = nullptr;  // [0] voxels, [1] ignored points, [2] overflow, [3] compaction cursor, [4] sort-merge inserts that fell back (of 8 words)
+  unsigned long long* d_counters = nullptr;  // [0] voxels, [1] ignored points, [2] overflow, [3] compaction cursor
   bool pristine = true;   // nothing has gone into the table since it was created / cleared (the merge then need not read it)
 };
 
@@ -201,24 +201,21 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
 // a whole line through HBM and back.  Random access is the cost, so this path has none.
 //
 // Round 5 form.  A key's place in the table is the top bits of h48 = key * G mod 2^48, a BIJECTION of the 48-bit keys
-// (r3d_voxel_dev.h).  The top 16 bits of h48 name one of 65536 PIECES of the table; within a piece a key is the low 32 bits of
-// h48.  So the sort moves 4-byte remainders (+ one digit byte while it is still needed), not 8-byte words:
-//   voxel_keys_kernel      12 B/point in; out: rem = h48 & 0xffffffff (4 B), the piece's two digit bytes hi | lo (2 B), and the
-//                          tile's histogram of `lo` (the first pass's);
-//   piece_scatter_kernel<1>  by `lo`: 6 B in, rem + hi out (5 B), stable, tile staged in LDS in bin order (r3d_sort_dev.h);
-//   byte_histogram_kernel  of the permuted `hi` bytes: 1 B/point (rounds 2-4 re-read the 8-byte words: 8 B/point);
-//   piece_scatter_kernel<2>  by `hi`: 5 B in, rem out (4 B) -- and the RUN STARTS of all 65536 pieces: the pass's input is in
-//                          `lo` order, so a tile knows from the first pass's bin totals which `lo` boundaries fall inside it,
-//                          and thread `hi` counts how many of its bin's elements lie in front of each (a binary search over the
-//                          original positions, kept beside the staged tile).  Rounds 2-4 spent a pass over the sorted words on this;
-//   voxel_merge_kernel     persistent workgroups walk the table's 2048..8192-slot regions: the region comes into LDS (or is just
-//                          initialised when the table is known to be empty), the remainders of its piece(s) are turned back into
-//                          keys (key = (piece << 32 | rem) * G^-1 mod 2^48) and inserted THERE (LDS compare-and-swap, linear
-//                          probing from the home slot: the same placement rule as table_insert), the region goes back with 16-byte
-//                          stores.  A probe that runs off the region's end is deferred to a spill list (voxel_spill_kernel,
-//                          ordinary CAS, ~0.1 % of the keys at load 0.4).
-// HBM sees streams only.  Per point: 18 (keys) + 11 + 1 + 9 (sort) + 4 + 16 x capacity / n (merge) = 43 + 8 x slots per point
-// bytes; rounds 2-4: 76 + 8 x slots per point.  C2 (2.73 slots per point): 64.8 instead of 97.8 B/point.
+// (r3d_voxel_dev.h).  The top 16 bits of h48 name one of 65536 PIECES of the table (hi | lo, a byte each); within a piece a key
+// is the low 32 bits of h48.  So the sort moves 4-byte remainders (+ one digit byte while it is still needed), not 8-byte words:
+//   voxel_bin_kernel        12 B/point in; keys, ranked by lo, straight into per-XCD bin segments: rem (4 B) + hi (1 B) out -- no
+//                           histogram in front, no round trip of the elements (see below);
+//   segment_histogram_kernel  of the segments' hi bytes, per 4096-element chunk: 1 B/point;
+//   segment_scatter_kernel  by hi: 5 B in, rem out (4 B) in piece order -- and the RUN STARTS of all 65536 pieces for free: a chunk
+//                           lies inside one lo bin, so starts[hi | lo] is the offset in bin hi of lo's first chunk;
+//   voxel_merge32_kernel / voxel_merge_kernel  persistent workgroups walk the table's 2048..8192-slot regions: the region is
+//                           initialised in LDS (or comes in, when the table is not fresh), the remainders of its piece(s) are
+//                           inserted THERE (LDS compare-and-swap, linear probing from the home slot: the same placement rule as
+//                           table_insert), keys are rebuilt (key = (piece << 32 | rem) * G^-1 mod 2^48) on the way out in 16-byte
+//                           stores.  A probe that runs off the region's end is deferred to a spill list (voxel_spill_kernel,
+//                           ordinary CAS, ~0.1 % of the keys at load 0.4).
+// HBM sees streams only.  Per point: 17 (keys + first pass) + 1 + 9 (second pass) + 4 + 8 x slots per point (merge); the first form
+// of this round (a key kernel, a dense first pass behind its histogram) moved 43 + 8 x slots, rounds 2-4 76 + 8 x slots.
 constexpr int kRegionMinLog2 = 11;   // slots per LDS region: 2048 (16 KB of LDS) ... 8192 (64 KB)
 constexpr int kRegionMaxLog2 = 13;
 constexpr int kPieceBits = 16;       // the table is sorted into 2^16 pieces (the top 16 bits of h48)
@@ -226,257 +223,6 @@ constexpr uint32_t kPieces = 1u << kPieceBits;
 using r3d_vox::hash48;
 using r3d_vox::kMask48;
 using r3d_vox::unhash48;
-
-// One workgroup per SORT TILE (4096 points): rem / hl for every point of the tile (live or not) and the tile's histogram of the
-// low piece byte, hist[bin][tile] (what the first pass would otherwise have to count from the elements again).
-// The kernel is bound by instruction issue, not by HBM (rocprofv3 SQ_WAIT_INST_ANY: 63 % of its wave-cycles wait for an issue
-// slot, profiles/r05_voxel_sq_counters.txt), so the common case is kept short: tile-relative 32-bit offsets, and three f32
-// compares that prove all three keys in range (|x|, |y|, |z| < safe_abs, a bound the host derives from the resolution;
-// a NaN fails them -- a max3 would drop it) before the exact fp64 floor -- only a point near the map's edge or a non-finite one takes voxel_key()'s six
-// fp64 comparisons.
-template <bool FULL>   // FULL: the tile lies wholly inside the cloud (all tiles but the last): no bounds in the loop
-__device__ __forceinline__ unsigned keys_of_tile(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
-                                                 uint32_t* __restrict__ rem, uint16_t* __restrict__ hl, uint32_t* bins,
-                                                 uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                 unsigned long long spill_cap) {
-  const int lane = threadIdx.x & 63;
-  unsigned n_ignored = 0;
-  const int64_t t0 = (int64_t)blockIdx.x * kSortTile;
-  const P3* __restrict__ tile_xyz = reinterpret_cast<const P3*>(xyz) + t0;
-  uint32_t* __restrict__ tile_rem = rem + t0;
-  uint16_t* __restrict__ tile_hl = hl + t0;
-  const uint32_t n_tile = FULL ? (uint32_t)kSortTile : (uint32_t)(n - t0);
-#pragma unroll
-  for (int q = 0; q < kSortTile / (kThreads * 4); ++q) {
-    P3 p[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
-      p[r] = tile_xyz[FULL || e < n_tile ? e : n_tile - 1];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t e = (uint32_t)(q * 4 + r) * kThreads + threadIdx.x;
-      const bool inside = FULL || e < n_tile;
-      uint64_t key = kEmpty;
-      bool live = inside;
-      if (fabsf(p[r].x) < safe_abs && fabsf(p[r].y) < safe_abs && fabsf(p[r].z) < safe_abs) {   // in range for sure (a NaN fails: fmaxf would drop it): the same fp64 floors, no range test
-        const uint32_t ix = (uint32_t)((int)floor(factor * (double)p[r].x) + r3d_vox::kTreeMaxVal);
-        const uint32_t iy = (uint32_t)((int)floor(factor * (double)p[r].y) + r3d_vox::kTreeMaxVal);
-        const uint32_t iz = (uint32_t)((int)floor(factor * (double)p[r].z) + r3d_vox::kTreeMaxVal);
-        key = (uint64_t)(ix | (iy << 16)) | ((uint64_t)iz << 32);
-      } else if (live && !r3d_vox::voxel_key(p[r].x, p[r].y, p[r].z, factor, &key)) {
-        ++n_ignored;
-        live = false;
-        key = kEmpty;
-      }
-      if (!live) key = kEmpty;
-      const uint64_t prev = prev_lane_u64(key);
-      if (lane > 0 && prev == key) live = false;
-      uint64_t h = live ? hash48(key) : kMask48;   // kMask48: no key
-      if (live && h == kMask48) {   // the one key whose h48 reads as "no key": it takes the deferred way in
-        const unsigned long long at = atomicAdd(spill_count, 1ull);   // (the list holds one entry per point: always room)
-        if (at < spill_cap) spill[at] = key;
-      }
-      if (inside) {
-        tile_rem[e] = (uint32_t)h;
-        tile_hl[e] = (uint16_t)(h >> 32);
-        atomicAdd(&bins[(uint32_t)(h >> 32) & 0xff], 1u);
-      }
-    }
-  }
-  return n_ignored;
-}
-
-__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
-                                                              uint32_t* __restrict__ rem, uint16_t* __restrict__ hl,
-                                                              uint32_t* __restrict__ hist, int hist_stride,
-                                                              uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                              unsigned long long spill_cap, unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t bins[256];
-  const int lane = threadIdx.x & 63;
-  bins[threadIdx.x] = 0;
-  __syncthreads();
-  unsigned n_ignored;
-  if ((int64_t)(blockIdx.x + 1) * kSortTile <= n)
-    n_ignored = keys_of_tile<true>(xyz, n, factor, safe_abs, rem, hl, bins, spill, spill_count, spill_cap);
-  else
-    n_ignored = keys_of_tile<false>(xyz, n, factor, safe_abs, rem, hl, bins, spill, spill_count, spill_cap);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
-  if (lane == 0 && n_ignored) atomicAdd(&counters[1], (unsigned long long)n_ignored);   // (rare: non-finite / far points only)
-  r3d_vox::lds_settle();
-  __syncthreads();
-  hist[(int64_t)threadIdx.x * hist_stride + blockIdx.x] = bins[threadIdx.x];
-}
-
-// hist[bin][tile] of a byte array, 4096 bytes per tile.  A workgroup takes EIGHT consecutive tiles, two per wave: bin b's eight
-// counters are then 32 consecutive, 32-byte-aligned bytes of row b -- one whole sector.  (One tile per workgroup: 12 000
-// workgroups bound by their own launch and 4-byte pieces; four tiles: 16-byte pieces, 73 MB written for 12 MB of counters
-// -- rocprofv3 WRITE_SIZE -- and 40 us.)  Four 16-byte loads per lane in flight, 64 LDS adds into the wave's own bins.
-__global__ __launch_bounds__(kThreads) void byte_histogram_kernel(const uint8_t* __restrict__ bytes, int64_t n, int n_tiles,
-                                                                  uint32_t* __restrict__ hist, int stride) {
-  __shared__ uint32_t bins[8][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) bins[w][threadIdx.x] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int slot = wave * 2 + half;
-    const int tile = blockIdx.x * 8 + slot;
-    if (tile >= n_tiles) continue;
-    const int64_t t0 = (int64_t)tile * kSortTile;
-    uint4 v[4];
-    bool whole[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t at = t0 + (int64_t)(k * 64 + lane) * 16;
-      whole[k] = at + 16 <= n;
-      v[k] = whole[k] ? *reinterpret_cast<const uint4*>(bytes + at) : uint4{0, 0, 0, 0};
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (whole[k]) {
-        const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          atomicAdd(&bins[slot][w4[c] & 0xff], 1u);
-          atomicAdd(&bins[slot][(w4[c] >> 8) & 0xff], 1u);
-          atomicAdd(&bins[slot][(w4[c] >> 16) & 0xff], 1u);
-          atomicAdd(&bins[slot][w4[c] >> 24], 1u);
-        }
-      } else {
-        const int64_t at = t0 + (int64_t)(k * 64 + lane) * 16;
-        for (int c = 0; c < 16 && at + c < n; ++c) atomicAdd(&bins[slot][bytes[at + c]], 1u);
-      }
-    }
-  }
-  r3d_vox::lds_settle();
-  __syncthreads();
-  uint32_t* row = hist + (int64_t)threadIdx.x * stride + blockIdx.x * 8;
-  if (blockIdx.x * 8 + 8 <= n_tiles) {   // (rows are 32-byte aligned: r3d_sort_stride)
-    reinterpret_cast<uint4*>(row)[0] = uint4{bins[0][threadIdx.x], bins[1][threadIdx.x], bins[2][threadIdx.x], bins[3][threadIdx.x]};
-    reinterpret_cast<uint4*>(row)[1] = uint4{bins[4][threadIdx.x], bins[5][threadIdx.x], bins[6][threadIdx.x], bins[7][threadIdx.x]};
-  } else {
-    for (int w = 0; w < 8 && blockIdx.x * 8 + w < n_tiles; ++w) row[w] = bins[w][threadIdx.x];
-  }
-}
-
-// One radix pass over the elements of the sort-merge insert.  PASS 1: digit = lo (of hl), carries rem + hi; any order inside a
-// bin (nothing has been sorted yet).  PASS 2: digit = hi, carries rem alone and leaves starts[piece] for all 65536 pieces (+ two
-// end markers).  Its input is in lo order and a tile of 4096 elements almost always lies inside ONE lo run (~190 K elements on
-// C2): such a tile may also be ranked in any order; only a tile with a lo boundary in its interior (1 in ~47) takes the stable
-// ranking, which keeps the smaller lo in front inside every hi bin.  totals_lo: the first pass's bin totals.
-template <int PASS>
-__global__ __launch_bounds__(kThreads) void piece_scatter_kernel(const uint32_t* __restrict__ rem_in, const uint16_t* __restrict__ hl_in,
-                                                                 const uint8_t* __restrict__ hi_in, int64_t n,
-                                                                 const uint32_t* __restrict__ hist, int stride,
-                                                                 const uint32_t* __restrict__ totals, const uint32_t* __restrict__ totals_lo,
-                                                                 uint32_t* __restrict__ rem_out, uint8_t* __restrict__ hi_out,
-                                                                 uint32_t* __restrict__ starts) {
-  using namespace r3d_sort;
-  __shared__ uint32_t s_rem[kTile];
-  __shared__ uint8_t s_dig[kTile];                       // the digit of the element staged at each place
-  __shared__ uint8_t s_hi[PASS == 1 ? kTile : 4];        // pass 1: the byte that travels on
-  __shared__ uint16_t s_orig[PASS == 2 ? kTile : 2];     // pass 2, stable tiles: where in the tile the element came from
-  __shared__ uint32_t s_owned[PASS == 2 ? kBins : 1];    // pass 2: the lo boundaries this tile owns: lo | tile-local position << 8
-  __shared__ uint32_t n_owned;
-  __shared__ RankShared rk;
-  __shared__ uint64_t g_base[kBins];
-  __shared__ uint64_t wave_total[kWaves];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int64_t base = (int64_t)tile * kTile;
-  const int n_tile = (int)(n - base < (int64_t)kTile ? n - base : (int64_t)kTile);
-  rank_reset(rk);
-  if (threadIdx.x == 0) n_owned = 0;
-  const uint64_t bin_base = block_exclusive_scan_256(totals[threadIdx.x], wave_total);
-  bool stable = false;
-  if (PASS == 2) {
-    // The input is in lo order: position P[lo] = sum of the first pass's totals below lo is where lo's run starts.  The tile that
-    // holds that position (the last tile when it is the end of the input) OWNS lo: it will say where the pieces (hi, lo) start.
-    __syncthreads();   // wave_total is reused
-    const int64_t q = (int64_t)block_exclusive_scan_256(totals_lo[threadIdx.x], wave_total) - base;   // thread = lo
-    const bool last = base + kTile >= n;
-    const bool own = q >= 0 && (q < kTile || (last && q <= (int64_t)n_tile));
-    if (own) s_owned[atomicAdd(&n_owned, 1u)] = threadIdx.x | ((uint32_t)q << 8);
-    stable = __syncthreads_or(own && q > 0 && q < (int64_t)n_tile) != 0;   // a boundary INSIDE the tile: order matters
-  }
-  const int64_t first = base + (int64_t)wave * kPerWave + lane;
-  uint32_t rem[kRounds], digit[kRounds], carry[kRounds], place[kRounds], live_mask = 0;
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int64_t i = first + r * 64;
-    const bool live = i < n;
-    rem[r] = live ? rem_in[i] : 0;
-    if (PASS == 1) {
-      const uint32_t v = live ? hl_in[i] : 0;
-      digit[r] = v & 0xff;
-      carry[r] = v >> 8;
-    } else {
-      digit[r] = live ? hi_in[i] : 0;
-      carry[r] = 0;
-    }
-    live_mask |= (live ? 1u : 0u) << r;
-  }
-  if (stable) {
-    rank_rounds(digit, live_mask, place, rk);
-    __syncthreads();
-    rank_place_bins(rk);
-  } else {
-    rank_any_rounds(digit, live_mask, place, rk);
-    __syncthreads();
-    rank_any_place_bins(rk);
-  }
-  g_base[threadIdx.x] = bin_base + hist[(int64_t)threadIdx.x * stride + tile];
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    if ((live_mask >> r) & 1u) {
-      const uint32_t at = rk.bin_start[digit[r]] + rk.wave_cnt[wave][digit[r]] + place[r];   // (the wave offsets are zero in any-order tiles)
-      s_rem[at] = rem[r];
-      s_dig[at] = (uint8_t)digit[r];
-      if (PASS == 1) s_hi[at] = (uint8_t)carry[r];
-      if (PASS == 2) s_orig[at] = (uint16_t)(wave * kPerWave + r * 64 + lane);
-    }
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int j = threadIdx.x; j < n_tile; j += kThreads) {
-    const uint32_t d = s_dig[j];
-    const uint64_t to = g_base[d] + (uint32_t)(j - (int)rk.bin_start[d]);
-    rem_out[to] = s_rem[j];
-    if (PASS == 1) hi_out[to] = s_hi[j];
-  }
-  if (PASS == 2) {
-    // starts[hi * 256 + lo] = index (in the pass's OUTPUT) of the first element whose piece is >= hi * 256 + lo = this tile's
-    // place in bin hi + the number of its bin-hi elements in front of tile-local position q (the ones with a smaller lo).  In
-    // a stable tile those come first inside the bin: found by their original positions.  Thread = hi.
-    const uint32_t b0 = rk.bin_start[threadIdx.x], cnt = rk.bin_count[threadIdx.x];
-    const uint64_t gb = g_base[threadIdx.x];
-    const uint32_t n_own = n_owned;
-    for (uint32_t k = 0; k < n_own; ++k) {   // (uniform over the workgroup; nearly every tile owns no boundary or one)
-      const uint32_t lo = s_owned[k] & 0xff, q = s_owned[k] >> 8;
-      uint32_t a = 0, b = cnt;                 // first place in the bin whose original position is >= q
-      if (q == 0) {
-        b = 0;
-      } else if (q >= (uint32_t)n_tile) {
-        a = cnt;
-      } else {
-        while (a < b) {
-          const uint32_t mid = (a + b) >> 1;
-          if ((uint32_t)s_orig[b0 + mid] < q) a = mid + 1; else b = mid;
-        }
-      }
-      starts[threadIdx.x * kBins + lo] = (uint32_t)(gb + a);
-    }
-    if (tile == 0 && threadIdx.x == 0) {
-      starts[kPieces] = (uint32_t)n;
-      starts[kPieces + 1] = (uint32_t)n;
-    }
-  }
-}
 
 // ---- the sort's front half without a histogram in front of the first pass ------------------------------------------------------
 // A radix pass needs every (tile, bin) offset before it can write, so the first pass above costs a round trip of the elements
@@ -490,9 +236,8 @@ __global__ __launch_bounds__(kThreads) void piece_scatter_kernel(const uint32_t*
 // tools/scatter_runs.hip).  The second pass walks the segments in chunks of 4096 -- a tile lies inside ONE lo bin, so the run
 // starts of the 65536 pieces are simply its offsets -- and is dense as before.  Points without a key and the previous lane's
 // duplicates are dropped here instead of travelling on as markers.
-// A segment that overflows (keys that crowd into few bins: not what this path is chosen for) raises a flag on the device; the
-// merge then leaves the table alone and voxel_spill_kernel inserts the whole cloud the ordinary way -- correct, slow, and
-// counted (r3d_voxelset_sort_fallbacks).
+// A segment that is full (keys that crowd into one bin: every pixel without depth of a frame is the same point) sends what it
+// cannot take to the list of deferred keys, which voxel_spill_kernel inserts the ordinary way.
 constexpr int kXcds = 8;
 constexpr int kSegments = 256 * kXcds;
 constexpr int kCursorStride = 32;   // words between two cursors: a line each
@@ -511,13 +256,11 @@ static SegPlan seg_plan(int64_t n_points) {
   return p;
 }
 
-// flags: [0] give up (see above), [2..3] points without a key (64 bits; added to the set's counter by voxel_spill_kernel when
-// the sort went through).  cursors[(lo * 8 + xcd) * kCursorStride]: elements in the segment (may exceed cap: clamp).
+// flags[2..3]: points without a key (64 bits; added to the set's counter by voxel_spill_kernel).  cursors[(lo * 8 + xcd) * kCursorStride]: elements in the segment (may exceed cap: clamp).
 // 512 threads, eight points each: the kernel waits for latencies in turn (points, LDS adds, the cursor, the stores), so it wants
 // waves -- four workgroups of eight per CU fill it (256 threads x 16 points: five of four, 20 of 32 wave slots, 272 -> ... us).
 constexpr int kBinThreads = 512;
 constexpr int kBinRounds = kSortTile / kBinThreads;
-template <int EXP>
 __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
                                                                    int n_tiles, int cap, uint32_t* __restrict__ seg_rem,
                                                                    uint8_t* __restrict__ seg_hi, uint32_t* __restrict__ cursors,
@@ -530,7 +273,6 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int xcd = blockIdx.x & (kXcds - 1);   // (workgroups go round the XCDs; nothing but locality depends on it)
   unsigned n_ignored = 0;
-  bool over = false;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {   // (gridDim.x is a multiple of 8: a workgroup stays with its cursors)
     const int64_t t0 = (int64_t)tile * kSortTile;
     const uint32_t n_tile = n - t0 < (int64_t)kSortTile ? (uint32_t)(n - t0) : (uint32_t)kSortTile;
@@ -586,9 +328,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
         if (!live) key = kEmpty;
         const uint64_t prev = prev_lane_u64(key);
         if (lane > 0 && prev == key) live = false;
-        uint64_t h = hash48(key & kMask48);
-        if (EXP == 6) { h = (uint64_t)__float_as_uint(p[r].x) ^ ((uint64_t)__float_as_uint(p[r].y) << 13) ^ ((uint64_t)__float_as_uint(p[r].z) << 27); live = true; }
-        if (EXP == 3) h = ((uint64_t)__float_as_uint(p[r].x) * 0x9E3779B1u) ^ ((uint64_t)__float_as_uint(p[r].y) << 20);
+        const uint64_t h = hash48(key & kMask48);
         if (live && h == kMask48) {   // the one key whose h48 reads as "no key" in the merge: it takes the deferred way in
           const unsigned long long at = atomicAdd(spill_count, 1ull);
           if (at < spill_cap) spill[at] = key;
@@ -598,13 +338,6 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
         dc[q * 4 + r] = (uint32_t)(h >> 32) & 0xffffu;
         live_mask |= (live ? 1u : 0u) << (q * 4 + r);
       }
-    }
-    if (EXP == 5 || EXP == 6) {
-      uint32_t acc = live_mask;
-#pragma unroll
-      for (int r = 0; r < kBinRounds; ++r) acc += rem[r] ^ dc[r];
-      if (acc == 0x12345u) seg_rem[tile] = acc;
-      continue;
     }
     if (threadIdx.x < kBins) bin_count[threadIdx.x] = 0;
     __syncthreads();   // (also: the previous tile's readers of the staging arrays are through)
@@ -619,7 +352,6 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
       inc = r3d_sort::wave_inclusive_scan(mine, lane);
       if (lane == 63) wave_sum[wave] = inc;
       // room for this tile's run of the bin: the add is on its way while the tile is staged
-      if (EXP == 2) base = (uint32_t)(tile >> 3) * 20u; else
       if (mine) base = atomicAdd(&cursors[(threadIdx.x * kXcds + xcd) * kCursorStride], mine);
     }
     __syncthreads();
@@ -638,23 +370,36 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
     }
     if (threadIdx.x < kBins) {
       s_base[threadIdx.x] = base - bin_start[threadIdx.x];   // (modulo 2^32: element j of the bin order goes to s_base[its bin] + j)
-      over |= base + mine > (uint32_t)cap;
     }
     __syncthreads();
     const int n_live = (int)(bin_start[kBins - 1] + bin_count[kBins - 1]);
+    bool full_seg = false;
 #pragma unroll 4
     for (int j = threadIdx.x; j < n_live; j += kBinThreads) {
       const uint2 el = s_el[j];
       const uint32_t d = el.y & 0xff;
       const uint32_t at = s_base[d] + (uint32_t)j;
-      if (at < (uint32_t)cap && (EXP != 1 || el.x == 0x12345u)) {
+      if (at < (uint32_t)cap) {
         const uint64_t to = (uint64_t)(d * kXcds + xcd) * (uint64_t)cap + at;
         seg_rem[to] = el.x;
-        if (EXP != 4) seg_hi[to] = (uint8_t)(el.y >> 8);
+        seg_hi[to] = (uint8_t)(el.y >> 8);
+      } else {
+        full_seg = true;
+      }
+    }
+    if (__any(full_seg)) {   // a segment is full (keys that crowd into one bin): the deferred way in, one counter add per wave and round
+      for (int j = threadIdx.x; j < n_live; j += kBinThreads) {
+        const uint2 el = s_el[j];
+        if (s_base[el.y & 0xff] + (uint32_t)j < (uint32_t)cap) continue;
+        const unsigned long long peers = __ballot(1);
+        const int leader = (int)__ffsll((long long)peers) - 1;
+        unsigned long long first = 0;
+        if (lane == leader) first = atomicAdd(spill_count, (unsigned long long)__popcll(peers));
+        first = __shfl(first, leader, 64) + __popcll(peers & ((1ull << lane) - 1));
+        if (first < spill_cap) spill[first] = unhash48(((uint64_t)(el.y & 0xffffu) << 32) | el.x);   // el.y = lo | hi << 8: h48's top 16 bits
       }
     }
   }
-  if (over) flags[0] = 1;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
   if (lane == 0 && n_ignored) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)n_ignored);
@@ -822,8 +567,7 @@ __global__ __launch_bounds__(kThreads) void voxel_merge_kernel(const uint32_t* _
                                                                uint32_t n_regions, int sub_log2_arg, uint64_t* __restrict__ table, int log2cap,
                                                                uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
                                                                unsigned long long spill_cap, int pristine,
-                                                               unsigned long long* __restrict__ partials, const uint32_t* __restrict__ gave_up) {
-  if (*gave_up) return;   // (uniform) the segmented sort raised its flag: voxel_spill_kernel inserts the cloud instead
+                                                               unsigned long long* __restrict__ partials) {
   const int sub_log2 = SUB ? sub_log2_arg : 0;
   constexpr int kSlots = 1 << REGION_LOG2;
   constexpr int kAhead = 4;    // elements per thread fetched one region ahead (1024 per region: a 2048-slot region holds ~750 at load 0.36)
@@ -1020,13 +764,11 @@ template <int REGION_LOG2, bool PRISTINE>
 __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
                                                                  uint32_t n_regions, uint64_t* __restrict__ table,
                                                                  uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
-                                                                 unsigned long long spill_cap, unsigned long long* __restrict__ partials,
-                                                                 const uint32_t* __restrict__ gave_up) {
+                                                                 unsigned long long spill_cap, unsigned long long* __restrict__ partials) {
   constexpr int kSlots = 1 << REGION_LOG2;
   constexpr int kAhead = 4;
   constexpr int kBatch = 128;
   constexpr int kPairs = kSlots / 2 / kThreads;   // slot pairs per thread
-  if (*gave_up) return;   // (uniform) see voxel_merge_kernel
   constexpr uint32_t kFree = 0xffffffffu, kForeign = 0xfffffffeu;
   __shared__ unsigned wg_count[2];
   if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;
@@ -1187,58 +929,43 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
   if (threadIdx.x < 2) partials[2 * (uint64_t)blockIdx.x + threadIdx.x] = wg_count[threadIdx.x];
 }
 
-// the deferred keys, by the ordinary CAS (their count is known on the device only: fixed grid, device-side bound)
+// the deferred keys, by the ordinary CAS (their count is known on the device only: fixed grid, device-side bound).  The list may
+// hold one key very many times (the points a first-pass segment had no room for: e.g. every pixel without depth of a frame is
+// the same point): a probe LOOKS before it swaps, so that those end as reads of a cached line instead of queueing at one address.
 __global__ __launch_bounds__(kThreads) void voxel_spill_kernel(const uint64_t* __restrict__ spill, const unsigned long long* __restrict__ spill_count,
                                                                unsigned long long spill_cap, uint64_t* __restrict__ table, int log2cap,
                                                                unsigned long long* __restrict__ counters,
                                                                const unsigned long long* __restrict__ partials, int n_partials,
-                                                               uint32_t* __restrict__ flags, const float* __restrict__ xyz, int64_t n_points,
-                                                               double factor) {
+                                                               const uint32_t* __restrict__ flags) {
   const uint64_t mask = ((uint64_t)1 << log2cap) - 1;
   unsigned long long n_new = 0, n_over = 0;
-  if (flags[0]) {   // (uniform) the segmented sort gave up (voxel_bin_kernel): nothing has reached the table -- every point the ordinary way
-    unsigned long long n_ignored = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kThreads) {
-      const P3 p = reinterpret_cast<const P3*>(xyz)[i];
-      uint64_t key;
-      if (!r3d_vox::voxel_key(p.x, p.y, p.z, factor, &key)) {
-        ++n_ignored;
-        continue;
-      }
-      const int r = table_insert(table, mask, log2cap, key);
-      n_new += r > 0 ? 1u : 0u;
-      n_over += r < 0 ? 1u : 0u;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      n_new += __shfl_down(n_new, off, 64);
-      n_over += __shfl_down(n_over, off, 64);
-      n_ignored += __shfl_down(n_ignored, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      if (n_new) atomicAdd(&counters[0], n_new);
-      if (n_ignored) atomicAdd(&counters[1], n_ignored);
-      if (n_over) atomicAdd(&counters[2], n_over);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[4], 1ull);   // how often that happened (r3d_voxelset_sort_fallbacks)
-    return;
-  }
   unsigned long long n = *spill_count;
   if (n > spill_cap) n = spill_cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the points the key kernel found no key for
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the points the first pass found no key for
     const unsigned long long ign = *reinterpret_cast<const unsigned long long*>(flags + 2);
     if (ign) atomicAdd(&counters[1], ign);
   }
   for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kThreads) {
-    const int r = table_insert(table, mask, log2cap, spill[i]);
+    const uint64_t key = spill[i];
+    uint64_t slot = r3d_vox::home_slot(key, log2cap);
+    int r = -1;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+      uint64_t old = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == kEmpty) old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]), (unsigned long long)kEmpty, (unsigned long long)key);
+      if (old == kEmpty) { r = 1; break; }
+      if (old == key) { r = 0; break; }
+      slot = (slot + 1) & mask;
+    }
     n_new += r > 0 ? 1u : 0u;
     n_over += r < 0 ? 1u : 0u;
   }
-  if (blockIdx.x == 0)   // ... and the merge launches' per-workgroup counts (pairs: new, no slot)
-    for (int k = threadIdx.x; k < n_partials; k += kThreads) {
-      n_new += partials[2 * k];
-      n_over += partials[2 * k + 1];
-    }
+  // ... and the merge launch's per-workgroup counts (pairs: new, no slot), a pair per thread over the whole grid (one block
+  // walking 2048 pairs was sixteen dependent round trips: 10 of this kernel's 15 us)
+  for (int k = blockIdx.x * kThreads + threadIdx.x; k < n_partials; k += gridDim.x * kThreads) {
+    const ulonglong2 pr = reinterpret_cast<const ulonglong2*>(partials)[k];
+    n_new += pr.x;
+    n_over += pr.y;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     n_new += __shfl_down(n_new, off, 64);
@@ -1583,9 +1310,9 @@ int r3d_voxelset_create(r3d_ctx* ctx, double resolution, int64_t capacity, r3d_v
   while (((int64_t)1 << vs->log2cap) < capacity && vs->log2cap < 40) ++vs->log2cap;
   vs->capacity = (uint64_t)1 << vs->log2cap;
   hipError_t e = hipMalloc((void**)&vs->d_table, vs->capacity * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&vs->d_counters, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&vs->d_counters, 4 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(vs->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream);
   if (e != hipSuccess) {
     r3d_voxelset_destroy(vs);
     return r3d_fail_hip(e, "voxel set allocation", __FILE__, __LINE__);
@@ -1609,7 +1336,7 @@ int r3d_voxelset_clear(r3d_voxelset* vs) {
   int rc = r3d_ctx_enter(vs->ctx);
   if (rc) return rc;
   R3D_HIP(hipMemsetAsync(vs->d_table, 0xff, vs->capacity * sizeof(uint64_t), vs->ctx->stream));
-  R3D_HIP(hipMemsetAsync(vs->d_counters, 0, 8 * sizeof(unsigned long long), vs->ctx->stream));
+  R3D_HIP(hipMemsetAsync(vs->d_counters, 0, 4 * sizeof(unsigned long long), vs->ctx->stream));
   vs->pristine = true;
   return R3D_OK;
 }
@@ -1623,8 +1350,8 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
   R3D_REQUIRE(d_xyz != nullptr, "NULL device pointer");
   // big inserts: a sample of the cloud decides between the two paths ("voxel_path": 1 / 2 force one)
   int path = 1;
-  if ((vs->ctx->voxel_path == 2 || vs->ctx->voxel_path == 3) && r3d_voxelset_sort_feasible(vs, n_points, true)) {
-    path = vs->ctx->voxel_path;
+  if (vs->ctx->voxel_path == 2 && r3d_voxelset_sort_feasible(vs, n_points, true)) {
+    path = 2;
   } else if (vs->ctx->voxel_path == 0 && r3d_voxelset_sort_feasible(vs, n_points, false)) {
     bool sort = false;
     if ((rc = r3d_voxelset_sample(vs, d_xyz, n_points, &sort))) return rc;
@@ -1666,7 +1393,7 @@ int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, 
   return R3D_OK;
 }
 
-static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, bool segmented) {
+static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) {
   r3d_ctx* ctx = vs->ctx;
   const int region_log2 = std::max(kRegionMinLog2, vs->log2cap - kPieceBits);   // slots per LDS region
   const int sub_log2 = kPieceBits - (vs->log2cap - region_log2);                // pieces per region (log2)
@@ -1680,75 +1407,53 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
     const uint64_t spill_cap = (uint64_t)m;   // every key may be deferred (a nearly full table): the list can take them all
     const SegPlan plan = seg_plan(m);
     const int64_t n_tiles1 = (m + kSortTile - 1) / kSortTile;   // the first pass's tiles
-    const int64_t n_tiles64 = segmented ? (int64_t)plan.n_tiles2 : n_tiles1;
-    const int n_tiles = (int)n_tiles64, stride = r3d_sort_stride(n_tiles);
+    const int n_tiles = plan.n_tiles2, stride = r3d_sort_stride(n_tiles);   // the second pass's tiles
     const size_t seg_elems = (size_t)kSegments * plan.cap;
     void *a_v = nullptr, *b_v = nullptr, *ws = nullptr;
-    if ((rc = r3d_scratch(ctx, 1, up((size_t)m * 4) + up((size_t)m * 2), &a_v))) return rc;   // rem | hl (the old front), later the sorted rem
-    if ((rc = r3d_scratch(ctx, 2, segmented ? up(seg_elems * 4) + up(seg_elems) : up((size_t)m * 4) + up((size_t)m), &b_v))) return rc;   // the first pass's output: rem | hi
+    if ((rc = r3d_scratch(ctx, 1, up((size_t)m * 4), &a_v))) return rc;   // the remainders in piece order
+    if ((rc = r3d_scratch(ctx, 2, up(seg_elems * 4) + up(seg_elems), &b_v))) return rc;   // the first pass's segments: rem | hi
     uint32_t* rem_a = static_cast<uint32_t*>(a_v);
-    uint16_t* hl_a = reinterpret_cast<uint16_t*>(static_cast<char*>(a_v) + up((size_t)m * 4));
     uint32_t* rem_b = static_cast<uint32_t*>(b_v);
-    uint8_t* hi_b = reinterpret_cast<uint8_t*>(static_cast<char*>(b_v) + up(segmented ? seg_elems * 4 : (size_t)m * 4));
+    uint8_t* hi_b = reinterpret_cast<uint8_t*>(static_cast<char*>(b_v) + up(seg_elems * 4));
     const unsigned merge_grid = (unsigned)ctx->num_cus * 8;   // (1536 .. 4096 workgroups measured within 3 % of each other)
     const size_t partial_bytes = up((size_t)merge_grid * 2 * sizeof(unsigned long long));
     const size_t starts_bytes = up(((size_t)kPieces + 2) * sizeof(uint32_t));
     const size_t hist_bytes = up((size_t)256 * stride * sizeof(uint32_t));
     const size_t count_bytes = up((size_t)kSegments * kCursorStride * sizeof(uint32_t));   // the segments' cursors, a line each
-    if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + count_bytes + spill_cap * 8, &ws))) return rc;
+    if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + hist_bytes + 1024 + count_bytes + spill_cap * 8, &ws))) return rc;
     char* w = static_cast<char*>(ws);
     unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(w + 32);
-    uint32_t* d_flags = reinterpret_cast<uint32_t*>(w + 64);   // [0] the segmented sort gave up, [2..3] points without a key
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(w + 64);   // [2..3] points without a key
     unsigned long long* d_partials = reinterpret_cast<unsigned long long*>(w + 256);
     uint32_t* d_starts = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes);
-    uint32_t* hist_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes);
-    uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes);
-    uint32_t* totals_lo = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes);
-    uint32_t* totals_hi = totals_lo + 256;
-    uint32_t* d_cursors = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024);
-    uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + 2 * hist_bytes + 2 * 1024 + count_bytes);
+    uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes);
+    uint32_t* totals_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes);
+    uint32_t* d_cursors = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes + 1024);
+    uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes + 1024 + count_bytes);
     R3D_HIP(hipMemsetAsync(w + 32, 0, 64, ctx->stream));   // the deferred keys' count and the flags
     // |x| < safe_abs  =>  |factor x| < 32767: every key in range whatever the rounding of the fp64 product (a bound strictly
     // inside the map's edge 32768 / factor, rounded towards zero and shrunk by 2^-20 on top)
     const float safe_abs = nextafterf((float)((32767.0 / vs->factor) * (1.0 - 1.0 / 1048576.0)), 0.0f);
-    if (segmented) {
-      R3D_HIP(hipMemsetAsync(d_cursors, 0, count_bytes, ctx->stream));
-      const unsigned bin_grid = (unsigned)((n_tiles1 + 7) / 8 * 8);   // a tile each (a multiple of 8: see the kernel)
-#define R3D_BIN(E) hipLaunchKernelGGL(voxel_bin_kernel<E>, dim3(bin_grid), dim3(kBinThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, (int)n_tiles1, \
-                         plan.cap, rem_b, hi_b, d_cursors, d_spill, d_spill_count, (unsigned long long)spill_cap, d_flags)
-      switch (ctx->voxel_dedupe >= 10 ? ctx->voxel_dedupe - 10 : 0) { case 1: R3D_BIN(1); break; case 2: R3D_BIN(2); break; case 3: R3D_BIN(3); break; case 4: R3D_BIN(4); break; case 5: R3D_BIN(5); break; case 6: R3D_BIN(6); break; default: R3D_BIN(0); }
-#undef R3D_BIN
-      hipLaunchKernelGGL(segment_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b,
-                         (const uint32_t*)d_cursors, plan.cap, plan.chunks, n_tiles, hist_hi, stride);
-      r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
-      hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)n_tiles), dim3(kBinThreads), 0, ctx->stream, (const uint32_t*)rem_b,
-                         (const uint8_t*)hi_b, (const uint32_t*)d_cursors, plan.cap, plan.chunks, (const uint32_t*)hist_hi, stride,
-                         (const uint32_t*)totals_hi, rem_a, d_starts);
-    } else {
-      hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, rem_a, hl_a, hist_lo,
-                         stride, d_spill, d_spill_count, (unsigned long long)spill_cap, vs->d_counters);
-      r3d_sort_launch_scan(ctx, hist_lo, n_tiles, stride, totals_lo);
-      hipLaunchKernelGGL(piece_scatter_kernel<1>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
-                         (const uint16_t*)hl_a, (const uint8_t*)nullptr, m, (const uint32_t*)hist_lo, stride, (const uint32_t*)totals_lo,
-                         (const uint32_t*)nullptr, rem_b, hi_b, (uint32_t*)nullptr);
-      hipLaunchKernelGGL(byte_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b, m, n_tiles,
-                         hist_hi, stride);
-      r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
-      hipLaunchKernelGGL(piece_scatter_kernel<2>, dim3((unsigned)n_tiles), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_b,
-                         (const uint16_t*)nullptr, (const uint8_t*)hi_b, m, (const uint32_t*)hist_hi, stride, (const uint32_t*)totals_hi,
-                         (const uint32_t*)totals_lo, rem_a, (uint8_t*)nullptr, d_starts);
-    }
+    R3D_HIP(hipMemsetAsync(d_cursors, 0, count_bytes, ctx->stream));
+    const unsigned bin_grid = (unsigned)((n_tiles1 + 7) / 8 * 8);   // a tile each (a multiple of 8: see the kernel)
+    hipLaunchKernelGGL(voxel_bin_kernel, dim3(bin_grid), dim3(kBinThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, (int)n_tiles1,
+                       plan.cap, rem_b, hi_b, d_cursors, d_spill, d_spill_count, (unsigned long long)spill_cap, d_flags);
+    hipLaunchKernelGGL(segment_histogram_kernel, dim3((unsigned)((n_tiles + 7) / 8)), dim3(kThreads), 0, ctx->stream, (const uint8_t*)hi_b,
+                       (const uint32_t*)d_cursors, plan.cap, plan.chunks, n_tiles, hist_hi, stride);
+    r3d_sort_launch_scan(ctx, hist_hi, n_tiles, stride, totals_hi);
+    hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)n_tiles), dim3(kBinThreads), 0, ctx->stream, (const uint32_t*)rem_b,
+                       (const uint8_t*)hi_b, (const uint32_t*)d_cursors, plan.cap, plan.chunks, (const uint32_t*)hist_hi, stride,
+                       (const uint32_t*)totals_hi, rem_a, d_starts);
     const int pristine = vs->pristine ? 1 : 0;
     vs->pristine = false;
     const unsigned merge_blocks = std::min<uint32_t>(n_regions, merge_grid);   // persistent workgroups: the loop inside is a pipeline
 #define R3D_LAUNCH_MERGE(L2, SUB)                                                                                                       \
   hipLaunchKernelGGL((voxel_merge_kernel<L2, SUB>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,         \
                      (const uint32_t*)d_starts, n_regions, sub_log2, vs->d_table, vs->log2cap, d_spill, d_spill_count,                  \
-                     (unsigned long long)spill_cap, pristine, d_partials, (const uint32_t*)d_flags)
+                     (unsigned long long)spill_cap, pristine, d_partials)
 #define R3D_LAUNCH_MERGE32(L2, PR)                                                                                                      \
   hipLaunchKernelGGL((voxel_merge32_kernel<L2, PR>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,        \
-                     (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials, \
-                     (const uint32_t*)d_flags)
+                     (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials)
     const bool narrow = sub_log2 == 0;   // regions are pieces: 32-bit slots in LDS (same-process A/B against the 64-bit form: 385-397 -> 359-362 us)
     if (narrow && region_log2 == 11) { if (pristine) R3D_LAUNCH_MERGE32(11, true); else R3D_LAUNCH_MERGE32(11, false); }
     else if (narrow && region_log2 == 12) { if (pristine) R3D_LAUNCH_MERGE32(12, true); else R3D_LAUNCH_MERGE32(12, false); }
@@ -1761,7 +1466,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
 #undef R3D_LAUNCH_MERGE32
     hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
                        (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters,
-                       (const unsigned long long*)d_partials, (int)merge_blocks, d_flags, src, m, vs->factor);
+                       (const unsigned long long*)d_partials, (int)merge_blocks, (const uint32_t*)d_flags);
     R3D_HIP(hipGetLastError());
   }
   return R3D_OK;
@@ -1771,7 +1476,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points,
 int r3d_voxelset_insert_path(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int path) {
   if (n_points <= 0) return R3D_OK;
   vs->ctx->voxel_last_path = path;
-  if (path == 2 || path == 3) return insert_sorted(vs, d_xyz, n_points, path == 2);   // (3: round 5's dense first pass, while both are compared)
+  if (path == 2) return insert_sorted(vs, d_xyz, n_points);
   vs->pristine = false;
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
   int blocks = vs->ctx->num_cus * 8;
@@ -1816,17 +1521,6 @@ int r3d_voxelset_stats(r3d_voxelset* vs, int64_t* n_voxels, int64_t* n_ignored, 
   if (n_voxels) *n_voxels = (int64_t)c[0];
   if (n_ignored) *n_ignored = (int64_t)c[1];
   if (n_overflow) *n_overflow = (int64_t)c[2];
-  return R3D_OK;
-}
-
-int r3d_voxelset_sort_fallbacks(r3d_voxelset* vs, int64_t* n_out) {
-  R3D_REQUIRE(vs != nullptr && n_out != nullptr, "NULL argument");
-  int rc = r3d_ctx_enter(vs->ctx);
-  if (rc) return rc;
-  unsigned long long c = 0;
-  R3D_HIP(hipMemcpyAsync(&c, vs->d_counters + 4, sizeof(c), hipMemcpyDeviceToHost, vs->ctx->stream));
-  R3D_HIP(hipStreamSynchronize(vs->ctx->stream));
-  *n_out = (int64_t)c;
   return R3D_OK;
 }
 

@@ -75,12 +75,6 @@ class VoxelSet:
         L.check(self.ctx.lib.r3d_voxelset_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
         return {"voxels": a.value, "ignored_points": b.value, "overflow": c.value}
 
-    def sort_fallbacks(self):
-        """Sort-merge inserts of this set that gave up on their first pass and went through the compare-and-swap path."""
-        n = C.c_int64()
-        L.check(self.ctx.lib.r3d_voxelset_sort_fallbacks(self.handle, C.byref(n)))
-        return n.value
-
     def codes(self):
         """Ascending unique Morton codes (uint64) of the occupied voxels."""
         n = C.c_int64()

@@ -20,10 +20,6 @@ extern "C" {
  * pixel -> (row, column) and tile -> (frame, tile) splits.  d >= 1, x < 2^31. */
 int r3d_selftest_magic_div(uint32_t d, uint32_t x, uint32_t* q_out);
 
-/* How many of the set's sort-merge inserts (r3d_voxelset_insert on a cloud whose points mostly have voxels of their own) found
- * their first pass's segments too small -- a group of points crowding into few voxels -- and inserted the cloud through the
- * ordinary compare-and-swap path instead (same set, slower): csrc/r3d_voxel.hip, voxel_bin_kernel.  Synchronises the stream. */
-int r3d_voxelset_sort_fallbacks(r3d_voxelset* vs, int64_t* n_out);
 
 /* The same with the matrix in HBM (16 doubles, row-major; e.g. the step a device-side ICP solve just wrote). */
 int r3d_apply_T_dev(r3d_ctx* ctx, const void* d_xyz_in, int in_dtype, int64_t n_points, const double* d_T,

@@ -467,7 +467,7 @@ def test_fused_cloud_and_voxels_any_run_length(V, ctx, blocks):
     assert st["voxels"] > 50_000 and st["overflow"] == 0
 
 
-# ---- the sort-merge insert (path 2): region-tagged keys, two radix passes, table regions updated in LDS ---------------------
+# ---- the sort-merge insert (path 2): keys into per-XCD bin segments, a second pass by piece, table regions updated in LDS -----
 
 @pytest.mark.parametrize("n,log2cap,spread", [(1, 16, 1.0), (1000, 16, 3.0), (4097, 17, 8.0), (300_000, 20, 40.0), (300_000, 19, 40.0),
                                                (1_000_000, 21, 60.0), (2_000_003, 22, 25.0), (3_000_000, 29, 80.0)])
@@ -546,6 +546,55 @@ def test_sort_merge_into_a_crowded_2_27_slot_table_agrees_with_the_cas_path(V, c
         ctx.set_tuning("voxel_path", 0)
         a.close()
         b.close()
+        d_xyz.free()
+
+
+@pytest.mark.parametrize("kind", ["eight_voxels", "hot_point", "one_bin_heavy", "tiny"])
+def test_sort_merge_first_pass_segments_that_fill_up(V, ctx, kind):
+    """The first pass writes into per-XCD bin segments sized for hashed keys (1.25 x the mean + 1024): keys that crowd into a
+    bin must go in through the deferred list instead.  eight_voxels: 2 M points alternating between eight voxels (the
+    neighbour-lane test removes nothing; every segment in use overflows many times over); hot_point: a cloud of distinct
+    voxels with a fifth of its points at ONE place, scattered (pixels without depth end at the camera centre); one_bin_heavy:
+    distinct voxels chosen so that a third of them share h48's lo byte; tiny: fewer points than there are segments."""
+    rng = np.random.default_rng(len(kind))
+    if kind == "eight_voxels":
+        n = 2_000_000
+        pts = np.zeros((n, 3), np.float32)
+        pts[:, 0] = (np.arange(n) % 8) * 0.1 + 0.05
+        pts[:, 1] = ((np.arange(n) // 8) % 2) * 0.1 + 0.05          # (16 voxels in fact: 8 x 2)
+    elif kind == "hot_point":
+        n = 3_000_000
+        pts = (rng.normal(size=(n, 3)) * 60).astype(np.float32)
+        pts[rng.random(n) < 0.2] = (1.234, -5.678, 9.1)
+    elif kind == "one_bin_heavy":
+        n = 1_500_000
+        cand = (rng.normal(size=(6 * n, 3)) * 60).astype(np.float32)
+        k = np.floor(cand.astype(np.float64) * 10.0).astype(np.int64) + 32768
+        ok = ((k >= 0) & (k < 65536)).all(1)
+        key = (k[:, 0] | (k[:, 1] << 16) | (k[:, 2] << 32)).astype(np.uint64)
+        h = (key * np.uint64(0x9E3779B97F4B)) & np.uint64((1 << 48) - 1)            # r3d_voxel_dev.h: hash48
+        lo = ((h >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64)
+        heavy = np.flatnonzero(ok & (lo == 77))[: n // 3]
+        rest = np.flatnonzero(ok & (lo != 77))[: n - heavy.shape[0]]
+        pts = cand[rng.permutation(np.concatenate([heavy, rest]))]
+        n = pts.shape[0]
+    else:
+        n = 1500
+        pts = (rng.normal(size=(n, 3)) * 9).astype(np.float32)
+    want, dropped = OM.occupied_set(pts)
+    d_xyz = ctx.alloc(n * 12).upload(pts)
+    vs = V.VoxelSet(0.1, 1 << 23, ctx)
+    try:
+        ctx.set_tuning("voxel_path", 2)
+        vs.insert_device(d_xyz.ptr, n)
+        assert ctx.get_tuning("voxel_last_path") == 2
+        assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}, (vs.stats(), len(want), dropped)
+        np.testing.assert_array_equal(vs.codes(), want)
+        vs.insert_device(d_xyz.ptr, n)                      # again, into the table that now holds them all
+        assert vs.stats()["voxels"] == len(want)
+    finally:
+        ctx.set_tuning("voxel_path", 0)
+        vs.close()
         d_xyz.free()
 
 
