@@ -1,6 +1,7 @@
-// Device-side pieces of the 8-bit-digit radix passes shared by r3d_sort.hip (64-bit keys) and r3d_voxel.hip (the sort-merge
-// insert's 4-byte words): how a workgroup ranks its tile of 4096 elements by one digit without a barrier per round, and where
-// each bin of the tile then sits.  See digit_scatter_kernel (r3d_sort.hip) for the measurements behind the shape.
+// Device-side pieces of the 8-bit-digit radix passes: how a workgroup ranks its tile of 4096 elements by one digit, stably and
+// without a barrier per round, and where each bin of the tile then sits (r3d_sort.hip, 64-bit keys); the blockIdx -> tile map and
+// the wave scan are shared with the sort-merge insert's passes (r3d_voxel.hip), whose order inside a bin is free -- they rank with
+// one returning LDS add per element instead.  See digit_scatter_kernel (r3d_sort.hip) for the measurements behind the shape.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,33 +42,11 @@ __device__ __forceinline__ int xcd_contiguous(unsigned b, unsigned g) {
   return (int)(x * q + (x < r ? x : r) + j);
 }
 
-// Every thread zeroes its column of the counters; a barrier must follow before rank_rounds / rank_any_rounds.
+// Every thread zeroes its column of the counters; a barrier must follow before rank_rounds.
 __device__ __forceinline__ void rank_reset(RankShared& sh) {
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) sh.wave_cnt[w][threadIdx.x] = 0;
   sh.bin_count[threadIdx.x] = 0;
-}
-
-// ANY-ORDER ranking, for passes whose output order inside a bin is free (the first pass of an LSD sort; tiles whose elements
-// are equal in everything sorted so far): place[r] = the element's arrival number in its bin OF THE TILE, one returning LDS add
-// per element -- ~700 instructions per thread and tile where the stable ranking takes ~2600.  That matters once a pass moves
-// few bytes per element: the stable ranking of 49 M elements is ~200 us of VALU issue on 1024 SIMDs, whatever the bytes.
-// After a barrier rank_any_place_bins gives bin_start / bin_count (one barrier inside, one must follow); the element of digit
-// d then goes to bin_start[d] + place[r] -- the same expression as the stable form's, whose wave offsets stay zero here.
-__device__ __forceinline__ void rank_any_rounds(const uint32_t (&digit)[kRounds], uint32_t live_mask, uint32_t (&place)[kRounds], RankShared& sh) {
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) place[r] = ((live_mask >> r) & 1u) ? atomicAdd(&sh.bin_count[digit[r] & 0xff], 1u) : 0u;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void rank_any_place_bins(RankShared& sh) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t tot = sh.bin_count[threadIdx.x];
-  const uint32_t inc = wave_inclusive_scan(tot, lane);
-  if (lane == 63) sh.wave_sum[wave] = inc;
-  __syncthreads();
-  uint32_t start = inc - tot;
-  for (int w = 0; w < wave; ++w) start += sh.wave_sum[w];
-  sh.bin_start[threadIdx.x] = start;
 }
 
 // place[r] = rank of the lane's round-r element among the elements OF ITS WAVE'S QUARTER that have the same digit (input

@@ -886,6 +886,8 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
         for (int k = 0; k < kPairs; ++k) {
           const uint2 v = reinterpret_cast<const uint2*>(region)[k * kThreads + threadIdx.x];
           ulonglong2 out;
+          // (rebuilding the keys with the piece's share of the product taken out of the loop and only the partial products that
+          // reach the low 48 bits -- two 32-bit multiplies and a 24-bit one -- changed nothing: same-process A/B)
           out.x = v.x == kFree ? kEmpty : unhash48(((uint64_t)r << 32) | v.x);
           out.y = v.y == kFree ? kEmpty : unhash48(((uint64_t)r << 32) | v.y);
           if (!PRISTINE) {

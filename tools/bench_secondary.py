@@ -230,10 +230,10 @@ def secondary(a):
                 "table_slots": 1 << int(np.ceil(np.log2(2 * n))),
                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
-                             "kernel": "voxel_keys_kernel + piece_scatter_kernel<1> + byte_histogram_kernel + piece_scatter_kernel<2> + "
-                                       "voxel_merge_kernel (sort-merge insert: 18 + 11 + 1 + 9 + 4 B/point of streams + 8 B per table slot; "
+                             "kernel": "voxel_bin_kernel + segment_histogram_kernel + segment_scatter_kernel + voxel_merge32_kernel "
+                                       "(sort-merge insert: 17 + 1 + 9 + 4 B/point of streams + 8 B per table slot; "
                                        "the CAS path is bound by scattered 64-bit atomics at ~19 G/s instead)",
-                             "designed_bytes_per_launch": n * 43 + (1 << int(np.ceil(np.log2(2 * n)))) * 8}}
+                             "designed_bytes_per_launch": n * 31 + (1 << int(np.ceil(np.log2(2 * n)))) * 8}}
     line.setdefault("higher_is_better", True)
     line.update({"n_gpus": 1, "data": "synthetic", "dtype": "f64" if a.workload in ("apply", "c5") else "f32",
                  "config": {"workload": a.workload}})

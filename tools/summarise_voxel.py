@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "voxel_" + rnd)
 N = 100 * 384 * 1280
-DESIGNED = {"voxel_keys_kernel": 18 * N, "piece_scatter_kernel<1>": 11 * N, "byte_histogram_kernel": 1 * N, "piece_scatter_kernel<2>": 9 * N,
-            "voxel_merge": 4 * N + (1 << 27) * 8, "digit_scan_kernel": 2 * 12e6, "voxel_spill_kernel": 0}
+DESIGNED = {"voxel_bin_kernel": 17 * N, "segment_histogram_kernel": 1 * N, "segment_scatter_kernel": 9 * N,
+            "voxel_merge": 4 * N + (1 << 27) * 8, "digit_scan_kernel": 2 * 16.8e6, "voxel_spill_kernel": 0}
 
 
 def newest(pattern):
@@ -63,10 +63,15 @@ voxels = int(re.search(r"(\d+) voxels", line).group(1))
 alg = 12 * N + 8 * voxels
 out = {"round": rnd, "what": "sort-merge insert of C2's worst-case cloud (49,152,000 points -> %d voxels, 2^27-slot table), tools/voxel_sort_once.py" % voxels,
        "stages": stages, "sum_of_stage_medians_us": round(total_us, 1), "hbm_bytes_per_insert": total_bytes,
-       "algorithmic_bytes": alg, "traffic_over_algorithmic": round(total_bytes / alg, 3), "designed_bytes_per_point": 64.8,
+       "algorithmic_bytes": alg, "traffic_over_algorithmic": round(total_bytes / alg, 3), "designed_bytes_per_point": 52.8,
        "unprofiled_ms_per_insert": ms, "unprofiled_median_ms": statistics.median(ms),
        "frac_of_hbm_peak": round(alg / (statistics.median(ms) * 1e-3) / 8e12, 4),
        "cas_path_same_cloud": open(os.path.join(src, "unprofiled_cas.log")).read().strip().splitlines()[-1],
+       "round5_first_form": {"what": "key kernel + dense first pass behind its histogram (voxel_keys_kernel, piece_scatter_kernel<1|2>, byte_histogram_kernel)",
+                             "ms": "0.87-0.97", "traffic_over_algorithmic": 3.519, "bytes_per_point": 64.8, "hbm_bytes_per_insert": 3435142992,
+                             "stage_medians_us": {"voxel_keys_kernel": 208.2, "piece_scatter_kernel<1>": 164.4, "byte_histogram_kernel": 20.9,
+                                                  "piece_scatter_kernel<2>": 141.5, "voxel_merge": 359.1, "digit_scan_kernel x2": 21.2, "voxel_spill_kernel": 15.4},
+                             "same_process_ab": "tools/voxel_front_ab.py at the commits in between: 0.94-0.96 ms (this form) vs 0.74 / 0.70 ms"},
        "round4": {"ms": "1.09-1.20", "traffic_over_algorithmic": 4.8, "bytes_per_point": 97.8, "source": "profiles/r04_voxel_sort_merge_stages.txt"}}
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_voxel_stage_pmc.json" % rnd), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("sum_of_stage_medians_us", "traffic_over_algorithmic", "unprofiled_median_ms", "frac_of_hbm_peak")}))
