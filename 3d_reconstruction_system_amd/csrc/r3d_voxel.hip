@@ -100,7 +100,11 @@ __global__ __launch_bounds__(kThreads) void voxel_insert_kernel(const float* __r
     }
   };
   unsigned total = 0, j = 0;  // codes in the set (same value in every thread), tiles done by this workgroup
-  P3 pn[4];                   // the next tile's points, in flight
+  // the next tile's points, in flight.  (Round 5: as nontemporal loads -- a 3-float vector type of 4-byte alignment, so that the
+  // compiler still tracks them -- 223 vs 223 and 231 vs 214 Gpoints/s on scans, same process: within the noise, not kept.  Inline-asm
+  // loads whose wait is a second asm statement further down are not an option at all: the compiler copies and re-uses their
+  // destination registers in between, and a load that lands in what has become an address register is a memory fault.)
+  P3 pn[4];
   if (tile_lo < tile_hi) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
