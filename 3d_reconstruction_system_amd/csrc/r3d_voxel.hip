@@ -935,6 +935,168 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
   if (threadIdx.x < 2) partials[2 * (uint64_t)blockIdx.x + threadIdx.x] = wg_count[threadIdx.x];
 }
 
+// The merge into a table of 2^27 slots with a piece per WAVE instead of per workgroup: no barrier anywhere in the loop (the LDS
+// serves a wave's operations in the order it issued them), four independent pieces in flight per workgroup and twenty per CU, the
+// next piece's bounds and remainders requested a piece ahead.  The workgroup form above spends a third of its time on the loop's
+// skeleton -- three barriers per piece, each waiting for the slowest of four waves' probe chains: 303-330 -> 250-275 us, same process.
+// PRISTINE = false: the piece's slots come in from the table first; a slot that holds a key of ANOTHER piece (kForeign) is read
+// again on the way out -- rare, so nothing is kept in registers for it.
+template <int REGION_LOG2, bool PRISTINE>
+__global__ __launch_bounds__(kThreads) void voxel_merge32w_kernel(const uint32_t* __restrict__ rems, const uint32_t* __restrict__ starts,
+                                                                  uint32_t n_regions, uint64_t* __restrict__ table,
+                                                                  uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                                  unsigned long long spill_cap, unsigned long long* __restrict__ partials) {
+  constexpr int kSlots = 1 << REGION_LOG2;
+  constexpr int kWavesPerWg = kThreads / 64;
+  constexpr int kAhead = 12;                    // remainders per lane requested ahead: 768 per piece (mean 737 at 2.73 slots per point)
+  constexpr int kPairs = kSlots / 2 / 64;       // slot pairs per lane
+  constexpr uint32_t kFree = 0xffffffffu, kForeign = 0xfffffffeu;
+  __shared__ __attribute__((aligned(16))) uint32_t region_all[kWavesPerWg][kSlots];   // 32 KB exactly: five workgroups per CU
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* region = region_all[wave];
+  const uint32_t n_waves = gridDim.x * kWavesPerWg;
+  unsigned n_new = 0, n_over = 0;
+  auto defer = [&](uint64_t key) {
+    const unsigned long long at = atomicAdd(spill_count, 1ull);
+    if (at < spill_cap) spill[at] = key; else ++n_over;
+  };
+  auto probe_on = [&](uint32_t piece, uint32_t rem, uint32_t s, uint32_t old) {
+    for (;;) {
+      if (old == kFree) {
+        ++n_new;
+        return;
+      }
+      if (old == rem) return;
+      if (++s >= (uint32_t)kSlots) break;
+      old = atomicCAS(&region[s], kFree, rem);
+    }
+    defer(unhash48(((uint64_t)piece << 32) | rem));   // every slot from home to the piece's end is taken: the probe goes on later
+  };
+  auto usable = [&](uint32_t r, uint32_t rem) -> bool {
+    if (rem < kForeign) return true;
+    if (!(r == kPieces - 1 && rem == kFree)) defer(unhash48(((uint64_t)r << 32) | rem));
+    return false;
+  };
+  auto fetch = [&](uint32_t lo_, uint32_t hi_, uint32_t (&dst)[kAhead]) {
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      const uint32_t i = lo_ + (uint32_t)k * 64 + lane;
+      dst[k] = i < hi_ ? rems[i] : kFree;
+    }
+  };
+  uint32_t r = blockIdx.x * kWavesPerWg + wave;
+  uint32_t lo = 0, hi = 0;
+  if (r < n_regions) {
+    lo = starts[r];
+    hi = starts[r + 1];
+  }
+  uint32_t cur[kAhead];
+  fetch(lo, hi, cur);
+  while (r < n_regions) {   // (wave-uniform)
+    const uint32_t rn = r + n_waves;
+    uint32_t lon = 0, hin = 0;
+    if (rn < n_regions) {
+      lon = starts[rn];
+      hin = starts[rn + 1];
+    }
+    uint32_t nxt[kAhead];
+    if (lo != hi) {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2* g = reinterpret_cast<u64x2*>(table + ((uint64_t)r << REGION_LOG2));
+      const unsigned n_before = n_new;
+      if (PRISTINE) {
+#pragma unroll
+        for (int k = 0; k < kSlots / 4 / 64; ++k) reinterpret_cast<uint4*>(region)[k * 64 + lane] = uint4{kFree, kFree, kFree, kFree};
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < kPairs; ++k) {
+          const u64x2 key = g[k * 64 + lane];
+          uint32_t v[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint64_t h = hash48(key[q]);
+            v[q] = key[q] == kEmpty ? kFree : (((uint32_t)(h >> 32) == r && (uint32_t)h < kForeign) ? (uint32_t)h : kForeign);
+          }
+          reinterpret_cast<uint2*>(region)[k * 64 + lane] = uint2{v[0], v[1]};
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // (the compiler keeps the order; the LDS keeps a wave's operations in order by itself)
+      fetch(lon, hin, nxt);
+#pragma unroll
+      for (int g = 0; g < kAhead; g += 4) {
+        uint32_t slot[4], old[4];
+        bool has[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t i = lo + (uint32_t)(g + k) * 64 + lane;
+          has[k] = i < hi && usable(r, cur[g + k]);
+          slot[k] = cur[g + k] >> (32 - REGION_LOG2);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) old[k] = has[k] ? atomicCAS(&region[slot[k]], kFree, cur[g + k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (has[k]) probe_on(r, cur[g + k], slot[k], old[k]);
+      }
+      // a longer run than usual -- possibly MUCH longer (a point that occurs a hundred thousand times: pixels without depth): eight
+      // loads at a time, and a look at the home slot before the swap (the same key again is then a broadcast read, not 64 swaps
+      // of one word in a row)
+      for (uint32_t i0 = lo + kAhead * 64 + lane; i0 < hi + lane; i0 += 8 * 64) {   // (wave-uniform trip count)
+        uint32_t more[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) more[k] = i0 + k * 64 < hi ? rems[i0 + k * 64] : kFree;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (i0 + k * 64 < hi && usable(r, more[k])) {
+            const uint32_t s = more[k] >> (32 - REGION_LOG2);
+            if (region[s] != more[k]) probe_on(r, more[k], s, atomicCAS(&region[s], kFree, more[k]));
+          }
+        }
+      }
+      r3d_vox::lds_settle();
+      __builtin_amdgcn_wave_barrier();
+      if (PRISTINE || __any(n_new != n_before)) {   // (a table that is not fresh: only a piece that gained a key goes back)
+#pragma unroll
+        for (int k = 0; k < kPairs; ++k) {
+          const uint2 v = reinterpret_cast<const uint2*>(region)[k * 64 + lane];
+          u64x2 out;
+          out.x = v.x == kFree ? kEmpty : unhash48(((uint64_t)r << 32) | v.x);
+          out.y = v.y == kFree ? kEmpty : unhash48(((uint64_t)r << 32) | v.y);
+          if (!PRISTINE && (v.x == kForeign || v.y == kForeign)) {
+            const u64x2 was = g[k * 64 + lane];
+            if (v.x == kForeign) out.x = was.x;
+            if (v.y == kForeign) out.y = was.y;
+          }
+          __builtin_nontemporal_store(out, g + k * 64 + lane);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      fetch(lon, hin, nxt);
+    }
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) cur[k] = nxt[k];
+    r = rn;
+    lo = lon;
+    hi = hin;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off, 64);
+    n_over += __shfl_down(n_over, off, 64);
+  }
+  __syncthreads();   // the pieces are done with: two of their words take the workgroup's counts
+  unsigned* wg_count = region_all[0];
+  if (threadIdx.x < 2) wg_count[threadIdx.x] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    if (n_new) atomicAdd(&wg_count[0], n_new);
+    if (n_over) atomicAdd(&wg_count[1], n_over);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) partials[2 * (uint64_t)blockIdx.x + threadIdx.x] = wg_count[threadIdx.x];
+}
+
 // the deferred keys, by the ordinary CAS (their count is known on the device only: fixed grid, device-side bound).  The list may
 // hold one key very many times (the points a first-pass segment had no room for: e.g. every pixel without depth of a frame is
 // the same point): a probe LOOKS before it swaps, so that those end as reads of a cached line instead of queueing at one address.
@@ -1422,7 +1584,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     uint32_t* rem_b = static_cast<uint32_t*>(b_v);
     uint8_t* hi_b = reinterpret_cast<uint8_t*>(static_cast<char*>(b_v) + up(seg_elems * 4));
     const unsigned merge_grid = (unsigned)ctx->num_cus * 8;   // (1536 .. 4096 workgroups measured within 3 % of each other)
-    const size_t partial_bytes = up((size_t)merge_grid * 2 * sizeof(unsigned long long));
+    const size_t partial_bytes = up((size_t)merge_grid * 2 * 2 * sizeof(unsigned long long));   // (the wave form's grid is twice merge_grid)
     const size_t starts_bytes = up(((size_t)kPieces + 2) * sizeof(uint32_t));
     const size_t hist_bytes = up((size_t)256 * stride * sizeof(uint32_t));
     const size_t count_bytes = up((size_t)kSegments * kCursorStride * sizeof(uint32_t));   // the segments' cursors, a line each
@@ -1461,7 +1623,16 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
   hipLaunchKernelGGL((voxel_merge32_kernel<L2, PR>), dim3(merge_blocks), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,        \
                      (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials)
     const bool narrow = sub_log2 == 0;   // regions are pieces: 32-bit slots in LDS (same-process A/B against the 64-bit form: 385-397 -> 359-362 us)
-    if (narrow && region_log2 == 11) { if (pristine) R3D_LAUNCH_MERGE32(11, true); else R3D_LAUNCH_MERGE32(11, false); }
+    unsigned wave_grid = 0;   // tables of 2^27 slots: a piece per wave (voxel_merge32w_kernel)
+    if (narrow && region_log2 == 11) {
+      wave_grid = (unsigned)ctx->num_cus * 16;
+      if (pristine)
+        hipLaunchKernelGGL((voxel_merge32w_kernel<11, true>), dim3(wave_grid), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
+                           (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials);
+      else
+        hipLaunchKernelGGL((voxel_merge32w_kernel<11, false>), dim3(wave_grid), dim3(kThreads), 0, ctx->stream, (const uint32_t*)rem_a,
+                           (const uint32_t*)d_starts, n_regions, vs->d_table, d_spill, d_spill_count, (unsigned long long)spill_cap, d_partials);
+    }
     else if (narrow && region_log2 == 12) { if (pristine) R3D_LAUNCH_MERGE32(12, true); else R3D_LAUNCH_MERGE32(12, false); }
     else if (narrow) { if (pristine) R3D_LAUNCH_MERGE32(13, true); else R3D_LAUNCH_MERGE32(13, false); }
     else if (sub_log2 > 0) R3D_LAUNCH_MERGE(11, true);       // tables below 2^27 slots: several pieces per 2048-slot region
@@ -1472,7 +1643,7 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
 #undef R3D_LAUNCH_MERGE32
     hipLaunchKernelGGL(voxel_spill_kernel, dim3((unsigned)ctx->num_cus), dim3(kThreads), 0, ctx->stream, (const uint64_t*)d_spill,
                        (const unsigned long long*)d_spill_count, (unsigned long long)spill_cap, vs->d_table, vs->log2cap, vs->d_counters,
-                       (const unsigned long long*)d_partials, (int)merge_blocks, (const uint32_t*)d_flags);
+                       (const unsigned long long*)d_partials, (int)(wave_grid ? wave_grid : merge_blocks), (const uint32_t*)d_flags);
     R3D_HIP(hipGetLastError());
   }
   return R3D_OK;
