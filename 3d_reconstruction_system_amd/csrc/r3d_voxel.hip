@@ -1588,21 +1588,21 @@ static int insert_sorted(r3d_voxelset* vs, const float* d_xyz, int64_t n_points)
     const size_t starts_bytes = up(((size_t)kPieces + 2) * sizeof(uint32_t));
     const size_t hist_bytes = up((size_t)256 * stride * sizeof(uint32_t));
     const size_t count_bytes = up((size_t)kSegments * kCursorStride * sizeof(uint32_t));   // the segments' cursors, a line each
-    if ((rc = r3d_scratch(ctx, 5, 256 + partial_bytes + starts_bytes + hist_bytes + 1024 + count_bytes + spill_cap * 8, &ws))) return rc;
+    if ((rc = r3d_scratch(ctx, 5, partial_bytes + starts_bytes + hist_bytes + 1024 + 256 + count_bytes + spill_cap * 8, &ws))) return rc;
     char* w = static_cast<char*>(ws);
-    unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(w + 32);
-    uint32_t* d_flags = reinterpret_cast<uint32_t*>(w + 64);   // [2..3] points without a key
-    unsigned long long* d_partials = reinterpret_cast<unsigned long long*>(w + 256);
-    uint32_t* d_starts = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes);
-    uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes);
-    uint32_t* totals_hi = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes);
-    uint32_t* d_cursors = reinterpret_cast<uint32_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes + 1024);
-    uint64_t* d_spill = reinterpret_cast<uint64_t*>(w + 256 + partial_bytes + starts_bytes + hist_bytes + 1024 + count_bytes);
-    R3D_HIP(hipMemsetAsync(w + 32, 0, 64, ctx->stream));   // the deferred keys' count and the flags
+    unsigned long long* d_partials = reinterpret_cast<unsigned long long*>(w);
+    uint32_t* d_starts = reinterpret_cast<uint32_t*>(w + partial_bytes);
+    uint32_t* hist_hi = reinterpret_cast<uint32_t*>(w + partial_bytes + starts_bytes);
+    uint32_t* totals_hi = reinterpret_cast<uint32_t*>(w + partial_bytes + starts_bytes + hist_bytes);
+    char* zeroed = w + partial_bytes + starts_bytes + hist_bytes + 1024;   // one memset: the deferred keys' count, the flags, the cursors
+    unsigned long long* d_spill_count = reinterpret_cast<unsigned long long*>(zeroed);
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(zeroed + 64);   // [2..3] points without a key
+    uint32_t* d_cursors = reinterpret_cast<uint32_t*>(zeroed + 256);
+    uint64_t* d_spill = reinterpret_cast<uint64_t*>(zeroed + 256 + count_bytes);
+    R3D_HIP(hipMemsetAsync(zeroed, 0, 256 + count_bytes, ctx->stream));
     // |x| < safe_abs  =>  |factor x| < 32767: every key in range whatever the rounding of the fp64 product (a bound strictly
     // inside the map's edge 32768 / factor, rounded towards zero and shrunk by 2^-20 on top)
     const float safe_abs = nextafterf((float)((32767.0 / vs->factor) * (1.0 - 1.0 / 1048576.0)), 0.0f);
-    R3D_HIP(hipMemsetAsync(d_cursors, 0, count_bytes, ctx->stream));
     const unsigned bin_grid = (unsigned)((n_tiles1 + 7) / 8 * 8);   // a tile each (a multiple of 8: see the kernel)
     hipLaunchKernelGGL(voxel_bin_kernel, dim3(bin_grid), dim3(kBinThreads), 0, ctx->stream, src, m, vs->factor, safe_abs, (int)n_tiles1,
                        plan.cap, rem_b, hi_b, d_cursors, d_spill, d_spill_count, (unsigned long long)spill_cap, d_flags);
