@@ -939,6 +939,7 @@ __global__ __launch_bounds__(kThreads) void voxel_merge32_kernel(const uint32_t*
 // serves a wave's operations in the order it issued them), four independent pieces in flight per workgroup and twenty per CU, the
 // next piece's bounds and remainders requested a piece ahead.  The workgroup form above spends a third of its time on the loop's
 // skeleton -- three barriers per piece, each waiting for the slowest of four waves' probe chains: 303-330 -> 250-275 us, same process.
+// (One loop for a group's four re-probe chains instead of four loops, four swaps in flight per step: 257 -> 300 us.  Not kept.)
 // PRISTINE = false: the piece's slots come in from the table first; a slot that holds a key of ANOTHER piece (kForeign) is read
 // again on the way out -- rare, so nothing is kept in registers for it.
 template <int REGION_LOG2, bool PRISTINE>
