@@ -231,7 +231,7 @@ using r3d_vox::unhash48;
 // ---- the sort's front half without a histogram in front of the first pass ------------------------------------------------------
 // A radix pass needs every (tile, bin) offset before it can write, so the first pass above costs a round trip of the elements
 // through HBM: the key kernel writes them (6 B/point) for the scatter to read back (6 B/point) once the scan is done.  The first
-// pass does not have to be dense, though, nor in any order.  Here every bin has one SEGMENT per XCD, with room for 1.25 x what
+// pass does not have to be dense, though, nor in any order.  Here every bin has one SEGMENT per XCD, with room for 1.125 x what
 // a hash spreads into it, and a cursor: a tile's workgroup turns its points into keys, ranks them by lo, takes room for each of
 // its 256 runs with one returning add on the cursor of (lo, its XCD) and writes -- 12 B/point in, 5 out, nothing in between.  The
 // workgroups that share a cursor run on one XCD: runs taken one after the other lie side by side and the lines they share are
@@ -254,17 +254,46 @@ struct SegPlan {
 static SegPlan seg_plan(int64_t n_points) {
   SegPlan p;
   const int64_t mean = (n_points + kSegments - 1) / kSegments;
-  p.chunks = (int)((mean + mean / 4 + 1024 + kSortTile - 1) / kSortTile);
+  p.chunks = (int)((mean + mean / 8 + 1024 + kSortTile - 1) / kSortTile);   // (C2: 24 000 +- 155 elements per segment, room for 28 672)
   p.cap = p.chunks * kSortTile;
   p.n_tiles2 = kSegments * p.chunks;
   return p;
 }
 
+constexpr int kBinThreads = 512;
+constexpr int kBinRounds = kSortTile / kBinThreads;
+// voxel_bin_kernel's rare way out, kept out of line so that it costs the kernel no registers: a segment is full (keys that crowd
+// into one bin), the tile's elements that found no room go to the deferred list -- with ONE add on the list's counter per tile (a
+// point that occurs millions of times would otherwise queue a hundred thousand adds at that one address, 11 ns each: C2's cloud
+// with a fifth of its pixels without depth spent 0.9 ms there).  Called by all threads of the workgroup.
+__device__ __attribute__((noinline)) void defer_full_segments(const uint2* s_el, const uint32_t* s_base, uint32_t* s_defer, int n_live, int cap,
+                                                              uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_count,
+                                                              unsigned long long spill_cap) {
+  if (threadIdx.x == 0) s_defer[0] = 0;
+  __syncthreads();
+  uint32_t n_mine = 0;
+  for (int j = threadIdx.x; j < n_live; j += kBinThreads) n_mine += s_base[s_el[j].y & 0xff] + (uint32_t)j >= (uint32_t)cap ? 1u : 0u;
+  uint32_t at = n_mine ? atomicAdd(&s_defer[0], n_mine) : 0u;   // this thread's places among the tile's deferred keys
+  r3d_vox::lds_settle();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long first = atomicAdd(spill_count, (unsigned long long)s_defer[0]);
+    s_defer[1] = (uint32_t)first;
+    s_defer[2] = (uint32_t)(first >> 32);
+  }
+  __syncthreads();
+  const unsigned long long first = (unsigned long long)s_defer[1] | ((unsigned long long)s_defer[2] << 32);
+  for (int j = threadIdx.x; j < n_live; j += kBinThreads) {
+    const uint2 el = s_el[j];
+    if (s_base[el.y & 0xff] + (uint32_t)j < (uint32_t)cap) continue;
+    if (first + at < spill_cap) spill[first + at] = unhash48(((uint64_t)(el.y & 0xffffu) << 32) | el.x);   // el.y = lo | hi << 8: h48's top 16 bits
+    ++at;
+  }
+}
+
 // flags[2..3]: points without a key (64 bits; added to the set's counter by voxel_spill_kernel).  cursors[(lo * 8 + xcd) * kCursorStride]: elements in the segment (may exceed cap: clamp).
 // 512 threads, eight points each: the kernel waits for latencies in turn (points, LDS adds, the cursor, the stores), so it wants
 // waves -- four workgroups of eight per CU fill it (256 threads x 16 points: five of four, 20 of 32 wave slots, 272 -> ... us).
-constexpr int kBinThreads = 512;
-constexpr int kBinRounds = kSortTile / kBinThreads;
 __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
                                                                    int n_tiles, int cap, uint32_t* __restrict__ seg_rem,
                                                                    uint8_t* __restrict__ seg_hi, uint32_t* __restrict__ cursors,
@@ -273,7 +302,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
   constexpr int kBins = r3d_sort::kBins;
   __shared__ uint2 s_el[kSortTile];   // the tile in bin order: rem, lo | hi << 8 (one LDS write and one read per element)
   __shared__ uint32_t s_base[kBins];
-  __shared__ uint32_t bin_count[kBins], bin_start[kBins], wave_sum[4];
+  __shared__ uint32_t bin_count[kBins], bin_start[kBins], wave_sum[4], s_defer[3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int xcd = blockIdx.x & (kXcds - 1);   // (workgroups go round the XCDs; nothing but locality depends on it)
   unsigned n_ignored = 0;
@@ -391,18 +420,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* 
         full_seg = true;
       }
     }
-    if (__any(full_seg)) {   // a segment is full (keys that crowd into one bin): the deferred way in, one counter add per wave and round
-      for (int j = threadIdx.x; j < n_live; j += kBinThreads) {
-        const uint2 el = s_el[j];
-        if (s_base[el.y & 0xff] + (uint32_t)j < (uint32_t)cap) continue;
-        const unsigned long long peers = __ballot(1);
-        const int leader = (int)__ffsll((long long)peers) - 1;
-        unsigned long long first = 0;
-        if (lane == leader) first = atomicAdd(spill_count, (unsigned long long)__popcll(peers));
-        first = __shfl(first, leader, 64) + __popcll(peers & ((1ull << lane) - 1));
-        if (first < spill_cap) spill[first] = unhash48(((uint64_t)(el.y & 0xffffu) << 32) | el.x);   // el.y = lo | hi << 8: h48's top 16 bits
-      }
-    }
+    if (__syncthreads_or(full_seg)) defer_full_segments(s_el, s_base, s_defer, n_live, cap, spill, spill_count, spill_cap);   // (uniform)
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_ignored += __shfl_down(n_ignored, off, 64);
@@ -1116,6 +1134,8 @@ __global__ __launch_bounds__(kThreads) void voxel_spill_kernel(const uint64_t* _
   }
   for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kThreads) {
     const uint64_t key = spill[i];
+    const uint64_t prev = prev_lane_u64(key);   // (by every lane of the iteration: a lane switched off would hand its neighbour that neighbour's own key)
+    if ((threadIdx.x & 63) > 0 && prev == key) continue;   // a full segment defers the same key wave after wave: the previous lane inserts it
     uint64_t slot = r3d_vox::home_slot(key, log2cap);
     int r = -1;
     for (uint64_t probe = 0; probe <= mask; ++probe) {

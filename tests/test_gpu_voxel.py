@@ -551,7 +551,7 @@ def test_sort_merge_into_a_crowded_2_27_slot_table_agrees_with_the_cas_path(V, c
 
 @pytest.mark.parametrize("kind", ["eight_voxels", "hot_point", "one_bin_heavy", "tiny"])
 def test_sort_merge_first_pass_segments_that_fill_up(V, ctx, kind):
-    """The first pass writes into per-XCD bin segments sized for hashed keys (1.25 x the mean + 1024): keys that crowd into a
+    """The first pass writes into per-XCD bin segments sized for hashed keys (1.125 x the mean + 1024): keys that crowd into a
     bin must go in through the deferred list instead.  eight_voxels: 2 M points alternating between eight voxels (the
     neighbour-lane test removes nothing; every segment in use overflows many times over); hot_point: a cloud of distinct
     voxels with a fifth of its points at ONE place, scattered (pixels without depth end at the camera centre); one_bin_heavy:
