@@ -229,9 +229,10 @@ using r3d_vox::kMask48;
 using r3d_vox::unhash48;
 
 // ---- the sort's front half without a histogram in front of the first pass ------------------------------------------------------
-// A radix pass needs every (tile, bin) offset before it can write, so the first pass above costs a round trip of the elements
-// through HBM: the key kernel writes them (6 B/point) for the scatter to read back (6 B/point) once the scan is done.  The first
-// pass does not have to be dense, though, nor in any order.  Here every bin has one SEGMENT per XCD, with room for 1.125 x what
+// A dense radix pass needs every (tile, bin) offset before it can write: a histogram in front of it, i.e. a round trip of the
+// elements through HBM -- whoever makes the keys writes them (6 B/point) for the scatter to read back (6 B/point) once the scan
+// is done (this round's first form: voxel_keys_kernel + piece_scatter_kernel<1>, 372 us of the insert's 930).  The first pass does
+// not have to be dense, though, nor in any order.  Here every bin has one SEGMENT per XCD, with room for 1.125 x what
 // a hash spreads into it, and a cursor: a tile's workgroup turns its points into keys, ranks them by lo, takes room for each of
 // its 256 runs with one returning add on the cursor of (lo, its XCD) and writes -- 12 B/point in, 5 out, nothing in between.  The
 // workgroups that share a cursor run on one XCD: runs taken one after the other lie side by side and the lines they share are
@@ -293,7 +294,7 @@ __device__ __attribute__((noinline)) void defer_full_segments(const uint2* s_el,
 
 // flags[2..3]: points without a key (64 bits; added to the set's counter by voxel_spill_kernel).  cursors[(lo * 8 + xcd) * kCursorStride]: elements in the segment (may exceed cap: clamp).
 // 512 threads, eight points each: the kernel waits for latencies in turn (points, LDS adds, the cursor, the stores), so it wants
-// waves -- four workgroups of eight per CU fill it (256 threads x 16 points: five of four, 20 of 32 wave slots, 272 -> ... us).
+// waves -- four workgroups of eight per CU fill it (256 threads x 16 points: five of four, 20 of 32 wave slots: 272 -> 252 us).
 __global__ __launch_bounds__(kBinThreads, 8) void voxel_bin_kernel(const float* __restrict__ xyz, int64_t n, double factor, float safe_abs,
                                                                    int n_tiles, int cap, uint32_t* __restrict__ seg_rem,
                                                                    uint8_t* __restrict__ seg_hi, uint32_t* __restrict__ cursors,
