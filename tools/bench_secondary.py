@@ -225,11 +225,24 @@ def secondary(a):
         # algorithmic bytes of a set insert: every point read once (12 B), every distinct voxel written once (8 B)
         alg = n * 12 + st["voxels"] * 8
         gbs = alg / ms / 1e6
+        # HBM bytes of one insert: a RECORDED figure (rocprofv3 --pmc passes over tools/voxel_sort_once.py, the same cloud and table:
+        # tools/collect_voxel_profile.sh), given only when that profile's cloud is this one
+        traffic, traffic_source = None, None
+        try:
+            import glob
+            rec_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_voxel_stage_pmc.json")))[-1]
+            rec = json.load(open(rec_path))
+            if rec.get("algorithmic_bytes") == alg:
+                traffic = int(rec["hbm_bytes_per_insert"])
+                traffic_source = "recorded: %s (FETCH_SIZE x 2 + WRITE_SIZE per stage)" % os.path.relpath(rec_path, ROOT)
+        except Exception:
+            pass
         line = {"metric": "Mpoints/s voxel insert (C2 cloud, 0.1 m, worst case ~1 voxel per point)", "value": round(n / ms / 1e3, 1),
                 "unit": "Mpoints/s", "voxels": st["voxels"], "kernel_ms": round(ms, 4), "paths": per_path,
                 "table_slots": 1 << int(np.ceil(np.log2(2 * n))),
                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                             "algorithmic_bytes_per_launch": alg,
                              "kernel": "voxel_bin_kernel + segment_histogram_kernel + segment_scatter_kernel + voxel_merge32_kernel "
                                        "(sort-merge insert: 17 + 1 + 9 + 4 B/point of streams + 8 B per table slot; "
                                        "the CAS path is bound by scattered 64-bit atomics at ~19 G/s instead)",
