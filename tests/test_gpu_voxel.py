@@ -598,6 +598,34 @@ def test_sort_merge_first_pass_segments_that_fill_up(V, ctx, kind):
         d_xyz.free()
 
 
+def test_sort_merge_insert_of_more_than_one_chunk_agrees_with_the_cas_path(V, ctx):
+    """The sort-merge insert walks a cloud in chunks of 2^27 points (its scratch is sized for one): 2^27 + 3 M points, nearly all
+    in voxels of their own, into a table of 2^29 slots -- the second chunk meets a table that is no longer fresh (the workgroup
+    form of the 32-bit merge, 8192-slot pieces).  No CPU oracle at this size: the CAS path's set of the same cloud is the check."""
+    rng = np.random.default_rng(29)
+    n = (1 << 27) + 3_000_000
+    pts = rng.random((n, 3), dtype=np.float32)
+    pts *= np.float32(900.0)
+    pts -= np.float32(450.0)
+    d_xyz = ctx.alloc(n * 12).upload(pts)
+    del pts
+    a, b = V.VoxelSet(0.1, 1 << 29, ctx), V.VoxelSet(0.1, 1 << 29, ctx)
+    try:
+        ctx.set_tuning("voxel_path", 2)
+        a.insert_device(d_xyz.ptr, n)
+        assert ctx.get_tuning("voxel_last_path") == 2
+        ctx.set_tuning("voxel_path", 1)
+        b.insert_device(d_xyz.ptr, n)
+        sa, sb = a.stats(), b.stats()
+        assert sa == sb and sa["overflow"] == 0 and sa["voxels"] > 0.9 * n, (sa, sb)
+        np.testing.assert_array_equal(a.codes(), b.codes())
+    finally:
+        ctx.set_tuning("voxel_path", 0)
+        a.close()
+        b.close()
+        d_xyz.free()
+
+
 def test_sort_merge_insert_on_a_nearly_full_table_spills_and_still_agrees(V, ctx):
     """load factor 0.93: long probe runs cross region boundaries all the time (thousands of deferred keys), some keys were
     CAS-placed in the NEXT region before -- and the set is still the oracle's; a table that is too small reports overflow"""
