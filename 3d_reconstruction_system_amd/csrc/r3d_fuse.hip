@@ -855,7 +855,7 @@ int r3d_fuse_frames_voxel(r3d_ctx* ctx, const r3d_camera* cam, const void* d_dep
   int rc = fuse_common(ctx, cam, d_depth, depth_dtype, f0, depth_scale, d_pose, with_pose, d_xyz_out, R3D_F32, d_rgb, d_rgba_out);
   if (rc) return rc;
   bool sort = path == 2;
-  if (!sort && (rc = r3d_voxelset_sample(vs, d_xyz_out, hw * f0, &sort))) return rc;
+  if (!sort && (rc = r3d_voxelset_sample(vs, d_xyz_out, hw * f0, total, 1.5, &sort))) return rc;
   const size_t dsz = r3d_depth_size(depth_dtype);
   const char* depth_rest = static_cast<const char*>(d_depth) + (size_t)hw * f0 * dsz;
   const double* pose_rest = with_pose ? d_pose + (size_t)f0 * 12 : nullptr;

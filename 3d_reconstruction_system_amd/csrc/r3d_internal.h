@@ -134,7 +134,7 @@ int r3d_voxelset_device_view(r3d_voxelset* vs, r3d_ctx** ctx, double* factor, ui
 
 // the two insert paths of a voxel set, and how a big insert chooses between them (r3d_voxel.hip)
 bool r3d_voxelset_sort_feasible(const r3d_voxelset* vs, int64_t n_points, bool forced);
-int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, bool* sort_out);
+int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int64_t n_insert, double cas_base_ps, bool* sort_out);
 int r3d_voxelset_insert_path(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int path);
 
 // Device -> pageable host memory through pinned staging chunks (r3d_hostpipe.hip); synchronous.

@@ -1547,7 +1547,7 @@ int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points) 
     path = 2;
   } else if (vs->ctx->voxel_path == 0 && r3d_voxelset_sort_feasible(vs, n_points, false)) {
     bool sort = false;
-    if ((rc = r3d_voxelset_sample(vs, d_xyz, n_points, &sort))) return rc;
+    if ((rc = r3d_voxelset_sample(vs, d_xyz, n_points, n_points, 4.5, &sort))) return rc;
     path = sort ? 2 : 1;
   }
   return r3d_voxelset_insert_path(vs, d_xyz, n_points, path);
@@ -1564,9 +1564,15 @@ bool r3d_voxelset_sort_feasible(const r3d_voxelset* vs, int64_t n_points, bool f
   return n_points >= ((int64_t)1 << 22) && vs->capacity <= (uint64_t)n_points * 16;
 }
 
-// *sort_out = the sample says most points have a voxel of their own (>= 1 distinct voxel per 2 points among neighbours):
-// the CAS path would pay a random HBM access for nearly every point.  Synchronises the stream (16 bytes come back).
-int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, bool* sort_out) {
+// *sort_out = by the sample, the sort-merge insert of `n_insert` points into this set's table will be the faster one.  The sample
+// gives r = distinct voxels per point among neighbours (256 groups of 4096 consecutive points); the two paths' costs on this chip,
+// from tools/voxel_path_crossover.py and the stage profiles (round 5):
+//   sort-merge   7.5 ps per point (both passes) + 2 ps per table slot (the merge streams the whole table) + 40 us of launches;
+//   LDS set + CAS   (4.5 + 62 r) ps per point -- 66 ps for a voxel per point (3.26 ms for C2), 6.7 ps at 28 points per voxel;
+//   `cas_base_ps`: the 4.5 (r3d_fuse_frames_voxel's one-launch kernel does not read the cloud back: 1.5).
+// Rounds 2-5 asked for >= 1 distinct voxel per 2 points, which left clouds of 2.7 / 5 / 10 points per voxel with the CAS path
+// at 1.55 / 0.97 / 0.62 ms where the sort-merge path takes 0.52 / 0.50 / 0.49.  Synchronises the stream (16 bytes come back).
+int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, int64_t n_insert, double cas_base_ps, bool* sort_out) {
   *sort_out = false;
   r3d_ctx* ctx = vs->ctx;
   const int64_t n_tiles = (n_points + kThreads * 4 - 1) / (kThreads * 4);
@@ -1582,7 +1588,12 @@ int r3d_voxelset_sample(r3d_voxelset* vs, const float* d_xyz, int64_t n_points, 
   unsigned long long h[2] = {0, 0};
   R3D_HIP(hipMemcpyAsync(h, d_sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   R3D_HIP(hipStreamSynchronize(ctx->stream));
-  *sort_out = h[0] > 0 && 2 * h[1] >= h[0];
+  if (h[0] > 0) {
+    const double r = (double)h[1] / (double)h[0];
+    const double us_sort = (double)n_insert * 7.5e-6 + (double)vs->capacity * 2.0e-6 + 40.0;
+    const double us_cas = (double)n_insert * (cas_base_ps + 62.0 * r) * 1e-6;
+    *sort_out = us_sort < us_cas;
+  }
   return R3D_OK;
 }
 

@@ -442,7 +442,8 @@ int r3d_voxelset_clear(r3d_voxelset* vs);
  *      access to HBM: for clouds where nearly every point has a voxel of its own (2-3x faster there; needs a table of
  *      2^16..2^29 slots).
  * Tuning key "voxel_path": 0 (default) = inserts of >= 2^22 points into a table of <= 16 slots per point are SAMPLED first
- * (256 groups of 4096 neighbouring points; path 2 when they show >= 1 distinct voxel per 2 points) -- that sample
+ * (256 groups of 4096 neighbouring points: distinct voxels per point; path 2 when its cost -- per point and per table slot -- comes
+ * out below path 1's, which on a 2-slots-per-point table is the case below ~7 points per voxel among neighbours) -- that sample
  * synchronises the stream once (16 bytes come back); smaller inserts take path 1 without asking.  1 / 2 force a path
  * (asynchronous).  "voxel_last_path" reads back which one the last insert took. */
 int r3d_voxelset_insert(r3d_voxelset* vs, const float* d_xyz, int64_t n_points);

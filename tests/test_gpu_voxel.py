@@ -708,3 +708,26 @@ def test_the_library_picks_the_path_by_sampling_the_cloud(V, ctx, kind):
         finally:
             ctx.set_tuning("voxel_path", 0)
         assert st["voxels"] == len(want)
+
+
+@pytest.mark.parametrize("res,expect", [(0.5, 2), (3.0, 1)])
+def test_surfaces_with_a_few_points_per_voxel_take_the_sort_merge_path(V, ctx, res, expect):
+    """The choice is a cost estimate, not a fixed ratio: slanted planes whose neighbouring points share voxels a little (2.7
+    points per voxel at 0.5 m) are 3x faster through the sort-merge path and must take it; the same cloud at 3 m voxels (tens of
+    points per voxel) stays with the LDS-set kernel.  Either way the set is the oracle's.  (tools/voxel_path_crossover.py)"""
+    F, H, W = 12, 384, 1280
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = np.stack([np.clip(40 + (xx // 8 + yy // 6 + 3 * f) % 200, 1, 255) for f in range(F)]).astype(np.uint8)
+    q, t = rng.normal(size=(F, 4)), rng.normal(size=(F, 3))
+    d_xyz = fuse_on_device(ctx, depth, q, t, _r3d().REF_INTRINSICS)
+    vs = V.VoxelSet(res, 1 << 24, ctx)
+    try:
+        vs.insert_device(d_xyz.ptr, F * H * W)
+        assert ctx.get_tuning("voxel_last_path") == expect
+        want, dropped = OM.occupied_set(d_xyz.download(np.float32, F * H * W * 3).reshape(-1, 3), res)
+        assert vs.stats() == {"voxels": len(want), "ignored_points": dropped, "overflow": 0}
+        np.testing.assert_array_equal(vs.codes(), want)
+    finally:
+        vs.close()
+        d_xyz.free()
